@@ -1,0 +1,218 @@
+#!/usr/bin/env python3
+"""bench.py — augmented-Lagrangian inner iterations/s of the SDPLR+ hot path on MI355X.
+
+One "step" = one pass of the inner `while` body of _sdplr (src/sdplr.jl:190-278): L-BFGS direction,
+exact line search (two 𝒜 passes), R += αD, g! (S assembly + SpMM), norms, L-BFGS update — on the
+north-star instance of BASELINE.json configs[1]: MaxCut on G(n = 1e5, p = 2e-4), r = 32, FP64,
+h = 4, σ = σ₀ = 2 fixed, no early exit (gtol = 0, fprec = −∞), all state resident in HBM.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+N > 1: independent replicas of the instance (graph seed + rank), one process per GPU, no data-path
+collective; RCCL only gathers the objectives at the end.  value = N·K / max-over-ranks time.
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import sdplrplus_jl_amd as sj  # noqa: E402
+from sdplrplus_jl_amd import problems  # noqa: E402
+
+HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured streaming)
+N_NODES, P_EDGE, RANK_R, GRAPH_SEED, R_SEED = 100_000, 2e-4, 32, 20240610, 0
+
+
+def algorithmic_bytes(d, h):
+    """Compulsory bytes per launch of each kernel family and per inner iteration:
+    each distinct input read once, each output written once; 8-B values, 4-B indices."""
+    n, m, r, nnzT, nnzS, nnzAgg = d["n"], d["m"], d["r"], d["nnzT"], d["nnzS"], d["nnzAgg"]
+    N = 8 * n * r
+    A_sparse = 4 * (n + 1) + 4 * nnzT + 12 * nnzAgg + 8 * (m + 1)
+    per_kernel = {
+        "lbfgs_dir": (2 * h + 1) * N + 2 * N,
+        "lbfgs_update": 5 * N,
+        "sddmm_linesearch": 2 * N + 4 * (n + 1) + 4 * nnzT,          # R, D rows + pattern (both 𝒜 passes fused)
+        "segreduce": 2 * (8 * nnzT + 12 * nnzAgg + 8 * (m + 1)),
+        "axpy_R": 3 * N,
+        "assemble_triu": 12 * nnzAgg + 8 * (m + 1) + 8 * nnzT,
+        "assemble_full": 4 * nnzS + 8 * nnzT + 8 * nnzS,
+        "spmm": 2 * N + 4 * (n + 1) + 12 * nnzS,
+    }
+    b_iter = ((2 * h + 1) * N + 2 * N      # lbfgs_dir!
+              + 2 * N                      # dot(dirt, Gt)
+              + 2 * N + A_sparse           # 𝒜!(A_RD; Rt, Dt)
+              + N + A_sparse               # 𝒜!(A_DD; Dt, Dt)
+              + 6 * 8 * m                  # line-search scalar stage
+              + 3 * N                      # axpy!
+              + 8 * 4 * (m + 1) + 12 * nnzAgg + 8 * nnzT + 4 * nnzS + 8 * nnzT + 8 * nnzS  # copy2y + S assembly
+              + 2 * N + 4 * (n + 1) + 12 * nnzS   # SpMM
+              + N                          # norm(Gt)
+              + 5 * N)                     # lbfgs_update!
+    return per_kernel, b_iter
+
+
+def build_instance(abi, graph_seed):
+    A = problems.gnp_graph(N_NODES, P_EDGE, graph_seed)
+    data = problems.maxcut_data(A)
+    cfg = sj.BurerMonteiroConfig(seed=R_SEED, printlevel=0)
+    var = sj.build_solver(abi, data, RANK_R, cfg)
+    return data, var
+
+
+def run_fixed(var, normC, normb, state, iters):
+    """`iters` inner iterations at fixed σ with every exit test disabled except the iteration budget."""
+    out = var.inner_loop(normC, normb, True, True, False, 0.0, -1e300, iters, 0.0, *state)
+    if out[4] != iters:
+        raise RuntimeError(f"inner loop stopped after {out[4]} of {iters} iterations (exit {out[5]})")
+    return out[:3]
+
+
+def cpu_baseline(data, budget_s=20.0):
+    """The oracle (CPU restatement, single thread — the reference's own protocol, exps/test.jl:46)
+    on the same instance: fg!, 2 warm-up iterations, then as many inner iterations as fit the budget."""
+    from oracle import oracle
+    cfg = sj.BurerMonteiroConfig(seed=R_SEED, printlevel=0)
+    o = sj.build_solver(oracle.abi(), data, RANK_R, cfg)
+    normC, normb = data.normC(), float(np.linalg.norm(data.b))
+    st = o.fg(normC, normb)
+    t0 = time.perf_counter()
+    st = run_fixed(o, normC, normb, st, 2)
+    per = (time.perf_counter() - t0) / 2
+    k = int(max(3, min(200, budget_s / max(per, 1e-6))))
+    t0 = time.perf_counter()
+    run_fixed(o, normC, normb, st, k)
+    dt = time.perf_counter() - t0
+    o.close()
+    return {"value": k / dt, "unit": "iterations/s", "cores": 1, "kind": "port",
+            "sample": f"same MaxCut G(1e5,2e-4) r=32 instance, {k} inner iterations after fg! + 2 warm-up iterations"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    K, W = max(args.steps, 1), max(args.warmup, 1)
+
+    abi = sj.load_hip()  # no fallback: raises if the HIP library is missing
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if abi.set_device(local_rank) != 0:
+        raise RuntimeError((abi.last_error(None) or b"set_device failed").decode())
+
+    def barrier():
+        abi.device_synchronize()
+        if dist is not None:
+            import torch
+            torch.cuda.synchronize()
+            dist.barrier()
+
+    data, var = build_instance(abi, GRAPH_SEED + rank)
+    dims = var.dims()
+    normC, normb = data.normC(), float(np.linalg.norm(data.b))
+    h = var.h
+    per_kernel_bytes, b_iter = algorithmic_bytes(dims, h)
+
+    state = var.fg(normC, normb)
+    # warm-up (untimed), with every kernel family timed by hipEvents to find the dominant one
+    var.profile_enable(True)
+    state = run_fixed(var, normC, normb, state, W)
+    prof_all = var.profile()
+    dominant = max(per_kernel_bytes, key=lambda k: prof_all.get(k, (0, 0.0))[1])
+    var.profile_enable(True)          # reset counters
+    var.profile_filter(dominant)      # timed region: only the dominant kernel carries an event pair
+
+    barrier()
+    t0 = time.perf_counter()
+    state = run_fixed(var, normC, normb, state, K)
+    barrier()
+    dt = time.perf_counter() - t0
+
+    launches, dom_ms = var.profile().get(dominant, (0, 0.0))
+    var.profile_enable(False)
+    obj = var.obj
+
+    dt_max = dt
+    objs = [obj]
+    if dist is not None:
+        import torch
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt_max = float(t.item())
+        o = torch.tensor([obj], dtype=torch.float64, device="cuda")
+        gathered = [torch.zeros_like(o) for _ in range(world)]
+        dist.all_gather(gathered, o)          # RCCL: the only collective of the workload (objectives)
+        objs = [float(x.item()) for x in gathered]
+
+    if rank == 0:
+        its = world * K / dt_max
+        avg_s = dom_ms / max(launches, 1) / 1e3
+        achieved = per_kernel_bytes[dominant] / avg_s / 1e9 if avg_s > 0 else 0.0
+        kern = {}
+        for name, (cnt, ms) in sorted(prof_all.items(), key=lambda kv: -kv[1][1]):
+            e = {"launches_per_step": round(cnt / W, 3), "us_per_step": round(1e3 * ms / W, 2)}
+            if name in per_kernel_bytes and cnt:
+                e["algorithmic_MB"] = round(per_kernel_bytes[name] / 1e6, 2)
+                e["GBps"] = round(per_kernel_bytes[name] / (ms / cnt / 1e3) / 1e9, 1)
+            kern[name] = e
+        line = {
+            "metric": "augmented-Lagrangian iters/sec + HBM GB/s, MaxCut n=1e5 r=32",
+            "value": its, "unit": "iterations/s", "n_gpus": world, "steps": K, "warmup": W,
+            "ms_per_step": 1e3 * dt_max / K, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "MaxCut SDP, G(n=1e5, p=2e-4) (BASELINE.json configs[1]), r=32, "
+                                   "h=4 L-BFGS pairs, sigma=2 fixed, one replica per GPU",
+                       "n": dims["n"], "m": dims["m"], "r": dims["r"], "nnzT": dims["nnzT"],
+                       "nnzS": dims["nnzS"], "numlbfgsvecs": h, "graph_seed": GRAPH_SEED},
+            "hbm_GBps_per_gpu_algorithmic": b_iter * (K / dt_max) / 1e9,
+            "bytes_per_iteration_algorithmic": b_iter,
+            "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved,
+                         "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+                         "traffic": load_traffic(dominant),
+                         "algorithmic_bytes_per_launch": per_kernel_bytes[dominant],
+                         "avg_launch_us": 1e6 * avg_s, "launches_timed": launches},
+            "iteration_roofline": {"achieved": b_iter * (K / dt_max) / 1e9, "peak": HBM_PEAK_GBPS,
+                                   "unit": "GB/s", "frac": b_iter * (K / dt_max) / 1e9 / HBM_PEAK_GBPS},
+            "kernels_warmup_profile": kern,
+            "objectives": objs,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(data)
+        print(json.dumps(line), flush=True)
+    var.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def load_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc summary (profiles/), or null."""
+    p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        with open(p) as f:
+            return json.load(f).get(kernel)
+    except (OSError, ValueError):
+        return None
+
+
+if __name__ == "__main__":
+    main()

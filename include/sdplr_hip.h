@@ -77,6 +77,7 @@ int32_t sdplr_hip_device_count(int32_t* count);
 int32_t sdplr_hip_set_device(int32_t device); /* process-wide; call before create (one rank = one GPU) */
 const char* sdplr_hip_last_error(const sdplr_hip_solver* s); /* s may be NULL: last create-time error */
 const char* sdplr_hip_version(void);
+int32_t sdplr_hip_device_synchronize(void); /* hipDeviceSynchronize on the current device */
 
 /* ---- construction: replaces SolverVars + SolverAuxiliary construction ------------------------
  * src/sdplr.jl:114-123, src/structs.jl:225-263 (SolverVars), :296-361 (SolverAuxiliary),
@@ -218,6 +219,8 @@ int32_t sdplr_hip_dual_obj(sdplr_hip_solver* s, double trace_bound, int64_t iter
 
 /* ---- per-kernel device timing (hipEvent pairs on the handle's stream) ------------------------ */
 int32_t sdplr_hip_profile_enable(sdplr_hip_solver* s, int32_t on); /* also resets the counters */
+/* time only launches of the kernel called `name` (NULL or "" ⇒ all); keeps the timed region undisturbed */
+int32_t sdplr_hip_profile_filter(sdplr_hip_solver* s, const char* name);
 int32_t sdplr_hip_profile_count(const sdplr_hip_solver* s, int32_t* n_entries);
 int32_t sdplr_hip_profile_get(sdplr_hip_solver* s, int32_t idx, char* name, int32_t name_cap,
                               int64_t* launches, double* total_ms);

@@ -1022,6 +1022,8 @@ int32_t sdplr_oracle_dual_obj(S* s, double trace_bound, int64_t iter, const doub
 }
 
 int32_t sdplr_oracle_profile_enable(S* s, int32_t on) { (void)s; (void)on; return OK; }
+int32_t sdplr_oracle_profile_filter(S* s, const char* name) { (void)s; (void)name; return OK; }
+int32_t sdplr_oracle_device_synchronize(void) { return OK; }
 int32_t sdplr_oracle_profile_count(const S* s, int32_t* n) { (void)s; if (n) *n = 0; return OK; }
 int32_t sdplr_oracle_profile_get(S* s, int32_t idx, char* name, int32_t cap, int64_t* launches, double* ms) {
   (void)s; (void)idx; (void)name; (void)cap; (void)launches; (void)ms;

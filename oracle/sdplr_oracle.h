@@ -33,6 +33,7 @@ int32_t sdplr_oracle_device_count(int32_t* count);
 int32_t sdplr_oracle_set_device(int32_t device);
 const char* sdplr_oracle_last_error(const sdplr_oracle_solver* s);
 const char* sdplr_oracle_version(void);
+int32_t sdplr_oracle_device_synchronize(void);
 
 int32_t sdplr_oracle_create(int64_t n, int64_t m, int64_t r, int64_t numlbfgsvecs,
                             sdplr_oracle_solver** out);
@@ -98,6 +99,7 @@ int32_t sdplr_oracle_approx_mineigval_lanczos(sdplr_oracle_solver* s, int64_t q,
 int32_t sdplr_oracle_dual_obj(sdplr_oracle_solver* s, double trace_bound, int64_t iter,
                               const double* v0, double* dual_value, double* mineig);
 int32_t sdplr_oracle_profile_enable(sdplr_oracle_solver* s, int32_t on);
+int32_t sdplr_oracle_profile_filter(sdplr_oracle_solver* s, const char* name);
 int32_t sdplr_oracle_profile_count(const sdplr_oracle_solver* s, int32_t* n_entries);
 int32_t sdplr_oracle_profile_get(sdplr_oracle_solver* s, int32_t idx, char* name,
                                  int32_t name_cap, int64_t* launches, double* total_ms);

@@ -37,6 +37,7 @@ SIGNATURES = {
     "set_device": [_i32],
     "last_error": [_vp],
     "version": [],
+    "device_synchronize": [],
     "create": [_i64, _i64, _i64, _i64, C.POINTER(_vp)],
     "set_sparse": [_vp, _i64, _i64, _pi64, _pi64, _pf64, _pf64, _pi64, _i64, _pi64, _pi64, _i64,
                    _pi64, _pi64, _pi64],
@@ -74,6 +75,7 @@ SIGNATURES = {
     "approx_mineigval_lanczos": [_vp, _i64, _pf64, _pf64],
     "dual_obj": [_vp, _f64, _i64, _pf64, _pf64, _pf64],
     "profile_enable": [_vp, _i32],
+    "profile_filter": [_vp, C.c_char_p],
     "profile_count": [_vp, _pi32],
     "profile_get": [_vp, _i32, C.c_char_p, _i32, _pi64, _pf64],
 }
@@ -396,6 +398,9 @@ class DeviceSolver:
     # -- device timing ------------------------------------------------------------------------------
     def profile_enable(self, on: bool = True):
         self._ck(self.abi.profile_enable(self._h, int(on)))
+
+    def profile_filter(self, name: str = ""):
+        self._ck(self.abi.profile_filter(self._h, name.encode()))
 
     def profile(self) -> dict:
         """{kernel name: (launches, total_ms)} measured with hipEvents on the solver's own stream."""

@@ -1,0 +1,130 @@
+// common.h — shared definitions of the gfx950 device backend (libsdplr_hip.so).
+//
+// Design (DESIGN.md has the long form):
+//  * every factor-shaped array is n rows × r contiguous doubles (the reference's r×n column-major
+//    `Rt`, src/structs.jl:195,236); slots live in one arena with a 256-B aligned stride.
+//  * all O(1) solver scalars live in ONE device-resident control block (DevCtrl).  Kernels read and
+//    write it directly; the host copies it back once per batch of inner iterations, so the
+//    reference's per-iteration scalar traffic (α, ℒ, ‖G‖, ‖pv‖, dot) never crosses PCIe mid-loop.
+//  * grid-wide reductions are deterministic: every block writes one partial per quantity, and the
+//    (single-block or multi-block) consumer adds the partials in a fixed order.  No float atomics.
+//  * wavefront = 64 lanes everywhere; a factor row is covered by a sub-wave group of LPR lanes,
+//    VEC doubles per lane (r = 32 ⇒ 16 lanes × 16-B loads, 4 rows per wave instruction).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define SDPLR_HMAX 16          // largest numlbfgsvecs supported by the fused L-BFGS kernels
+#define SDPLR_NT 256           // threads per block for every kernel (4 waves)
+#define SDPLR_MAXNB 1024       // largest grid of a partial-producing kernel
+#define SDPLR_NSLOT 160        // reduction slots in the partials buffer
+#define SDPLR_LRMAX 8          // low-rank columns handled per register pass
+
+// exit reasons of the inner loop (include/sdplr_hip.h, sdplr_hip_inner_loop)
+#define EXIT_GTOL 0
+#define EXIT_RELDELTA 1
+#define EXIT_ITERS 2
+#define EXIT_TIME 3
+
+// Device-resident control block: loop control + every O(1) scalar of SolverVars / LBFGSHistory.
+struct DevCtrl {
+  // ---- inner-loop control (src/sdplr.jl:190-278) ----
+  int done;            // 1 ⇒ every later kernel of the batch returns immediately
+  int exit_reason;
+  int err;             // 0 or SDPLR_ERR_NOT_DESCENT (src/linesearch.jl:60-62)
+  int use_armijo;
+  long long iters;     // localiter
+  long long max_iters;
+  double cur_gtol, fprec_eps, normC, normb;
+  int grel, prel;
+  // ---- SolverVars scalars (src/structs.jl:203-205) ----
+  double sigma, obj;
+  // ---- per-iteration scalars ----
+  double L, lastval, gnorm, pvnorm, alpha, descent, alpha_max;
+  double biquad[5];
+  // ---- Lanczos (src/coreop.jl:461-500) ----
+  int lz_done;
+  long long lz_steps;
+  double lz_beta_prev;
+  // ---- L-BFGS (src/lbfgs.jl:4-28) ----
+  int latest;          // 1-based, as in the reference
+  int pad0;
+  double rho[SDPLR_HMAX], a[SDPLR_HMAX];
+  double c_alpha[SDPLR_HMAX], c_gamma[SDPLR_HMAX];   // two-loop coefficients of the current direction
+  double SY[SDPLR_HMAX * SDPLR_HMAX];                // SY[a][b] = ⟨s_a, y_b⟩
+  double YY[SDPLR_HMAX * SDPLR_HMAX];                // YY[a][b] = ⟨y_a, y_b⟩
+  double Sg[SDPLR_HMAX], Yg[SDPLR_HMAX];             // ⟨s_a, G⟩, ⟨y_a, G⟩ for the current G
+};
+
+// ---- deterministic reductions --------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;  // every lane holds the same, order-fixed sum
+}
+
+// sum over a sub-wave group of G lanes (G power of two ≤ 64); every lane of the group gets it
+template <int G>
+__device__ __forceinline__ double group_sum(double v) {
+#pragma unroll
+  for (int o = G / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// block-wide sums of K values; result valid in every thread.  sh must hold K*(NT/64) doubles.
+template <int K>
+__device__ __forceinline__ void block_sum(double (&v)[K], double* sh) {
+  const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+  constexpr int NW = SDPLR_NT / 64;
+#pragma unroll
+  for (int k = 0; k < K; k++) v[k] = wave_sum(v[k]);
+  __syncthreads();
+  if (l == 0) {
+#pragma unroll
+    for (int k = 0; k < K; k++) sh[k * NW + w] = v[k];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < K; k++) {
+    double t = 0.0;
+#pragma unroll
+    for (int i = 0; i < NW; i++) t += sh[k * NW + i];
+    v[k] = t;
+  }
+}
+__device__ __forceinline__ double block_sum1(double v, double* sh) {
+  double a[1] = {v};
+  block_sum<1>(a, sh);
+  return a[0];
+}
+
+// sum of the nb per-block partials of one slot, same value and same order in every calling block
+__device__ __forceinline__ double reduce_partials(const double* __restrict__ p, int nb, double* sh) {
+  double t = 0.0;
+  for (int i = threadIdx.x; i < nb; i += SDPLR_NT) t += p[i];
+  return block_sum1(t, sh);
+}
+
+__device__ __forceinline__ const double* slot_partials(const double* base, int slot) {
+  return base + (size_t)slot * SDPLR_MAXNB;
+}
+__device__ __forceinline__ double* slot_partials(double* base, int slot) {
+  return base + (size_t)slot * SDPLR_MAXNB;
+}
+
+// reduction slots in the partials buffer
+enum {
+  SLOT_DESCENT = 0,   // ⟨dirt, G⟩
+  SLOT_GNORM2 = 1,    // ‖G‖²
+  SLOT_PVNORM2 = 2,   // ‖primal_vio‖²
+  SLOT_F = 3,         // Σ (ỹ² − λ²)/(2σ)
+  SLOT_LZ_A = 9,      // Lanczos v·Av
+  SLOT_LZ_B = 10,     // Lanczos ‖Av‖²
+  SLOT_V0 = 11,       // ‖v0‖²
+  SLOT_DUALYB = 12,   // ⟨y[1:m], b⟩
+  SLOT_GRAM = 16,     // 16 .. 16+5*HMAX-1: partials of lbfgs_update (see k_dense.h)
+  SLOT_ARMIJO = 96,   // 96 .. 96+53-1: ℒ(α_max/2^k), k = 0..50, ℒ(0), slope (see k_scalar.h)
+  SLOT_LS = 150,      // 150..157: the eight sums behind the quartic's coefficients (see k_scalar.h)
+};
+static_assert(SLOT_GRAM + 5 * SDPLR_HMAX <= SLOT_ARMIJO, "slot overlap");
+static_assert(SLOT_ARMIJO + 53 <= SLOT_LS && SLOT_LS + 8 <= SDPLR_NSLOT, "slot overflow");

@@ -1,0 +1,352 @@
+// k_dense.h — dense n×r sweeps: the L-BFGS direction and update, the step R += αD, and the small
+// in-loop BLAS-1 of _sdplr.  All are HBM-bound streaming kernels over flat arrays of N = n·r doubles:
+// 16-B (double2) loads/stores per lane, grid-stride, ≤ SDPLR_MAXNB blocks of 256 threads.
+//
+// L-BFGS is evaluated in "Gram" form.  The two-loop recursion of src/lbfgs.jl:77-124 only ever
+// takes inner products between the history vectors and the running direction, and the running
+// direction is always a linear combination of {G, y_l, s_l}; so every α_l, β_l follows from the
+// small Gram data  SY[a][b] = ⟨s_a,y_b⟩, YY[a][b] = ⟨y_a,y_b⟩, Sg[a] = ⟨s_a,G⟩, Yg[a] = ⟨y_a,G⟩
+// by O(h²) scalar arithmetic (k_lbfgs_coeff), and the direction is ONE pass
+//     dir = ∓(G − Σ α_l y_l + Σ γ_l s_l)                                  (k_lbfgs_dir, (2h+1)N read)
+// instead of the reference's 2h dependent dot/axpy sweeps (48 N of traffic at h = 4).  The Gram
+// rows of the newest pair and the dots with the new gradient are accumulated by the pass that
+// writes the pair (k_lbfgs_update, src/lbfgs.jl:129-149) — direct dots on the stored vectors, no
+// differences of dots.  The history vectors themselves are kept exactly as the reference keeps them.
+#pragma once
+#include "common.h"
+
+struct FactorArena {
+  double* base;      // slot k at base + k*stride
+  long long stride;  // doubles, multiple of 32 (256 B)
+  int h;             // numlbfgsvecs: slots are R, G, D, s_0..s_{h-1}, y_0..y_{h-1}
+};
+// arena slot numbers
+#define AS_R 0
+#define AS_G 1
+#define AS_D 2
+#define AS_S0 3                     // s_j at AS_S0 + j
+
+__host__ __device__ __forceinline__ double* aslot(const FactorArena& A, int k) { return A.base + (long long)k * A.stride; }
+__host__ __device__ __forceinline__ int as_y0(const FactorArena& A) { return AS_S0 + A.h; }  // y_j at as_y0(A) + j
+
+// ---- two-loop coefficients from the Gram data (one thread) -----------------------------------------
+// Mirrors src/lbfgs.jl:93-113 step by step; j runs newest → oldest, then oldest → newest.
+__device__ inline void lbfgs_coefficients(DevCtrl* c, int h) {
+  if (h == 0) return;
+  int order[SDPLR_HMAX];
+  int j = c->latest - 1;  // 0-based newest
+  for (int i = 0; i < h; i++) {
+    order[i] = j;
+    j = (j == 0) ? h - 1 : j - 1;
+  }
+  double al[SDPLR_HMAX], ga[SDPLR_HMAX];
+  for (int i = 0; i < h; i++) {  // α_j = ρ_j ⟨s_j, q⟩,  q = G − Σ_{newer l} α_l y_l
+    int jj = order[i];
+    double sq = c->Sg[jj];
+    for (int k = 0; k < i; k++) sq -= al[order[k]] * c->SY[jj * SDPLR_HMAX + order[k]];
+    al[jj] = c->rho[jj] * sq;
+    c->a[jj] = al[jj];           // lbfgshis.vecs[j].a[] = α  (:97)
+  }
+  for (int i = h - 1; i >= 0; i--) {  // β_j = ρ_j ⟨y_j, r⟩,  r = q + Σ_{older l} γ_l s_l
+    int jj = order[i];
+    double yr = c->Yg[jj];
+    for (int k = 0; k < h; k++) yr -= al[order[k]] * c->YY[jj * SDPLR_HMAX + order[k]];
+    for (int k = h - 1; k > i; k--) yr += ga[order[k]] * c->SY[order[k] * SDPLR_HMAX + jj];
+    double beta = c->rho[jj] * yr;
+    ga[jj] = al[jj] - beta;      // γ = a − β  (:107)
+  }
+  for (int l = 0; l < h; l++) {
+    c->c_alpha[l] = al[l];
+    c->c_gamma[l] = ga[l];
+  }
+}
+
+// Start of one inner iteration: the loop tests of src/sdplr.jl:190 and :272-277, localiter += 1,
+// lastval = ℒ (:207), then the two-loop coefficients.  check_loop = 0 for the stand-alone operator.
+__global__ void k_lbfgs_coeff(DevCtrl* c, int h, int check_loop) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  if (check_loop) {
+    if (c->done) return;
+    if (c->iters > 0 && c->iters >= c->max_iters) {  // :272-277 (checked after the update)
+      c->done = 1;
+      c->exit_reason = EXIT_ITERS;
+      return;
+    }
+    if (!(c->gnorm > c->cur_gtol)) {                  // :190
+      c->done = 1;
+      c->exit_reason = EXIT_GTOL;
+      return;
+    }
+    c->iters += 1;
+    c->lastval = c->L;
+  }
+  lbfgs_coefficients(c, h);
+}
+
+// ---- direction: dir = ∓(G − Σ α_l y_l + Σ γ_l s_l); y_next = −G; partial ⟨dir, G⟩ -----------------
+// src/lbfgs.jl:84 (copy), :94-113 (as one combination), :116-118 (negate), :121-123 (y_next = −grad),
+// src/sdplr.jl:201 (descent).
+template <int HM>
+__global__ void __launch_bounds__(SDPLR_NT)
+k_lbfgs_dir(const DevCtrl* __restrict__ c, FactorArena A, long long N, int h, int negate,
+            int check_done, double* __restrict__ partials) {
+  __shared__ double sh[8];
+  if (check_done && c->done) return;
+  const double* G = aslot(A, AS_G);
+  double* dir = aslot(A, AS_D);
+  const int latest = c->latest;
+  int order[HM];
+  double ca[HM], cg[HM];
+  {
+    int j = latest - 1;
+#pragma unroll
+    for (int i = 0; i < HM; i++) {
+      order[i] = j;
+      if (i < h) {
+        ca[i] = c->c_alpha[j];
+        cg[i] = c->c_gamma[j];
+      } else {
+        ca[i] = 0.0;
+        cg[i] = 0.0;
+      }
+      j = (j <= 0) ? h - 1 : j - 1;
+    }
+  }
+  double* ynext = (h > 0) ? aslot(A, as_y0(A) + (latest % h)) : nullptr;
+  const double sgn = negate ? -1.0 : 1.0;
+  double desc = 0.0;
+  const long long N2 = N >> 1;
+  const long long stride = (long long)gridDim.x * SDPLR_NT;
+  for (long long i = (long long)blockIdx.x * SDPLR_NT + threadIdx.x; i < N2; i += stride) {
+    const double2 g = reinterpret_cast<const double2*>(G)[i];
+    double2 r = g;
+#pragma unroll
+    for (int k = 0; k < HM; k++)  // newest → oldest: q −= α y   (:94-102)
+      if (k < h) {
+        const double2 y = reinterpret_cast<const double2*>(aslot(A, as_y0(A) + order[k]))[i];
+        r.x -= ca[k] * y.x;
+        r.y -= ca[k] * y.y;
+      }
+#pragma unroll
+    for (int k = HM - 1; k >= 0; k--)  // oldest → newest: r += γ s  (:104-113)
+      if (k < h) {
+        const double2 s = reinterpret_cast<const double2*>(aslot(A, AS_S0 + order[k]))[i];
+        r.x += cg[k] * s.x;
+        r.y += cg[k] * s.y;
+      }
+    double2 d;
+    d.x = sgn * r.x;
+    d.y = sgn * r.y;
+    reinterpret_cast<double2*>(dir)[i] = d;
+    if (ynext) {
+      double2 ng;
+      ng.x = -g.x;
+      ng.y = -g.y;
+      reinterpret_cast<double2*>(ynext)[i] = ng;
+    }
+    desc += d.x * g.x + d.y * g.y;
+  }
+  if ((N & 1) && blockIdx.x == 0 && threadIdx.x == 0) {  // odd tail element
+    const long long e = N - 1;
+    const double g = G[e];
+    double r = g;
+    for (int k = 0; k < h; k++) r -= ca[k] * aslot(A, as_y0(A) + order[k])[e];
+    for (int k = h - 1; k >= 0; k--) r += cg[k] * aslot(A, AS_S0 + order[k])[e];
+    const double d = sgn * r;
+    dir[e] = d;
+    if (ynext) ynext[e] = -g;
+    desc += d * g;
+  }
+  desc = block_sum1(desc, sh);
+  if (threadIdx.x == 0) slot_partials(partials, SLOT_DESCENT)[blockIdx.x] = desc;
+}
+
+// descent = Σ partials (src/sdplr.jl:201); with `apply`, the steepest-descent fallback of
+// src/sdplr.jl:202-205 (G ← −G; dirt ← G) is taken on the device when descent is NaN or ≥ 0.
+__global__ void __launch_bounds__(SDPLR_NT)
+k_descent(DevCtrl* __restrict__ c, FactorArena A, long long N, int nb_partials, int apply,
+          int check_done, const double* __restrict__ partials) {
+  __shared__ double sh[8];
+  if (check_done && c->done) return;
+  const double desc = reduce_partials(slot_partials(partials, SLOT_DESCENT), nb_partials, sh);
+  if (blockIdx.x == 0 && threadIdx.x == 0) c->descent = desc;
+  if (!apply) return;
+  if (!(isnan(desc) || desc >= 0.0)) return;
+  double* G = aslot(A, AS_G);
+  double* dir = aslot(A, AS_D);
+  const long long stride = (long long)gridDim.x * SDPLR_NT;
+  for (long long i = (long long)blockIdx.x * SDPLR_NT + threadIdx.x; i < N; i += stride) {
+    const double g = -G[i];
+    G[i] = g;
+    dir[i] = g;
+  }
+}
+
+// unconditional fallback for the stand-alone operator sdplr_hip_descent_fallback
+__global__ void __launch_bounds__(SDPLR_NT) k_neg_copy(double* __restrict__ G, double* __restrict__ dir, long long N) {
+  const long long stride = (long long)gridDim.x * SDPLR_NT;
+  for (long long i = (long long)blockIdx.x * SDPLR_NT + threadIdx.x; i < N; i += stride) {
+    const double g = -G[i];
+    G[i] = g;
+    dir[i] = g;
+  }
+}
+
+// ---- history update + Gram rows of slot j ----------------------------------------------------------
+// UPDATE: src/lbfgs.jl:140-146 — dirt *= α; s_j = dirt; y_j += G, j = latest mod h (0-based).
+// Both variants accumulate, for every slot l (with the new s_j, y_j for l = j):
+//   q=0: ⟨s_j, y_l⟩   q=1: ⟨s_l, y_j⟩   q=2: ⟨y_j, y_l⟩   q=3: ⟨s_l, G⟩   q=4: ⟨y_l, G⟩
+// into partial slot SLOT_GRAM + q*SDPLR_HMAX + l.  !UPDATE recomputes row `jfixed` from the stored
+// vectors (used when the host has written history slots or G behind the library's back).
+template <int HM, bool UPDATE>
+__global__ void __launch_bounds__(SDPLR_NT)
+k_lbfgs_update(const DevCtrl* __restrict__ c, FactorArena A, long long N, int h, int jfixed,
+               int check_done, double* __restrict__ partials) {
+  __shared__ double sh[5 * HM * (SDPLR_NT / 64)];
+  if (check_done && c->done) return;
+  const int j = UPDATE ? (c->latest % h) : jfixed;
+  const double alpha = c->alpha;
+  const double* G = aslot(A, AS_G);
+  double* dir = aslot(A, AS_D);
+  double* Sj = aslot(A, AS_S0 + j);
+  double* Yj = aslot(A, as_y0(A) + j);
+  double acc[5 * HM];
+#pragma unroll
+  for (int k = 0; k < 5 * HM; k++) acc[k] = 0.0;
+  const long long N2 = N >> 1;
+  const long long stride = (long long)gridDim.x * SDPLR_NT;
+  for (long long i = (long long)blockIdx.x * SDPLR_NT + threadIdx.x; i < N2; i += stride) {
+    const double2 g = reinterpret_cast<const double2*>(G)[i];
+    double2 sn, yn;
+    if (UPDATE) {
+      const double2 d = reinterpret_cast<const double2*>(dir)[i];
+      sn.x = alpha * d.x;  // BLAS.scal!(stepsize, dir)  (:142)
+      sn.y = alpha * d.y;
+      reinterpret_cast<double2*>(dir)[i] = sn;
+      reinterpret_cast<double2*>(Sj)[i] = sn;  // copy!(s_j, dir)  (:143)
+      const double2 yo = reinterpret_cast<const double2*>(Yj)[i];
+      yn.x = yo.x + g.x;  // axpy!(1, grad, y_j)  (:145)
+      yn.y = yo.y + g.y;
+      reinterpret_cast<double2*>(Yj)[i] = yn;
+    } else {
+      sn = reinterpret_cast<const double2*>(Sj)[i];
+      yn = reinterpret_cast<const double2*>(Yj)[i];
+    }
+#pragma unroll
+    for (int l = 0; l < HM; l++)
+      if (l < h) {
+        double2 sl, yl;
+        if (l == j) {
+          sl = sn;
+          yl = yn;
+        } else {
+          sl = reinterpret_cast<const double2*>(aslot(A, AS_S0 + l))[i];
+          yl = reinterpret_cast<const double2*>(aslot(A, as_y0(A) + l))[i];
+        }
+        acc[0 * HM + l] += sn.x * yl.x + sn.y * yl.y;
+        acc[1 * HM + l] += sl.x * yn.x + sl.y * yn.y;
+        acc[2 * HM + l] += yn.x * yl.x + yn.y * yl.y;
+        acc[3 * HM + l] += sl.x * g.x + sl.y * g.y;
+        acc[4 * HM + l] += yl.x * g.x + yl.y * g.y;
+      }
+  }
+  if ((N & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+    const long long e = N - 1;
+    const double g = G[e];
+    double sn, yn;
+    if (UPDATE) {
+      sn = alpha * dir[e];
+      dir[e] = sn;
+      Sj[e] = sn;
+      yn = Yj[e] + g;
+      Yj[e] = yn;
+    } else {
+      sn = Sj[e];
+      yn = Yj[e];
+    }
+    for (int l = 0; l < h; l++) {
+      const double sl = (l == j) ? sn : aslot(A, AS_S0 + l)[e];
+      const double yl = (l == j) ? yn : aslot(A, as_y0(A) + l)[e];
+      acc[0 * HM + l] += sn * yl;
+      acc[1 * HM + l] += sl * yn;
+      acc[2 * HM + l] += yn * yl;
+      acc[3 * HM + l] += sl * g;
+      acc[4 * HM + l] += yl * g;
+    }
+  }
+  block_sum<5 * HM>(acc, sh);
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int q = 0; q < 5; q++)
+#pragma unroll
+      for (int l = 0; l < HM; l++)
+        if (l < h) slot_partials(partials, SLOT_GRAM + q * SDPLR_HMAX + l)[blockIdx.x] = acc[q * HM + l];
+  }
+}
+
+// Fold the update partials into the Gram data; with `update`: ρ_j = 1/⟨y_j, s_j⟩ (:146) and
+// latest = j (:148).  One block; all 5h sums are reduced together (one pass over the partials).
+template <int HM>
+__global__ void __launch_bounds__(SDPLR_NT)
+k_gram_finalize(DevCtrl* __restrict__ c, int h, int jfixed, int update, int nb_partials,
+                int check_done, const double* __restrict__ partials) {
+  __shared__ double sh[5 * HM * (SDPLR_NT / 64)];
+  if (check_done && c->done) return;
+  const int j = update ? (c->latest % h) : jfixed;
+  double acc[5 * HM];
+#pragma unroll
+  for (int k = 0; k < 5 * HM; k++) acc[k] = 0.0;
+  for (int i = threadIdx.x; i < nb_partials; i += SDPLR_NT) {
+#pragma unroll
+    for (int q = 0; q < 5; q++)
+#pragma unroll
+      for (int l = 0; l < HM; l++)
+        if (l < h) acc[q * HM + l] += slot_partials(partials, SLOT_GRAM + q * SDPLR_HMAX + l)[i];
+  }
+  block_sum<5 * HM>(acc, sh);
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int l = 0; l < HM; l++)
+      if (l < h) {
+        c->SY[j * SDPLR_HMAX + l] = acc[0 * HM + l];
+        if (l != j) c->SY[l * SDPLR_HMAX + j] = acc[1 * HM + l];
+        c->YY[j * SDPLR_HMAX + l] = acc[2 * HM + l];
+        c->YY[l * SDPLR_HMAX + j] = acc[2 * HM + l];
+        c->Sg[l] = acc[3 * HM + l];
+        c->Yg[l] = acc[4 * HM + l];
+      }
+    if (update) {
+      c->rho[j] = 1.0 / c->SY[j * SDPLR_HMAX + j];
+      c->latest = j + 1;
+    }
+  }
+}
+
+// ---- R += α·dirt  (src/sdplr.jl:219) ------------------------------------------------------------------
+__global__ void __launch_bounds__(SDPLR_NT)
+k_axpy_R(const DevCtrl* __restrict__ c, double* __restrict__ R, const double* __restrict__ D,
+         long long N, int check_done) {
+  if (check_done && c->done) return;
+  const double alpha = c->alpha;
+  const long long N2 = N >> 1;
+  const long long stride = (long long)gridDim.x * SDPLR_NT;
+  for (long long i = (long long)blockIdx.x * SDPLR_NT + threadIdx.x; i < N2; i += stride) {
+    double2 r = reinterpret_cast<double2*>(R)[i];
+    const double2 d = reinterpret_cast<const double2*>(D)[i];
+    r.x += alpha * d.x;
+    r.y += alpha * d.y;
+    reinterpret_cast<double2*>(R)[i] = r;
+  }
+  if ((N & 1) && blockIdx.x == 0 && threadIdx.x == 0) R[N - 1] += alpha * D[N - 1];
+}
+
+// ‖x‖² partials of a flat array (stand-alone norm of G when no fused producer ran)
+__global__ void __launch_bounds__(SDPLR_NT)
+k_sumsq(const double* __restrict__ x, long long N, int slot, double* __restrict__ partials) {
+  __shared__ double sh[8];
+  double t = 0.0;
+  const long long stride = (long long)gridDim.x * SDPLR_NT;
+  for (long long i = (long long)blockIdx.x * SDPLR_NT + threadIdx.x; i < N; i += stride) t += x[i] * x[i];
+  t = block_sum1(t, sh);
+  if (threadIdx.x == 0) slot_partials(partials, slot)[blockIdx.x] = t;
+}

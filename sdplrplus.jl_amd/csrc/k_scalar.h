@@ -1,0 +1,418 @@
+// k_scalar.h — O(m) vector kernels and the single-block "scalar stage" kernels that keep every
+// solver scalar on the device: Lagrangian value, line-search coefficient sums and root selection,
+// primal-violation bookkeeping, the inner loop's exit tests, Armijo backtracking, Lanczos updates.
+#pragma once
+#include "common.h"
+
+#define SDPLR_EPS 2.220446049250313e-16
+
+// ---- f! tail: src/coreop.jl:16-29 on pv_raw = 𝒜(RRᵀ) ------------------------------------------------
+__global__ void __launch_bounds__(SDPLR_NT)
+k_f_tail(DevCtrl* __restrict__ c, int m, double* __restrict__ pv_raw, const double* __restrict__ b,
+         const double* __restrict__ lb, double* __restrict__ pv, const double* __restrict__ lam,
+         const double* __restrict__ lam_ub, double* __restrict__ partials) {
+  __shared__ double sh[8];
+  const double sigma = c->sigma;
+  double t = 0.0;
+  const int stride = gridDim.x * SDPLR_NT;
+  for (int i = blockIdx.x * SDPLR_NT + threadIdx.x; i < m; i += stride) {
+    const double v = pv_raw[i] - b[i];                      // v .-= b            (:20)
+    pv_raw[i] = v;
+    pv[i] = fmax(v, lb[i]);                                 // capped violation   (:22)
+    const double l = lam[i];
+    const double yi = fmin(lam_ub[i], l - sigma * v);       // (:27)
+    t += (yi * yi - l * l) / (2 * sigma);                   // (:28)
+  }
+  t = block_sum1(t, sh);
+  if (threadIdx.x == 0) slot_partials(partials, SLOT_F)[blockIdx.x] = t;
+}
+__global__ void __launch_bounds__(SDPLR_NT)
+k_f_finalize(DevCtrl* __restrict__ c, int m, const double* __restrict__ pv_raw, int nb,
+             const double* __restrict__ partials) {
+  __shared__ double sh[8];
+  const double s = reduce_partials(slot_partials(partials, SLOT_F), nb, sh);
+  if (threadIdx.x == 0) {
+    c->obj = pv_raw[m];      // (:16)
+    c->L = c->obj + s;       // (:25-30)
+  }
+}
+
+// copy2y_λ_sub_pvio!  src/coreop.jl:229-236
+__global__ void __launch_bounds__(SDPLR_NT)
+k_copy2y(const DevCtrl* __restrict__ c, int m, double* __restrict__ y, const double* __restrict__ lam,
+         const double* __restrict__ lam_ub, const double* __restrict__ pv_raw, int check_done) {
+  if (check_done && c->done) return;
+  const double sigma = c->sigma;
+  const int stride = gridDim.x * SDPLR_NT;
+  for (int i = blockIdx.x * SDPLR_NT + threadIdx.x; i <= m; i += stride)
+    y[i] = (i == m) ? 1.0 : -fmin(lam_ub[i], lam[i] - sigma * pv_raw[i]);
+}
+
+// primal_vio = max(primal_vio_raw, lb) and ‖primal_vio‖² partials  (src/coreop.jl:340-347)
+__global__ void __launch_bounds__(SDPLR_NT)
+k_pv_norm(int m, const double* __restrict__ pv_raw, const double* __restrict__ lb, double* __restrict__ pv,
+          int recompute, double* __restrict__ partials) {
+  __shared__ double sh[8];
+  double t = 0.0;
+  const int stride = gridDim.x * SDPLR_NT;
+  for (int i = blockIdx.x * SDPLR_NT + threadIdx.x; i < m; i += stride) {
+    double v;
+    if (recompute) {
+      v = fmax(pv_raw[i], lb[i]);
+      pv[i] = v;
+    } else {
+      v = pv[i];
+    }
+    t += v * v;
+  }
+  t = block_sum1(t, sh);
+  if (threadIdx.x == 0) slot_partials(partials, SLOT_PVNORM2)[blockIdx.x] = t;
+}
+
+// grad_norm / primal_vio_norm from the ‖·‖² partials (src/sdplr.jl:224-234, src/coreop.jl:334-347) and,
+// with `loop_tail`, the relative-decrease exit of src/sdplr.jl:238-241.  One block.
+__global__ void __launch_bounds__(SDPLR_NT)
+k_norms(DevCtrl* __restrict__ c, int nb_g, int nb_p, int loop_tail, int check_done,
+        const double* __restrict__ partials) {
+  __shared__ double sh[8];
+  if (check_done && c->done) return;
+  const double g2 = reduce_partials(slot_partials(partials, SLOT_GNORM2), nb_g, sh);
+  __syncthreads();
+  const double p2 = reduce_partials(slot_partials(partials, SLOT_PVNORM2), nb_p, sh);
+  if (threadIdx.x != 0) return;
+  const double g = sqrt(g2), p = sqrt(p2);
+  c->gnorm = c->grel ? g / c->normC : g;
+  c->pvnorm = c->prel ? p / c->normb : p;
+  if (loop_tail) {
+    const double L = c->L, last = c->lastval;
+    const double rel_delta = (last - L) / fmax(1.0, fmax(fabs(L), fabs(last)));
+    if (rel_delta < c->fprec_eps) {
+      c->done = 1;
+      c->exit_reason = EXIT_RELDELTA;
+    }
+  }
+}
+
+// λᵢ ← min(λ_ubᵢ, λᵢ − σ·pv_rawᵢ)   (src/sdplr.jl:358-362)
+__global__ void __launch_bounds__(SDPLR_NT)
+k_update_lambda(const DevCtrl* __restrict__ c, int m, double* __restrict__ lam,
+                const double* __restrict__ lam_ub, const double* __restrict__ pv_raw) {
+  const double sigma = c->sigma;
+  const int stride = gridDim.x * SDPLR_NT;
+  for (int i = blockIdx.x * SDPLR_NT + threadIdx.x; i < m; i += stride)
+    lam[i] = fmin(lam_ub[i], lam[i] - sigma * pv_raw[i]);
+}
+
+// Σ partials of one slot → *dst.  One block.
+__global__ void __launch_bounds__(SDPLR_NT)
+k_reduce_slot(double* __restrict__ dst, int slot, int nb, const double* __restrict__ partials) {
+  __shared__ double sh[8];
+  const double s = reduce_partials(slot_partials(partials, slot), nb, sh);
+  if (threadIdx.x == 0) *dst = s;
+}
+// ⟨x, y⟩ partials of two short vectors
+__global__ void __launch_bounds__(SDPLR_NT)
+k_dot(int len, const double* __restrict__ x, const double* __restrict__ y, int slot, double* __restrict__ partials) {
+  __shared__ double sh[8];
+  double t = 0.0;
+  const int stride = gridDim.x * SDPLR_NT;
+  for (int i = blockIdx.x * SDPLR_NT + threadIdx.x; i < len; i += stride) t += x[i] * y[i];
+  t = block_sum1(t, sh);
+  if (threadIdx.x == 0) slot_partials(partials, slot)[blockIdx.x] = t;
+}
+
+// ---- exact line search: coefficient sums (src/linesearch.jl:36-56) -----------------------------------
+//   s0 = λ·(−q0)  s1 = ‖q0‖²  s2 = λ·q1  s3 = (−q0)·q1  s4 = (λ − σ(−q0))·q2  s5 = ‖q1‖²  s6 = q1·q2  s7 = ‖q2‖²
+__global__ void __launch_bounds__(SDPLR_NT)
+k_ls_partials(const DevCtrl* __restrict__ c, int m, const double* __restrict__ lam,
+              const double* __restrict__ pv_raw, const double* __restrict__ A_RD,
+              const double* __restrict__ A_DD, double* __restrict__ partials, int check_done) {
+  __shared__ double sh[8 * (SDPLR_NT / 64)];
+  if (check_done && c->done) return;
+  const double sigma = c->sigma;
+  double s[8];
+#pragma unroll
+  for (int k = 0; k < 8; k++) s[k] = 0.0;
+  const int stride = gridDim.x * SDPLR_NT;
+  for (int i = blockIdx.x * SDPLR_NT + threadIdx.x; i < m; i += stride) {
+    const double l = lam[i], nq0 = pv_raw[i], q1 = A_RD[i], q2 = A_DD[i];
+    s[0] += l * nq0;
+    s[1] += nq0 * nq0;
+    s[2] += l * q1;
+    s[3] += nq0 * q1;
+    s[4] += (l - sigma * nq0) * q2;
+    s[5] += q1 * q1;
+    s[6] += q1 * q2;
+    s[7] += q2 * q2;
+  }
+  block_sum<8>(s, sh);
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int k = 0; k < 8; k++) slot_partials(partials, SLOT_LS + k)[blockIdx.x] = s[k];
+  }
+}
+
+__device__ inline double horner4(const double* b, double x) {
+  return (((b[4] * x + b[3]) * x + b[2]) * x + b[1]) * x + b[0];
+}
+// real roots of c0 + c1 x + c2 x² + c3 x³ (c3 ≠ 0): trigonometric / Cardano closed form, then Newton
+// polish on the unscaled cubic.  Stands in for PolynomialRoots.roots (src/linesearch.jl:94) — the
+// reference keeps a root only if |imag| < eps (:100); real roots are produced here directly.
+__device__ inline int cubic_real_roots(double c0, double c1, double c2, double c3, double* roots) {
+  const double a = c2 / c3, b = c1 / c3, cc = c0 / c3;
+  const double p = b - a * a / 3.0;
+  const double q = 2.0 * a * a * a / 27.0 - a * b / 3.0 + cc;
+  const double disc = q * q / 4.0 + p * p * p / 27.0;
+  int nr = 0;
+  if (disc > 0.0) {
+    const double sq = sqrt(disc);
+    const double A = (q > 0.0) ? -cbrt(q / 2.0 + sq) : cbrt(-q / 2.0 + sq);
+    const double B = (A != 0.0) ? -p / (3.0 * A) : 0.0;
+    roots[nr++] = A + B - a / 3.0;
+  } else if (p == 0.0) {
+    roots[nr++] = -a / 3.0;  // triple root
+  } else {
+    const double mm = 2.0 * sqrt(-p / 3.0);
+    double arg = 3.0 * q / (p * mm);
+    arg = fmin(1.0, fmax(-1.0, arg));
+    const double th = acos(arg) / 3.0;
+    const double twopi3 = 2.0943951023931953;
+    for (int k = 0; k < 3; k++) roots[nr++] = mm * cos(th - twopi3 * k) - a / 3.0;
+  }
+  for (int i = 0; i < nr; i++) {
+    double x = roots[i];
+    double fx = ((c3 * x + c2) * x + c1) * x + c0;
+    for (int it = 0; it < 4; it++) {
+      const double d = (3.0 * c3 * x + 2.0 * c2) * x + c1;
+      if (d == 0.0) break;
+      const double xn = x - fx / d;
+      const double fn = ((c3 * xn + c2) * xn + c1) * xn + c0;
+      if (!(fabs(fn) < fabs(fx))) break;
+      x = xn;
+      fx = fn;
+    }
+    roots[i] = x;
+  }
+  return nr;
+}
+// scalar stage of linesearch!  src/linesearch.jl:58-112.  Returns 0 or −3 (not a descent direction).
+__device__ inline int quartic_argmin(const double* bq, double alpha_max, double* alpha, double* fval) {
+  const double k0 = 1.0 * bq[1];
+  if (k0 > SDPLR_EPS) return -3;  // :60-62
+  const double k1 = 2.0 * bq[2], k2 = 3.0 * bq[3], k3 = 4.0 * bq[4];
+  double roots[4];
+  int nr = 0;
+  if (fabs(k3) < SDPLR_EPS) {     // :70-83 quadratic (or lower) derivative
+    if (k2 != 0.0) {
+      const double disc = k1 * k1 - 4.0 * k2 * k0;
+      if (disc >= 0.0) {
+        const double sq = sqrt(disc);
+        const double qq = -0.5 * (k1 + (k1 >= 0.0 ? sq : -sq));
+        roots[nr++] = qq / k2;
+        if (qq != 0.0) roots[nr++] = k0 / qq;
+      }
+    } else if (k1 != 0.0) {
+      roots[nr++] = -k0 / k1;
+    }
+  } else {                        // :86-95
+    nr = cubic_real_roots(k0, k1, k2, k3, roots);
+  }
+  roots[nr++] = alpha_max;
+  double a_star = 0.0, f_star = bq[0];
+  for (int i = 0; i < nr; i++) {  // :98-112
+    const double root = roots[i];
+    if (!(root >= 0.0) || root > alpha_max) continue;
+    const double fa = horner4(bq, root);
+    if (fa < f_star) {
+      f_star = fa;
+      a_star = root;
+    }
+  }
+  *alpha = a_star;
+  *fval = f_star;
+  return 0;
+}
+
+// One block: quartic coefficients (src/linesearch.jl:44-56), root selection, α* and ℒ(α*).
+__global__ void __launch_bounds__(SDPLR_NT)
+k_ls_solve(DevCtrl* __restrict__ c, int m, int nb, const double* __restrict__ A_RD,
+           const double* __restrict__ A_DD, const double* __restrict__ partials, int check_done) {
+  __shared__ double sh[8 * (SDPLR_NT / 64)];
+  if (check_done && c->done) return;
+  double s[8];
+#pragma unroll
+  for (int k = 0; k < 8; k++) s[k] = 0.0;
+  for (int i = threadIdx.x; i < nb; i += SDPLR_NT) {
+#pragma unroll
+    for (int k = 0; k < 8; k++) s[k] += slot_partials(partials, SLOT_LS + k)[i];
+  }
+  block_sum<8>(s, sh);
+  if (threadIdx.x != 0) return;
+  const double sigma = c->sigma, p0 = c->obj, p1 = A_RD[m], p2 = A_DD[m];
+  double bq[5];
+  bq[0] = p0 - s[0] + sigma * s[1] / 2;
+  bq[1] = p1 - s[2] + sigma * s[3];
+  bq[2] = p2 - s[4] + sigma * s[5] / 2;
+  bq[3] = sigma * s[6];
+  bq[4] = sigma * s[7] / 2;
+  for (int k = 0; k < 5; k++) c->biquad[k] = bq[k];
+  double a = 0.0, f = bq[0];
+  const int rc = quartic_argmin(bq, c->alpha_max, &a, &f);
+  if (rc != 0) {
+    c->err = rc;
+    c->done = 1;
+    return;
+  }
+  c->alpha = a;
+  c->L = f;
+}
+
+// commit of either line search (src/linesearch.jl:118-124 / :184-188): pv_raw += α(α·A_DD + A_RD),
+// obj, capped violation and its ‖·‖² partials; with `fuse_y`, y of the following g! (copy2y_λ_sub_pvio!)
+__global__ void __launch_bounds__(SDPLR_NT)
+k_ls_commit(DevCtrl* __restrict__ c, int m, double* __restrict__ pv_raw, const double* __restrict__ A_RD,
+            const double* __restrict__ A_DD, const double* __restrict__ lb, double* __restrict__ pv,
+            int fuse_y, double* __restrict__ y, const double* __restrict__ lam,
+            const double* __restrict__ lam_ub, double* __restrict__ partials, int check_done) {
+  __shared__ double sh[8];
+  if (check_done && c->done) return;
+  const double a = c->alpha, sigma = c->sigma;
+  double t = 0.0;
+  const int stride = gridDim.x * SDPLR_NT;
+  for (int i = blockIdx.x * SDPLR_NT + threadIdx.x; i <= m; i += stride) {
+    const double v = pv_raw[i] + a * (a * A_DD[i] + A_RD[i]);
+    pv_raw[i] = v;
+    if (i == m) {
+      c->obj = v;
+      if (fuse_y) y[m] = 1.0;
+    } else {
+      const double pc = fmax(v, lb[i]);
+      pv[i] = pc;
+      t += pc * pc;
+      if (fuse_y) y[i] = -fmin(lam_ub[i], lam[i] - sigma * v);
+    }
+  }
+  t = block_sum1(t, sh);
+  if (threadIdx.x == 0) slot_partials(partials, SLOT_PVNORM2)[blockIdx.x] = t;
+}
+
+// ---- Armijo backtracking (src/linesearch.jl:139-191), all 51 trial steps in one sweep ---------------
+// sum[k] = Σ_i (λ̃ᵢ(α_k)² − λᵢ²)/(2σ), α_k = α_max/2^k, k = 0..50; sum[51] the same at α = 0;
+// sum[52] = Σ_i yᵢ·A_RDᵢ (slope, :171).
+__global__ void __launch_bounds__(SDPLR_NT)
+k_armijo_partials(const DevCtrl* __restrict__ c, int m, const double* __restrict__ lam,
+                  const double* __restrict__ lam_ub, const double* __restrict__ pv_raw,
+                  const double* __restrict__ A_RD, const double* __restrict__ A_DD,
+                  const double* __restrict__ y, double* __restrict__ partials, int check_done) {
+  __shared__ double sh[53 * (SDPLR_NT / 64)];
+  if (check_done && c->done) return;
+  const double sigma = c->sigma, amax = c->alpha_max;
+  double s[53];
+#pragma unroll
+  for (int k = 0; k < 53; k++) s[k] = 0.0;
+  const int stride = gridDim.x * SDPLR_NT;
+  for (int i = blockIdx.x * SDPLR_NT + threadIdx.x; i < m; i += stride) {
+    const double l = lam[i], ub = lam_ub[i], g0 = pv_raw[i], q1 = A_RD[i], q2 = A_DD[i];
+    double a = amax;
+#pragma unroll
+    for (int k = 0; k < 51; k++) {
+      const double gi = g0 + a * q1 + a * a * q2;            // :160
+      const double lt = fmin(ub, l - sigma * gi);            // :161
+      s[k] += (lt * lt - l * l) / (2 * sigma);               // :162
+      a /= 2;
+    }
+    const double lt0 = fmin(ub, l - sigma * g0);
+    s[51] += (lt0 * lt0 - l * l) / (2 * sigma);
+    s[52] += y[i] * q1;
+  }
+  block_sum<53>(s, sh);
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int k = 0; k < 53; k++) slot_partials(partials, SLOT_ARMIJO + k)[blockIdx.x] = s[k];
+  }
+}
+__global__ void __launch_bounds__(SDPLR_NT)
+k_armijo_pick(DevCtrl* __restrict__ c, int m, int nb, const double* __restrict__ A_RD,
+              const double* __restrict__ A_DD, const double* __restrict__ partials, int check_done) {
+  __shared__ double tot[53];
+  __shared__ double sh[8];
+  if (check_done && c->done) return;
+  for (int k = 0; k < 53; k++) {
+    const double v = reduce_partials(slot_partials(partials, SLOT_ARMIJO + k), nb, sh);
+    if (threadIdx.x == 0) tot[k] = v;
+    __syncthreads();
+  }
+  if (threadIdx.x != 0) return;
+  const double obj = c->obj, p1 = A_RD[m], p2 = A_DD[m];
+  const double L0 = obj + tot[51];                      // eval_AL(0)      :167
+  const double slope = p1 + tot[52];                    // :171
+  const double cc = 1e-4;                               // :173
+  double a = c->alpha_max;
+  int k = 0;
+  double La = obj + a * p1 + a * a * p2 + tot[0];       // :175
+  for (int it = 0; it < 50; it++) {                     // :177-181
+    if (La <= L0 + cc * a * slope) break;
+    a /= 2;
+    k++;
+    La = obj + a * p1 + a * a * p2 + tot[k];
+  }
+  c->alpha = a;
+  c->L = La;
+}
+
+// ---- Lanczos vector updates (src/coreop.jl:473-499) ---------------------------------------------------
+// v = v0/‖v0‖  (:474)
+__global__ void __launch_bounds__(SDPLR_NT)
+k_lz_init(int n, const double* __restrict__ v0, double* __restrict__ v, int nb, const double* __restrict__ partials) {
+  __shared__ double sh[8];
+  const double nv = sqrt(reduce_partials(slot_partials(partials, SLOT_V0), nb, sh));
+  const int stride = gridDim.x * SDPLR_NT;
+  for (int i = blockIdx.x * SDPLR_NT + threadIdx.x; i < n; i += stride) v[i] = v0[i] / nv;
+}
+// alpha[i] = v·Av (:484); Av −= alpha[i]·v (+ beta[i−1]·v_pre) (:486-490); ‖Av‖² partials (:492)
+__global__ void __launch_bounds__(SDPLR_NT)
+k_lz_update1(DevCtrl* __restrict__ c, int n, int step, const double* __restrict__ v, double* __restrict__ Av,
+             const double* __restrict__ vpre, double* __restrict__ alpha_out, int nb_in,
+             double* __restrict__ partials) {
+  __shared__ double sh[8];
+  if (c->lz_done) return;
+  const double al = reduce_partials(slot_partials(partials, SLOT_LZ_A), nb_in, sh);
+  const double be = c->lz_beta_prev;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    alpha_out[step] = al;
+    c->lz_steps = step + 1;  // iter += 1 (:482)
+  }
+  double t = 0.0;
+  const int stride = gridDim.x * SDPLR_NT;
+  for (int i = blockIdx.x * SDPLR_NT + threadIdx.x; i < n; i += stride) {
+    double a = Av[i];
+    if (step == 0) a -= al * v[i];
+    else a -= al * v[i] + be * vpre[i];
+    Av[i] = a;
+    t += a * a;
+  }
+  __syncthreads();
+  t = block_sum1(t, sh);
+  if (threadIdx.x == 0) slot_partials(partials, SLOT_LZ_B)[blockIdx.x] = t;
+}
+// beta[i] = ‖Av‖ (:492); stop if |beta| < √n·eps (:494-496); else Av ./= beta (:497)
+__global__ void __launch_bounds__(SDPLR_NT)
+k_lz_update2(DevCtrl* __restrict__ c, int n, int step, double* __restrict__ Av, double* __restrict__ beta_out,
+             int nb_in, const double* __restrict__ partials) {
+  __shared__ double sh[8];
+  if (c->lz_done) return;
+  const double be = sqrt(reduce_partials(slot_partials(partials, SLOT_LZ_B), nb_in, sh));
+  const bool stop = fabs(be) < sqrt((double)n) * SDPLR_EPS;
+  // every block has read lz_done before any block can have set it below only if the flag is written
+  // last: a late-starting block could otherwise see lz_done = 1 and skip its share of the scaling —
+  // harmless, because after a stop the vectors are never used again.
+  if (!stop) {
+    const int stride = gridDim.x * SDPLR_NT;
+    for (int i = blockIdx.x * SDPLR_NT + threadIdx.x; i < n; i += stride) Av[i] /= be;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    beta_out[step] = be;
+    c->lz_beta_prev = be;
+    if (stop) c->lz_done = 1;
+  }
+}

@@ -1,0 +1,409 @@
+// k_sparse.h — the gather-bound operators on the aggregated sparse layout (src/structs.jl:274-294):
+//   SDDMM  UVt[q] = ⟨U_col, V_row⟩ over the upper-triangular pattern   (src/coreop.jl:153-203)
+//   segmented reduction  out[k] = Σ_{e∈seg k} nzval_two[e]·UVt[nzind[e]]     (src/coreop.jl:80-90)
+//   S assembly  triu_nzval = Agg_one·y ; nzval = triu_nzval[mappedto_triu]     (src/coreop.jl:205-227)
+//   SpMM   Y = scale·(X·S + low-rank terms)                                    (src/coreop.jl:260-279)
+//   SpMV   y = S·x + low-rank terms                                            (src/coreop.jl:281-300)
+//   low-rank projections  W = Xᵀ·B                                             (src/coreop.jl:115-130)
+//
+// A factor row (r doubles, 256 B at r = 32) is covered by a sub-wave group of LPR lanes holding
+// VEC doubles each, so one wave64 instruction moves 64/LPR whole rows, each a contiguous
+// (LPR·VEC·8)-byte segment.  Rows are gathered at random from a factor that fits the 256 MiB
+// Infinity Cache but not the 4 MiB per-XCD L2, so these kernels are bound by gathered-row bandwidth,
+// not by HBM streaming; there is no matrix-core work here (FP64 dot products of length r).
+#pragma once
+#include "common.h"
+
+struct DevSparse {
+  int n, nnzT, nnzS, nnzAgg, n_sparse;
+  const int *triu_colptr, *triu_rowval, *triu_colidx;  // upper-triangular aggregated pattern (CSC + explicit col)
+  const int *colptr, *rowval, *mapped;                 // full aggregated pattern, map → triu position
+  double *nzval, *triu_nzval;                          // S values (full / triu)
+  const int *matptr, *nzind, *gids;                    // per-matrix segments over the triu pattern
+  const double *nzval_one, *nzval_two;
+  const int *tptr, *tmat;                              // transpose of the segments: triu position → (y index, value)
+  const double* tval;
+  // segmented-reduction plan
+  int n_short, n_chunks, n_long, n_short_blocks;
+  const int *short_ids, *chunk_beg, *chunk_end, *long_ids, *long_chunk_ptr;
+  double *chunk_partial0, *chunk_partial1;
+  double *UVt0, *UVt1;
+};
+
+struct DevLowRank {
+  int n_lr, ST;            // matrices, total columns
+  const double* Bcat;      // [ST][n]   column c contiguous
+  const double* Dcat;      // [ST]
+  const int* col_gid;      // [ST]  index into the (m+1)-vectors of the owning matrix
+  const int* mat_ptr;      // [n_lr+1] column range of matrix t
+  const int* mat_gid;      // [n_lr]
+};
+
+template <int VEC> struct vecd;
+template <> struct vecd<1> { double v[1]; };
+template <> struct vecd<2> { double v[2]; };
+
+template <int VEC>
+__device__ __forceinline__ vecd<VEC> ldrow(const double* __restrict__ p) {
+  vecd<VEC> o;
+  if constexpr (VEC == 2) {
+    const double2 t = *reinterpret_cast<const double2*>(p);
+    o.v[0] = t.x;
+    o.v[VEC - 1] = t.y;
+  } else {
+    o.v[0] = *p;
+  }
+  return o;
+}
+template <int VEC>
+__device__ __forceinline__ void strow(double* __restrict__ p, const vecd<VEC>& o) {
+  if constexpr (VEC == 2) {
+    double2 t;
+    t.x = o.v[0];
+    t.y = o.v[VEC - 1];
+    *reinterpret_cast<double2*>(p) = t;
+  } else {
+    *p = o.v[0];
+  }
+}
+
+// ---- SDDMM over the upper-triangular pattern --------------------------------------------------------
+// MODE 0: UVt0[q] = ⟨U_c, U_r⟩                                   𝒜_sparse_formUUt!  src/coreop.jl:174-186
+// MODE 1: UVt0[q] = (⟨U_c, V_r⟩ + ⟨V_c, U_r⟩)/2                   𝒜_sparse_formUVt!  src/coreop.jl:188-203
+// MODE 2: UVt0[q] = ⟨U_c, V_r⟩ + ⟨V_c, U_r⟩ ; UVt1[q] = ⟨V_c, V_r⟩  both line-search passes in one sweep
+//         (src/linesearch.jl:10-16 with U = Rt, V = dirt; the ×2 of :13 is already applied)
+template <int LPR, int VEC, int MODE>
+__global__ void __launch_bounds__(SDPLR_NT)
+k_sddmm(DevSparse sp, const double* __restrict__ U, const double* __restrict__ V, int r,
+        const DevCtrl* __restrict__ c, int check_done) {
+  if (check_done && c->done) return;
+  constexpr int G = SDPLR_NT / LPR;
+  const int lane = threadIdx.x % LPR;
+  const long long total = (long long)gridDim.x * G;
+  for (long long q = (long long)blockIdx.x * G + threadIdx.x / LPR; q < sp.nnzT; q += total) {
+    const long long row = sp.triu_rowval[q], col = sp.triu_colidx[q];
+    double a0 = 0.0, a1 = 0.0;
+    for (int ch = lane * VEC; ch < r; ch += LPR * VEC) {
+      const vecd<VEC> uc = ldrow<VEC>(U + col * r + ch), ur = ldrow<VEC>(U + row * r + ch);
+      if (MODE == 0) {
+#pragma unroll
+        for (int k = 0; k < VEC; k++) a0 += uc.v[k] * ur.v[k];
+      } else {
+        const vecd<VEC> vc = ldrow<VEC>(V + col * r + ch), vr = ldrow<VEC>(V + row * r + ch);
+#pragma unroll
+        for (int k = 0; k < VEC; k++) {
+          a0 += uc.v[k] * vr.v[k];
+          a0 += vc.v[k] * ur.v[k];
+          if (MODE == 2) a1 += vc.v[k] * vr.v[k];
+        }
+      }
+    }
+    a0 = group_sum<LPR>(a0);
+    if (MODE == 2) a1 = group_sum<LPR>(a1);
+    if (lane == 0) {
+      sp.UVt0[q] = (MODE == 1) ? a0 / 2 : a0;
+      if (MODE == 2) sp.UVt1[q] = a1;
+    }
+  }
+}
+
+// ---- segmented reduction over the per-matrix segments ----------------------------------------------
+// short segments: one thread each; long segments: cut into chunks, one block per chunk writes a
+// partial, k_seg_finalize adds a segment's partials in chunk order (deterministic, no atomics).
+template <bool DUAL>
+__global__ void __launch_bounds__(SDPLR_NT)
+k_segreduce(DevSparse sp, double* __restrict__ out0, double* __restrict__ out1,
+            const DevCtrl* __restrict__ c, int check_done) {
+  __shared__ double sh[2 * (SDPLR_NT / 64)];
+  if (check_done && c->done) return;
+  if ((int)blockIdx.x < sp.n_short_blocks) {
+    const int t = blockIdx.x * SDPLR_NT + threadIdx.x;
+    if (t >= sp.n_short) return;
+    const int k = sp.short_ids[t];
+    double v0 = 0.0, v1 = 0.0;
+    for (int e = sp.matptr[k]; e < sp.matptr[k + 1]; e++) {
+      const int q = sp.nzind[e];
+      const double w = sp.nzval_two[e];
+      v0 += sp.UVt0[q] * w;
+      if (DUAL) v1 += sp.UVt1[q] * w;
+    }
+    out0[sp.gids[k]] = v0;
+    if (DUAL) out1[sp.gids[k]] = v1;
+  } else {
+    const int ci = blockIdx.x - sp.n_short_blocks;
+    double v[2] = {0.0, 0.0};
+    for (int e = sp.chunk_beg[ci] + threadIdx.x; e < sp.chunk_end[ci]; e += SDPLR_NT) {
+      const int q = sp.nzind[e];
+      const double w = sp.nzval_two[e];
+      v[0] += sp.UVt0[q] * w;
+      if (DUAL) v[1] += sp.UVt1[q] * w;
+    }
+    block_sum<2>(v, sh);
+    if (threadIdx.x == 0) {
+      sp.chunk_partial0[ci] = v[0];
+      if (DUAL) sp.chunk_partial1[ci] = v[1];
+    }
+  }
+}
+template <bool DUAL>
+__global__ void __launch_bounds__(SDPLR_NT)
+k_seg_finalize(DevSparse sp, double* __restrict__ out0, double* __restrict__ out1,
+               const DevCtrl* __restrict__ c, int check_done) {
+  if (check_done && c->done) return;
+  const int w = (blockIdx.x * SDPLR_NT + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+  if (w >= sp.n_long) return;
+  const int k = sp.long_ids[w];
+  double v0 = 0.0, v1 = 0.0;
+  for (int ci = sp.long_chunk_ptr[w] + lane; ci < sp.long_chunk_ptr[w + 1]; ci += 64) {
+    v0 += sp.chunk_partial0[ci];
+    if (DUAL) v1 += sp.chunk_partial1[ci];
+  }
+  v0 = wave_sum(v0);
+  if (DUAL) v1 = wave_sum(v1);
+  if (lane == 0) {
+    out0[sp.gids[k]] = v0;
+    if (DUAL) out1[sp.gids[k]] = v1;
+  }
+}
+
+// ---- S assembly ------------------------------------------------------------------------------------
+// triu_nzval[q] = Σ_e nzval_one[e]·y[global id of e's matrix], summed in ascending matrix order — the
+// order in which the reference's CSC×vector product (src/coreop.jl:214-221) accumulates into it.
+__global__ void __launch_bounds__(SDPLR_NT)
+k_assemble_triu(DevSparse sp, const double* __restrict__ y, const DevCtrl* __restrict__ c, int check_done) {
+  if (check_done && c->done) return;
+  const long long stride = (long long)gridDim.x * SDPLR_NT;
+  for (long long q = (long long)blockIdx.x * SDPLR_NT + threadIdx.x; q < sp.nnzT; q += stride) {
+    double v = 0.0;
+    for (int e = sp.tptr[q]; e < sp.tptr[q + 1]; e++) v += sp.tval[e] * y[sp.tmat[e]];
+    sp.triu_nzval[q] = v;
+  }
+}
+// sparse_S.nzval[i] = triu_nzval[mappedto_triu[i]]   (src/coreop.jl:223-226)
+__global__ void __launch_bounds__(SDPLR_NT)
+k_assemble_full(DevSparse sp, const DevCtrl* __restrict__ c, int check_done) {
+  if (check_done && c->done) return;
+  const long long stride = (long long)gridDim.x * SDPLR_NT;
+  for (long long p = (long long)blockIdx.x * SDPLR_NT + threadIdx.x; p < sp.nnzS; p += stride)
+    sp.nzval[p] = sp.triu_nzval[sp.mapped[p]];
+}
+
+// ---- SpMM: Y[j,:] = scale·( Σ_{p∈col j} S[p]·X[rowval[p],:] + Σ_c WS[c,:]·B[c][j] ) ----------------------
+// 𝒜t!(y, x, aux, var) src/coreop.jl:260-279 (S is symmetric: column j of the CSC pattern lists row j's
+// neighbours); scale = 2 fuses BLAS.scal!(2, Gt) of g! (:315); with slot ≥ 0 the ‖Y‖² partials of
+// norm(Gt) (src/sdplr.jl:225) are produced on the way out.  WS[c,:] = y[gid]·D_c·(XᵀB)[c,:] is the
+// low-rank product of src/structs.jl:135-145 prepared by k_lr_finalize.
+template <int LPR, int VEC>
+__global__ void __launch_bounds__(SDPLR_NT)
+k_spmm(DevSparse sp, const double* __restrict__ X, double* __restrict__ Y, int r, double scale,
+       DevLowRank lr, const double* __restrict__ WS, int slot, double* __restrict__ partials,
+       const DevCtrl* __restrict__ c, int check_done) {
+  __shared__ double sh[8];
+  if (check_done && c->done) return;
+  constexpr int G = SDPLR_NT / LPR;
+  const int lane = threadIdx.x % LPR;
+  const long long total = (long long)gridDim.x * G;
+  double nrm = 0.0;
+  for (long long j = (long long)blockIdx.x * G + threadIdx.x / LPR; j < sp.n; j += total) {
+    const int beg = sp.colptr[j], end = sp.colptr[j + 1];
+    for (int ch = lane * VEC; ch < r; ch += LPR * VEC) {
+      vecd<VEC> acc;
+#pragma unroll
+      for (int k = 0; k < VEC; k++) acc.v[k] = 0.0;
+      int p = beg;
+      for (; p + 4 <= end; p += 4) {  // four independent row gathers in flight
+        const long long i0 = sp.rowval[p], i1 = sp.rowval[p + 1], i2 = sp.rowval[p + 2], i3 = sp.rowval[p + 3];
+        const double v0 = sp.nzval[p], v1 = sp.nzval[p + 1], v2 = sp.nzval[p + 2], v3 = sp.nzval[p + 3];
+        const vecd<VEC> x0 = ldrow<VEC>(X + i0 * r + ch), x1 = ldrow<VEC>(X + i1 * r + ch);
+        const vecd<VEC> x2 = ldrow<VEC>(X + i2 * r + ch), x3 = ldrow<VEC>(X + i3 * r + ch);
+#pragma unroll
+        for (int k = 0; k < VEC; k++) {
+          acc.v[k] += x0.v[k] * v0;
+          acc.v[k] += x1.v[k] * v1;
+          acc.v[k] += x2.v[k] * v2;
+          acc.v[k] += x3.v[k] * v3;
+        }
+      }
+      for (; p < end; p++) {
+        const long long i = sp.rowval[p];
+        const double v = sp.nzval[p];
+        const vecd<VEC> x = ldrow<VEC>(X + i * r + ch);
+#pragma unroll
+        for (int k = 0; k < VEC; k++) acc.v[k] += x.v[k] * v;
+      }
+      for (int cc = 0; cc < lr.ST; cc++) {
+        const double b = lr.Bcat[(long long)cc * sp.n + j];
+        const vecd<VEC> w = ldrow<VEC>(WS + (long long)cc * r + ch);
+#pragma unroll
+        for (int k = 0; k < VEC; k++) acc.v[k] += w.v[k] * b;
+      }
+#pragma unroll
+      for (int k = 0; k < VEC; k++) {
+        acc.v[k] *= scale;
+        nrm += acc.v[k] * acc.v[k];
+      }
+      strow<VEC>(Y + j * r + ch, acc);
+    }
+  }
+  if (slot >= 0) {
+    nrm = block_sum1(nrm, sh);
+    if (threadIdx.x == 0) slot_partials(partials, slot)[blockIdx.x] = nrm;
+  }
+}
+
+// ---- SpMV on an n-vector: y = S·x + Σ_c coef[c]·B[c][:], with the partial of ⟨x, y⟩ ----------------
+// 𝒜t!(y, aux, x, var) src/coreop.jl:281-300 for one column, 8 lanes per row; coef[c] =
+// y[gid]·D_c·⟨B[c], x⟩ (src/structs.jl:117-127) prepared by k_lr_btx_finalize.  The dot is
+// alpha[i] = v'·Av of the Lanczos recurrence (src/coreop.jl:484).
+__global__ void __launch_bounds__(SDPLR_NT)
+k_spmv(DevSparse sp, const double* __restrict__ x, double* __restrict__ y, DevLowRank lr,
+       const double* __restrict__ coef, int slot, double* __restrict__ partials,
+       const int* __restrict__ stop_flag) {
+  __shared__ double sh[8];
+  if (stop_flag && *stop_flag) return;
+  constexpr int LPR = 8, G = SDPLR_NT / LPR;
+  const int lane = threadIdx.x % LPR;
+  const long long total = (long long)gridDim.x * G;
+  double dot = 0.0;
+  for (long long j = (long long)blockIdx.x * G + threadIdx.x / LPR; j < sp.n; j += total) {
+    double t = 0.0;
+    for (int p = sp.colptr[j] + lane; p < sp.colptr[j + 1]; p += LPR) t += sp.nzval[p] * x[sp.rowval[p]];
+    t = group_sum<LPR>(t);
+    if (lane == 0) {
+      for (int cc = 0; cc < lr.ST; cc++) t += coef[cc] * lr.Bcat[(long long)cc * sp.n + j];
+      y[j] = t;
+      dot += x[j] * t;
+    }
+  }
+  if (slot >= 0) {
+    dot = block_sum1(dot, sh);
+    if (threadIdx.x == 0) slot_partials(partials, slot)[blockIdx.x] = dot;
+  }
+}
+
+// ---- low-rank projections W[f][c][k] = Σ_i B[c][i]·X_f[i][k] -------------------------------------------
+// `Ut * A.B` of tr_UtAU / tr_UtAV (src/coreop.jl:116,125-126) and `X * A.B` of mul! (src/structs.jl:142),
+// for up to two factors in one pass.  Per-block partials lr_part[((blk*F + f)*ST + c)*r + k].
+template <int LPR, int VEC, int F>
+__global__ void __launch_bounds__(SDPLR_NT)
+k_lr_project(DevLowRank lr, const double* __restrict__ X0, const double* __restrict__ X1, int n, int r,
+             double* __restrict__ lr_part, const DevCtrl* __restrict__ c, int check_done) {
+  __shared__ double sh[SDPLR_NT * VEC * SDPLR_LRMAX];
+  if (check_done && c->done) return;
+  constexpr int G = SDPLR_NT / LPR;
+  const int lane = threadIdx.x % LPR, g = threadIdx.x / LPR;
+  const long long rows_per_block = ((long long)n + gridDim.x - 1) / gridDim.x;
+  const long long lo = (long long)blockIdx.x * rows_per_block;
+  const long long hi = (lo + rows_per_block < n) ? lo + rows_per_block : n;
+  for (int f = 0; f < F; f++) {
+    const double* X = f == 0 ? X0 : X1;
+    for (int c0 = 0; c0 < lr.ST; c0 += SDPLR_LRMAX) {
+      const int nc = (lr.ST - c0 < SDPLR_LRMAX) ? lr.ST - c0 : SDPLR_LRMAX;
+      for (int chb = 0; chb < r; chb += LPR * VEC) {
+        const int ch = chb + lane * VEC;
+        double acc[SDPLR_LRMAX][VEC];
+#pragma unroll
+        for (int cc = 0; cc < SDPLR_LRMAX; cc++)
+#pragma unroll
+          for (int k = 0; k < VEC; k++) acc[cc][k] = 0.0;
+        if (ch < r)
+          for (long long i = lo + g; i < hi; i += G) {
+            const vecd<VEC> x = ldrow<VEC>(X + i * r + ch);
+#pragma unroll
+            for (int cc = 0; cc < SDPLR_LRMAX; cc++)
+              if (cc < nc) {
+                const double b = lr.Bcat[(long long)(c0 + cc) * n + i];
+#pragma unroll
+                for (int k = 0; k < VEC; k++) acc[cc][k] += x.v[k] * b;
+              }
+          }
+        __syncthreads();
+#pragma unroll
+        for (int cc = 0; cc < SDPLR_LRMAX; cc++)
+#pragma unroll
+          for (int k = 0; k < VEC; k++) sh[(g * SDPLR_LRMAX + cc) * (LPR * VEC) + lane * VEC + k] = acc[cc][k];
+        __syncthreads();
+        for (int t = threadIdx.x; t < nc * LPR * VEC; t += SDPLR_NT) {
+          const int cc = t / (LPR * VEC), k = t % (LPR * VEC);
+          if (chb + k < r) {
+            double s = 0.0;
+            for (int gg = 0; gg < G; gg++) s += sh[(gg * SDPLR_LRMAX + cc) * (LPR * VEC) + k];
+            lr_part[(((long long)blockIdx.x * F + f) * lr.ST + c0 + cc) * r + chb + k] = s;
+          }
+        }
+      }
+    }
+  }
+}
+
+// One block: W = Σ_blocks partials, then the mode-specific tail.
+//  mode 0: out0[gid_t] = Σ_c D_c Σ_k W0²            tr_UtAU, src/coreop.jl:115-120   (F = 1)
+//  mode 1: out0[gid_t] = Σ_c D_c Σ_k W0·W1          tr_UtAV, src/coreop.jl:122-130   (F = 2)
+//  mode 2: out0[gid_t] = 2·Σ D W0·W1 ; out1[gid_t] = Σ D W1²   line search (src/linesearch.jl:10-16)
+//  mode 3: WS[c][k] = yvec[gid_c]·D_c·W0[c][k]      mul!(Y, X, A, α, β), src/structs.jl:142-144
+__global__ void __launch_bounds__(SDPLR_NT)
+k_lr_finalize(DevLowRank lr, int r, int F, int nb, const double* __restrict__ lr_part, double* __restrict__ W,
+              int mode, double* __restrict__ out0, double* __restrict__ out1, const double* __restrict__ yvec,
+              double* __restrict__ WS, const DevCtrl* __restrict__ c, int check_done) {
+  if (check_done && c->done) return;
+  const int per = lr.ST * r;
+  for (int t = threadIdx.x; t < F * per; t += SDPLR_NT) {
+    const int f = t / per, ck = t % per;
+    double s = 0.0;
+    for (int b = 0; b < nb; b++) s += lr_part[((long long)b * F + f) * per + ck];
+    W[t] = s;
+  }
+  __syncthreads();
+  if (mode == 3) {
+    for (int t = threadIdx.x; t < per; t += SDPLR_NT) {
+      const int cc = t / r;
+      WS[t] = yvec[lr.col_gid[cc]] * lr.Dcat[cc] * W[t];
+    }
+    return;
+  }
+  for (int t = threadIdx.x; t < lr.n_lr; t += SDPLR_NT) {
+    double s0 = 0.0, s1 = 0.0;
+    for (int cc = lr.mat_ptr[t]; cc < lr.mat_ptr[t + 1]; cc++) {
+      double d0 = 0.0, d1 = 0.0;
+      for (int k = 0; k < r; k++) {
+        const double w0 = W[cc * r + k];
+        if (mode == 0) d0 += w0 * w0;
+        else {
+          const double w1 = W[per + cc * r + k];
+          d0 += w0 * w1;
+          if (mode == 2) d1 += w1 * w1;
+        }
+      }
+      s0 += d0 * lr.Dcat[cc];
+      s1 += d1 * lr.Dcat[cc];
+    }
+    out0[lr.mat_gid[t]] = (mode == 2) ? 2.0 * s0 : s0;
+    if (mode == 2) out1[lr.mat_gid[t]] = s1;
+  }
+}
+
+// ⟨B[c], x⟩ partials for the SpMV low-rank term; grid.y = column
+__global__ void __launch_bounds__(SDPLR_NT)
+k_lr_btx(DevLowRank lr, const double* __restrict__ x, int n, double* __restrict__ part /* [ST][gridDim.x] */,
+         const int* __restrict__ stop_flag) {
+  __shared__ double sh[8];
+  if (stop_flag && *stop_flag) return;
+  const int cc = blockIdx.y;
+  double t = 0.0;
+  const long long stride = (long long)gridDim.x * SDPLR_NT;
+  for (long long i = (long long)blockIdx.x * SDPLR_NT + threadIdx.x; i < n; i += stride)
+    t += lr.Bcat[(long long)cc * n + i] * x[i];
+  t = block_sum1(t, sh);
+  if (threadIdx.x == 0) part[(long long)cc * gridDim.x + blockIdx.x] = t;
+}
+__global__ void __launch_bounds__(SDPLR_NT)
+k_lr_btx_finalize(DevLowRank lr, int nb, const double* __restrict__ part, const double* __restrict__ yvec,
+                  double* __restrict__ coef, const int* __restrict__ stop_flag) {
+  __shared__ double sh[8];
+  if (stop_flag && *stop_flag) return;
+  for (int cc = 0; cc < lr.ST; cc++) {
+    const double s = reduce_partials(part + (long long)cc * nb, nb, sh);
+    if (threadIdx.x == 0) coef[cc] = yvec[lr.col_gid[cc]] * lr.Dcat[cc] * s;
+    __syncthreads();
+  }
+}

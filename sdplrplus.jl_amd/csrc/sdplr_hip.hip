@@ -1,0 +1,1237 @@
+// sdplr_hip.hip — host side of libsdplr_hip.so: the C ABI of include/sdplr_hip.h over the gfx950
+// kernels in k_dense.h / k_sparse.h / k_scalar.h.  One solver handle = one SDP instance resident in
+// HBM + one HIP stream.  There is no CPU fallback: without a device every entry point fails.
+#include "../../include/sdplr_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstddef>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "common.h"
+#include "k_dense.h"
+#include "k_scalar.h"
+#include "k_sparse.h"
+
+namespace {
+
+std::string g_err;
+
+struct LowRankHost {
+  int64_t gid, s;
+  std::vector<double> B, D;
+};
+
+struct ProfEntry {
+  int64_t launches = 0;
+  double ms = 0.0;
+};
+
+}  // namespace
+
+struct sdplr_hip_solver {
+  int64_t n = 0, m = 0, r = 0, h = 0;
+  bool finalized = false;
+  hipStream_t stream = nullptr;
+  std::string err;
+
+  // ---- host staging of the layout (released at finalize) ----
+  bool have_sparse = false;
+  int64_t n_sparse = 0, nnzT = 0, nnzS = 0, nnzAgg = 0;
+  std::vector<int> h_matptr, h_nzind, h_gids, h_tcp, h_trv, h_fcp, h_frv, h_mapped;
+  std::vector<double> h_one, h_two;
+  std::vector<LowRankHost> h_lr;
+
+  // ---- device state ----
+  std::vector<void*> allocs;
+  DevSparse sp{};
+  DevLowRank lr{};
+  bool all_covered = false;  // every slot of an (m+1)-vector is written by some matrix
+  FactorArena arena{};
+  long long N = 0;
+  double *lambda = nullptr, *lambda_ub = nullptr, *b = nullptr, *y = nullptr, *pv_raw = nullptr,
+         *pv_lb = nullptr, *pv = nullptr, *A_RD = nullptr, *A_DD = nullptr;
+  DevCtrl* ctrl = nullptr;   // device
+  DevCtrl* hc = nullptr;     // pinned host shadow
+  double* partials = nullptr;
+  double *lz_buf[3] = {nullptr, nullptr, nullptr}, *lz_v0 = nullptr, *lz_alpha = nullptr, *lz_beta = nullptr;
+  int64_t lz_cap = 0;
+  double *lr_part = nullptr, *lr_W = nullptr, *lr_WS = nullptr, *lr_coef = nullptr, *lr_btx_part = nullptr;
+  int nb_lr = 1;
+
+  // kernel shapes
+  int LPR = 1, VEC = 1, HM = 4;
+  int nb_dense = 1, nb_m = 1, nb_sddmm = 1, nb_spmm = 1, nb_spmv = 1, nb_nnzT = 1, nb_nnzS = 1, nb_n = 1;
+
+  // Gram bookkeeping (see k_dense.h)
+  bool gram_dirty = false, sg_stale = false, ynext_pending = false;
+
+  // profiling
+  bool prof_on = false;
+  std::string prof_filter;
+  std::vector<std::string> prof_names;
+  std::map<std::string, int> prof_index;
+  std::vector<ProfEntry> prof;
+  struct Pending { int id; hipEvent_t a, b; };
+  std::vector<Pending> prof_pending;
+  std::vector<hipEvent_t> ev_pool;
+};
+
+namespace {
+using S = sdplr_hip_solver;
+
+int fail(S* s, int code, const std::string& msg) {
+  if (s) s->err = msg; else g_err = msg;
+  return code;
+}
+#define HIPCK(s, call)                                                                      \
+  do {                                                                                      \
+    hipError_t e__ = (call);                                                                \
+    if (e__ != hipSuccess)                                                                  \
+      return fail((s), SDPLR_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e__));  \
+  } while (0)
+#define NEED_FINAL(s)                                                            \
+  do {                                                                           \
+    if (!(s)) return fail(nullptr, SDPLR_ERR_INVALID_ARG, "null handle");        \
+    if (!(s)->finalized) return fail((s), SDPLR_ERR_STATE, "not finalized");     \
+  } while (0)
+
+int have_device() {
+  int c = 0;
+  if (hipGetDeviceCount(&c) != hipSuccess) return 0;
+  return c;
+}
+
+template <typename T>
+int dalloc(S* s, T** p, size_t count) {
+  void* q = nullptr;
+  hipError_t e = hipMalloc(&q, std::max<size_t>(count, 1) * sizeof(T));
+  if (e != hipSuccess) return fail(s, SDPLR_ERR_ALLOC, std::string("hipMalloc: ") + hipGetErrorString(e));
+  s->allocs.push_back(q);
+  *p = (T*)q;
+  return SDPLR_OK;
+}
+template <typename T>
+int upload(S* s, const T** dst, const std::vector<T>& v) {
+  T* p = nullptr;
+  int rc = dalloc(s, &p, v.size());
+  if (rc) return rc;
+  if (!v.empty()) HIPCK(s, hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+  *dst = p;
+  return SDPLR_OK;
+}
+int dzero(S* s, double** p, size_t count) {
+  int rc = dalloc(s, p, count);
+  if (rc) return rc;
+  HIPCK(s, hipMemset(*p, 0, std::max<size_t>(count, 1) * sizeof(double)));
+  return SDPLR_OK;
+}
+
+// ---- profiling (hipEvent pairs on the solver's stream) -----------------------------------------------
+struct ProfScope {
+  S* s;
+  bool on;
+  S::Pending p{};
+  ProfScope(S* s_, const char* name) : s(s_), on(s_->prof_on) {
+    if (on && !s->prof_filter.empty() && s->prof_filter != name) on = false;
+    if (!on) return;
+    auto it = s->prof_index.find(name);
+    int id;
+    if (it == s->prof_index.end()) {
+      id = (int)s->prof_names.size();
+      s->prof_names.push_back(name);
+      s->prof_index[name] = id;
+      s->prof.emplace_back();
+    } else {
+      id = it->second;
+    }
+    auto get = [&]() {
+      hipEvent_t e;
+      if (!s->ev_pool.empty()) { e = s->ev_pool.back(); s->ev_pool.pop_back(); }
+      else (void)hipEventCreate(&e);
+      return e;
+    };
+    p.id = id;
+    p.a = get();
+    p.b = get();
+    (void)hipEventRecord(p.a, s->stream);
+  }
+  ~ProfScope() {
+    if (!on) return;
+    (void)hipEventRecord(p.b, s->stream);
+    s->prof_pending.push_back(p);
+  }
+};
+void prof_drain(S* s) {
+  if (s->prof_pending.empty()) return;
+  (void)hipStreamSynchronize(s->stream);
+  for (auto& p : s->prof_pending) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+      s->prof[p.id].launches++;
+      s->prof[p.id].ms += ms;
+    }
+    s->ev_pool.push_back(p.a);
+    s->ev_pool.push_back(p.b);
+  }
+  s->prof_pending.clear();
+}
+
+// ---- control block transfer -------------------------------------------------------------------------
+int pull(S* s) {
+  HIPCK(s, hipMemcpyAsync(s->hc, s->ctrl, sizeof(DevCtrl), hipMemcpyDeviceToHost, s->stream));
+  HIPCK(s, hipStreamSynchronize(s->stream));
+  return SDPLR_OK;
+}
+int push(S* s) {
+  HIPCK(s, hipMemcpyAsync(s->ctrl, s->hc, sizeof(DevCtrl), hipMemcpyHostToDevice, s->stream));
+  HIPCK(s, hipStreamSynchronize(s->stream));
+  return SDPLR_OK;
+}
+int sync_check(S* s) {
+  HIPCK(s, hipGetLastError());
+  HIPCK(s, hipStreamSynchronize(s->stream));
+  return SDPLR_OK;
+}
+
+int blocks_for(long long work, int per_block, int cap) {
+  long long b = (work + per_block - 1) / per_block;
+  if (b < 1) b = 1;
+  if (b > cap) b = cap;
+  return (int)b;
+}
+
+double* factor_ptr(S* s, int32_t slot) {
+  if (slot == SDPLR_F_RT) return aslot(s->arena, AS_R);
+  if (slot == SDPLR_F_GT) return aslot(s->arena, AS_G);
+  if (slot == SDPLR_F_DIRT) return aslot(s->arena, AS_D);
+  if (slot >= SDPLR_F_LBFGS_S && slot < SDPLR_F_LBFGS_S + s->h) return aslot(s->arena, AS_S0 + (slot - SDPLR_F_LBFGS_S));
+  if (slot >= SDPLR_F_LBFGS_Y && slot < SDPLR_F_LBFGS_Y + s->h) return aslot(s->arena, as_y0(s->arena) + (slot - SDPLR_F_LBFGS_Y));
+  return nullptr;
+}
+void note_factor_written(S* s, int32_t slot) {
+  if (slot == SDPLR_F_GT) s->sg_stale = true;
+  if (slot >= SDPLR_F_LBFGS_S) s->gram_dirty = true;
+}
+
+// sub-wave shape for a given rank: VEC doubles per lane, LPR lanes per row (power of two ≤ 64)
+void choose_shape(S* s) {
+  s->VEC = (s->r % 2 == 0) ? 2 : 1;
+  long long need = (s->r + s->VEC - 1) / s->VEC;
+  int lpr = 1;
+  while (lpr < need && lpr < 64) lpr <<= 1;
+  s->LPR = lpr;
+  s->HM = s->h <= 4 ? 4 : (s->h <= 8 ? 8 : 16);
+}
+
+int alloc_factors(S* s) {
+  s->N = s->n * s->r;
+  long long stride = (s->N + 31) / 32 * 32;
+  s->arena.stride = stride;
+  s->arena.h = (int)s->h;
+  const size_t used = (size_t)(3 + 2 * s->h);  // R, G, dirt, s_0..s_{h-1}, y_0..y_{h-1}
+  double* base = nullptr;
+  hipError_t e = hipMalloc((void**)&base, std::max<size_t>(used * stride, 1) * sizeof(double));
+  if (e != hipSuccess) return fail(s, SDPLR_ERR_ALLOC, std::string("hipMalloc(factors): ") + hipGetErrorString(e));
+  HIPCK(s, hipMemset(base, 0, used * stride * sizeof(double)));
+  s->arena.base = base;
+  choose_shape(s);
+  const int G = SDPLR_NT / s->LPR;
+  s->nb_dense = blocks_for((s->N + 1) / 2, SDPLR_NT, SDPLR_MAXNB);
+  s->nb_sddmm = blocks_for(s->nnzT, G, 8192);
+  s->nb_spmm = blocks_for(s->n, G, SDPLR_MAXNB);
+  return SDPLR_OK;
+}
+
+}  // namespace
+
+// ================================================================================================
+// device management / construction
+// ================================================================================================
+extern "C" {
+
+const char* sdplr_hip_version(void) { return "sdplr_hip 0.1 (gfx950, FP64)"; }
+const char* sdplr_hip_last_error(const sdplr_hip_solver* s) { return s ? s->err.c_str() : g_err.c_str(); }
+
+int32_t sdplr_hip_device_synchronize(void) {
+  if (have_device() <= 0) return fail(nullptr, SDPLR_ERR_NO_DEVICE, "no HIP device");
+  hipError_t e = hipDeviceSynchronize();
+  if (e != hipSuccess) return fail(nullptr, SDPLR_ERR_HIP, std::string("hipDeviceSynchronize: ") + hipGetErrorString(e));
+  return SDPLR_OK;
+}
+int32_t sdplr_hip_device_count(int32_t* count) {
+  if (!count) return SDPLR_ERR_INVALID_ARG;
+  *count = have_device();
+  return SDPLR_OK;
+}
+int32_t sdplr_hip_set_device(int32_t device) {
+  if (have_device() <= 0) return fail(nullptr, SDPLR_ERR_NO_DEVICE, "no HIP device");
+  hipError_t e = hipSetDevice(device);
+  if (e != hipSuccess) return fail(nullptr, SDPLR_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(e));
+  return SDPLR_OK;
+}
+
+int32_t sdplr_hip_create(int64_t n, int64_t m, int64_t r, int64_t h, sdplr_hip_solver** out) {
+  if (!out) return fail(nullptr, SDPLR_ERR_INVALID_ARG, "create: null out");
+  *out = nullptr;
+  if (n < 1 || m < 0 || r < 1 || h < 0) return fail(nullptr, SDPLR_ERR_INVALID_ARG, "create: bad sizes");
+  if (h > SDPLR_HMAX) return fail(nullptr, SDPLR_ERR_INVALID_ARG, "create: numlbfgsvecs > 16 is not supported");
+  if (n >= (1LL << 31) - 1 || m >= (1LL << 31) - 2 || n * r >= (1LL << 40))
+    return fail(nullptr, SDPLR_ERR_INVALID_ARG, "create: sizes exceed the int32 index range of the device layout");
+  if (have_device() <= 0) return fail(nullptr, SDPLR_ERR_NO_DEVICE, "no usable HIP device (libsdplr_hip has no CPU fallback)");
+  S* s = new S();
+  s->n = n; s->m = m; s->r = r; s->h = h;
+  *out = s;
+  return SDPLR_OK;
+}
+
+int32_t sdplr_hip_set_sparse(S* s, int64_t base, int64_t n_sparse, const int64_t* matptr,
+                             const int64_t* nzind, const double* one, const double* two,
+                             const int64_t* gids, int64_t nnzT, const int64_t* tcp, const int64_t* trv,
+                             int64_t nnzS, const int64_t* fcp, const int64_t* frv, const int64_t* mapped) {
+  if (!s) return fail(nullptr, SDPLR_ERR_INVALID_ARG, "null handle");
+  if (s->finalized || s->have_sparse) return fail(s, SDPLR_ERR_STATE, "set_sparse: already set / finalized");
+  if (base != 0 && base != 1) return fail(s, SDPLR_ERR_INVALID_ARG, "set_sparse: index_base must be 0 or 1");
+  if (n_sparse < 0 || nnzT < 0 || nnzS < 0 || !matptr || !tcp || !fcp)
+    return fail(s, SDPLR_ERR_INVALID_ARG, "set_sparse: bad sizes / null arrays");
+  const int64_t n = s->n, lim = (1LL << 31) - 2;
+  if (nnzT > lim || nnzS > lim || n_sparse > lim) return fail(s, SDPLR_ERR_INVALID_ARG, "set_sparse: nnz exceeds int32");
+  const int64_t nnzAgg = matptr[n_sparse] - base;
+  if (matptr[0] - base != 0 || nnzAgg < 0 || nnzAgg > lim) return fail(s, SDPLR_ERR_INVALID_ARG, "set_sparse: bad matptr");
+  s->h_matptr.resize(n_sparse + 1);
+  for (int64_t k = 0; k <= n_sparse; k++) {
+    s->h_matptr[k] = (int)(matptr[k] - base);
+    if (k > 0 && s->h_matptr[k] < s->h_matptr[k - 1]) return fail(s, SDPLR_ERR_INVALID_ARG, "set_sparse: matptr not monotone");
+  }
+  s->h_nzind.resize(nnzAgg); s->h_one.resize(nnzAgg); s->h_two.resize(nnzAgg);
+  for (int64_t e = 0; e < nnzAgg; e++) {
+    const int64_t q = nzind[e] - base;
+    if (q < 0 || q >= nnzT) return fail(s, SDPLR_ERR_INVALID_ARG, "set_sparse: nzind out of range");
+    s->h_nzind[e] = (int)q; s->h_one[e] = one[e]; s->h_two[e] = two[e];
+  }
+  s->h_gids.resize(n_sparse);
+  for (int64_t k = 0; k < n_sparse; k++) {
+    const int64_t g = gids[k] - base;
+    if (g < 0 || g > s->m) return fail(s, SDPLR_ERR_INVALID_ARG, "set_sparse: global index out of range");
+    s->h_gids[k] = (int)g;
+  }
+  s->h_tcp.resize(n + 1); s->h_fcp.resize(n + 1);
+  for (int64_t j = 0; j <= n; j++) {
+    s->h_tcp[j] = (int)(tcp[j] - base); s->h_fcp[j] = (int)(fcp[j] - base);
+    if (j > 0 && (s->h_tcp[j] < s->h_tcp[j - 1] || s->h_fcp[j] < s->h_fcp[j - 1]))
+      return fail(s, SDPLR_ERR_INVALID_ARG, "set_sparse: colptr not monotone");
+  }
+  if (s->h_tcp[0] != 0 || s->h_fcp[0] != 0 || s->h_tcp[n] != nnzT || s->h_fcp[n] != nnzS)
+    return fail(s, SDPLR_ERR_INVALID_ARG, "set_sparse: colptr/nnz mismatch");
+  s->h_trv.resize(nnzT);
+  for (int64_t p = 0; p < nnzT; p++) {
+    const int64_t i = trv[p] - base;
+    if (i < 0 || i >= n) return fail(s, SDPLR_ERR_INVALID_ARG, "set_sparse: triu rowval out of range");
+    s->h_trv[p] = (int)i;
+  }
+  s->h_frv.resize(nnzS); s->h_mapped.resize(nnzS);
+  for (int64_t p = 0; p < nnzS; p++) {
+    const int64_t i = frv[p] - base, q = mapped[p] - base;
+    if (i < 0 || i >= n || q < 0 || q >= nnzT) return fail(s, SDPLR_ERR_INVALID_ARG, "set_sparse: full pattern out of range");
+    s->h_frv[p] = (int)i; s->h_mapped[p] = (int)q;
+  }
+  s->n_sparse = n_sparse; s->nnzT = nnzT; s->nnzS = nnzS; s->nnzAgg = nnzAgg;
+  s->have_sparse = true;
+  return SDPLR_OK;
+}
+
+int32_t sdplr_hip_add_symlowrank(S* s, int64_t base, int64_t gid, int64_t sc, const double* B, const double* D) {
+  if (!s) return fail(nullptr, SDPLR_ERR_INVALID_ARG, "null handle");
+  if (s->finalized) return fail(s, SDPLR_ERR_STATE, "add_symlowrank: already finalized");
+  if (sc < 1 || !B || !D || gid - base < 0 || gid - base > s->m) return fail(s, SDPLR_ERR_INVALID_ARG, "add_symlowrank: bad args");
+  LowRankHost L;
+  L.gid = gid - base; L.s = sc;
+  L.B.assign(B, B + s->n * sc);
+  L.D.assign(D, D + sc);
+  s->h_lr.push_back(std::move(L));
+  return SDPLR_OK;
+}
+
+int32_t sdplr_hip_finalize(S* s) {
+  if (!s) return fail(nullptr, SDPLR_ERR_INVALID_ARG, "null handle");
+  if (s->finalized) return fail(s, SDPLR_ERR_STATE, "finalize: already finalized");
+  HIPCK(s, hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+  const int64_t n = s->n, m = s->m;
+  int rc;
+  // ---- sparse layout ----
+  DevSparse& sp = s->sp;
+  sp.n = (int)n; sp.nnzT = (int)s->nnzT; sp.nnzS = (int)s->nnzS; sp.nnzAgg = (int)s->nnzAgg; sp.n_sparse = (int)s->n_sparse;
+  if (!s->have_sparse) { s->h_tcp.assign(n + 1, 0); s->h_fcp.assign(n + 1, 0); s->h_matptr.assign(1, 0); }
+  std::vector<int> colidx(s->nnzT);
+  for (int64_t j = 0; j < n; j++)
+    for (int p = s->h_tcp[j]; p < s->h_tcp[j + 1]; p++) colidx[p] = (int)j;
+  // transpose of the per-matrix segments: triu position → list of (y index, nzval_one), ascending matrix
+  std::vector<int> tptr(s->nnzT + 1, 0), tmat(s->nnzAgg);
+  std::vector<double> tval(s->nnzAgg);
+  for (int64_t e = 0; e < s->nnzAgg; e++) tptr[s->h_nzind[e] + 1]++;
+  for (int64_t q = 0; q < s->nnzT; q++) tptr[q + 1] += tptr[q];
+  {
+    std::vector<int> fill(tptr.begin(), tptr.end() - 1);
+    for (int64_t k = 0; k < s->n_sparse; k++)
+      for (int e = s->h_matptr[k]; e < s->h_matptr[k + 1]; e++) {
+        const int pos = fill[s->h_nzind[e]]++;
+        tmat[pos] = s->h_gids[k];
+        tval[pos] = s->h_one[e];
+      }
+  }
+  // segmented-reduction plan
+  const int SHORT_MAX = 16, CHUNK = 2048;
+  std::vector<int> short_ids, chunk_beg, chunk_end, long_ids, long_chunk_ptr(1, 0);
+  for (int64_t k = 0; k < s->n_sparse; k++) {
+    const int len = s->h_matptr[k + 1] - s->h_matptr[k];
+    if (len <= SHORT_MAX) { short_ids.push_back((int)k); continue; }
+    long_ids.push_back((int)k);
+    for (int bgn = s->h_matptr[k]; bgn < s->h_matptr[k + 1]; bgn += CHUNK) {
+      chunk_beg.push_back(bgn);
+      chunk_end.push_back(std::min(bgn + CHUNK, s->h_matptr[k + 1]));
+    }
+    long_chunk_ptr.push_back((int)chunk_beg.size());
+  }
+  sp.n_short = (int)short_ids.size(); sp.n_chunks = (int)chunk_beg.size(); sp.n_long = (int)long_ids.size();
+  sp.n_short_blocks = (sp.n_short + SDPLR_NT - 1) / SDPLR_NT;
+  {
+    std::vector<char> cov(m + 1, 0);
+    for (int g : s->h_gids) cov[g] = 1;
+    for (auto& L : s->h_lr) cov[L.gid] = 1;
+    s->all_covered = std::all_of(cov.begin(), cov.end(), [](char c) { return c != 0; });
+  }
+#define UP(field, vec) if ((rc = upload(s, &sp.field, vec))) return rc
+  UP(triu_colptr, s->h_tcp); UP(triu_rowval, s->h_trv); UP(triu_colidx, colidx);
+  UP(colptr, s->h_fcp); UP(rowval, s->h_frv); UP(mapped, s->h_mapped);
+  UP(matptr, s->h_matptr); UP(nzind, s->h_nzind); UP(gids, s->h_gids);
+  UP(nzval_one, s->h_one); UP(nzval_two, s->h_two);
+  UP(tptr, tptr); UP(tmat, tmat); UP(tval, tval);
+  UP(short_ids, short_ids); UP(chunk_beg, chunk_beg); UP(chunk_end, chunk_end);
+  UP(long_ids, long_ids); UP(long_chunk_ptr, long_chunk_ptr);
+#undef UP
+  if ((rc = dzero(s, &sp.nzval, s->nnzS))) return rc;
+  if ((rc = dzero(s, &sp.triu_nzval, s->nnzT))) return rc;
+  if ((rc = dzero(s, &sp.UVt0, s->nnzT))) return rc;
+  if ((rc = dzero(s, &sp.UVt1, s->nnzT))) return rc;
+  if ((rc = dzero(s, &sp.chunk_partial0, sp.n_chunks))) return rc;
+  if ((rc = dzero(s, &sp.chunk_partial1, sp.n_chunks))) return rc;
+  // ---- low-rank matrices ----
+  DevLowRank& lr = s->lr;
+  lr.n_lr = (int)s->h_lr.size();
+  {
+    std::vector<double> Bcat, Dcat;
+    std::vector<int> col_gid, mat_ptr(1, 0), mat_gid;
+    for (auto& L : s->h_lr) {
+      Bcat.insert(Bcat.end(), L.B.begin(), L.B.end());
+      Dcat.insert(Dcat.end(), L.D.begin(), L.D.end());
+      for (int64_t t = 0; t < L.s; t++) col_gid.push_back((int)L.gid);
+      mat_ptr.push_back((int)col_gid.size());
+      mat_gid.push_back((int)L.gid);
+    }
+    lr.ST = (int)col_gid.size();
+    if ((rc = upload(s, &lr.Bcat, Bcat))) return rc;
+    if ((rc = upload(s, &lr.Dcat, Dcat))) return rc;
+    if ((rc = upload(s, &lr.col_gid, col_gid))) return rc;
+    if ((rc = upload(s, &lr.mat_ptr, mat_ptr))) return rc;
+    if ((rc = upload(s, &lr.mat_gid, mat_gid))) return rc;
+  }
+  // ---- vectors ----
+  if ((rc = dzero(s, &s->lambda, m))) return rc;
+  if ((rc = dzero(s, &s->lambda_ub, m))) return rc;
+  if ((rc = dzero(s, &s->b, m))) return rc;
+  if ((rc = dzero(s, &s->pv_lb, m))) return rc;
+  if ((rc = dzero(s, &s->pv, m))) return rc;
+  if ((rc = dzero(s, &s->y, m + 1))) return rc;
+  if ((rc = dzero(s, &s->pv_raw, m + 1))) return rc;
+  if ((rc = dzero(s, &s->A_RD, m + 1))) return rc;
+  if ((rc = dzero(s, &s->A_DD, m + 1))) return rc;
+  {  // all-equality defaults (src/structs.jl:266-268, :247)
+    std::vector<double> inf(m, std::numeric_limits<double>::infinity()), ninf(m, -std::numeric_limits<double>::infinity());
+    if (m > 0) {
+      HIPCK(s, hipMemcpy(s->lambda_ub, inf.data(), m * sizeof(double), hipMemcpyHostToDevice));
+      HIPCK(s, hipMemcpy(s->pv_lb, ninf.data(), m * sizeof(double), hipMemcpyHostToDevice));
+    }
+  }
+  if ((rc = dzero(s, &s->partials, (size_t)SDPLR_NSLOT * SDPLR_MAXNB))) return rc;
+  for (int k = 0; k < 3; k++)
+    if ((rc = dzero(s, &s->lz_buf[k], n))) return rc;
+  if ((rc = dzero(s, &s->lz_v0, n))) return rc;
+  s->nb_lr = 256;
+  if ((rc = dzero(s, &s->lr_btx_part, (size_t)std::max(lr.ST, 1) * 64))) return rc;
+  if ((rc = dzero(s, &s->lr_coef, std::max(lr.ST, 1)))) return rc;
+  {
+    DevCtrl* d = nullptr;
+    if ((rc = dalloc(s, &d, 1))) return rc;
+    s->ctrl = d;
+    HIPCK(s, hipHostMalloc((void**)&s->hc, sizeof(DevCtrl), hipHostMallocDefault));
+    memset(s->hc, 0, sizeof(DevCtrl));
+    s->hc->sigma = 2.0;             // config.σ_0 default, src/options.jl:5
+    s->hc->alpha_max = 1.0;
+    s->hc->latest = (int)s->h;      // src/lbfgs.jl:45
+    HIPCK(s, hipMemcpy(s->ctrl, s->hc, sizeof(DevCtrl), hipMemcpyHostToDevice));
+  }
+  if ((rc = alloc_factors(s))) return rc;
+  s->nb_m = blocks_for(m + 1, SDPLR_NT, 256);
+  s->nb_spmv = blocks_for(n, SDPLR_NT / 8, SDPLR_MAXNB);
+  s->nb_nnzT = blocks_for(s->nnzT, SDPLR_NT, 4096);
+  s->nb_nnzS = blocks_for(s->nnzS, SDPLR_NT, 4096);
+  s->nb_n = blocks_for(n, SDPLR_NT, SDPLR_MAXNB);
+  // low-rank scratch depends on r: allocated for the largest rank seen (reset_rank re-allocates)
+  if ((rc = dzero(s, &s->lr_part, (size_t)s->nb_lr * 2 * std::max(lr.ST, 1) * s->r))) return rc;
+  if ((rc = dzero(s, &s->lr_W, (size_t)2 * std::max(lr.ST, 1) * s->r))) return rc;
+  if ((rc = dzero(s, &s->lr_WS, (size_t)std::max(lr.ST, 1) * s->r))) return rc;
+  // release host staging
+  std::vector<int>().swap(s->h_nzind); std::vector<int>().swap(s->h_trv); std::vector<int>().swap(s->h_frv);
+  std::vector<int>().swap(s->h_mapped); std::vector<double>().swap(s->h_one); std::vector<double>().swap(s->h_two);
+  for (auto& L : s->h_lr) { std::vector<double>().swap(L.B); }
+  s->finalized = true;
+  return SDPLR_OK;
+}
+
+int32_t sdplr_hip_destroy(S* s) {
+  if (!s) return SDPLR_OK;
+  if (s->stream) (void)hipStreamSynchronize(s->stream);
+  for (auto& p : s->prof_pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
+  for (auto e : s->ev_pool) (void)hipEventDestroy(e);
+  for (void* p : s->allocs) (void)hipFree(p);
+  if (s->arena.base) (void)hipFree(s->arena.base);
+  if (s->lz_alpha) (void)hipFree(s->lz_alpha);
+  if (s->lz_beta) (void)hipFree(s->lz_beta);
+  if (s->hc) (void)hipHostFree(s->hc);
+  if (s->stream) (void)hipStreamDestroy(s->stream);
+  delete s;
+  return SDPLR_OK;
+}
+
+int32_t sdplr_hip_reset_rank(S* s, int64_t new_r) {
+  NEED_FINAL(s);
+  if (new_r < 1 || s->n * new_r >= (1LL << 40)) return fail(s, SDPLR_ERR_INVALID_ARG, "reset_rank: bad rank");
+  HIPCK(s, hipStreamSynchronize(s->stream));
+  if (s->arena.base) (void)hipFree(s->arena.base);
+  s->arena.base = nullptr;
+  s->r = new_r;
+  int rc = alloc_factors(s);
+  if (rc) return rc;
+  const int64_t m = s->m;
+  HIPCK(s, hipMemset(s->lambda, 0, std::max<int64_t>(m, 1) * sizeof(double)));
+  HIPCK(s, hipMemset(s->pv, 0, std::max<int64_t>(m, 1) * sizeof(double)));
+  for (double* p : {s->y, s->pv_raw, s->A_RD, s->A_DD}) HIPCK(s, hipMemset(p, 0, (m + 1) * sizeof(double)));
+  if ((rc = dzero(s, &s->lr_part, (size_t)s->nb_lr * 2 * std::max(s->lr.ST, 1) * s->r))) return rc;
+  if ((rc = dzero(s, &s->lr_W, (size_t)2 * std::max(s->lr.ST, 1) * s->r))) return rc;
+  if ((rc = dzero(s, &s->lr_WS, (size_t)std::max(s->lr.ST, 1) * s->r))) return rc;
+  if ((rc = pull(s))) return rc;
+  DevCtrl keep = *s->hc;
+  memset(s->hc, 0, sizeof(DevCtrl));
+  s->hc->sigma = keep.sigma;
+  s->hc->alpha_max = 1.0;
+  s->hc->latest = (int)s->h;
+  s->gram_dirty = s->sg_stale = s->ynext_pending = false;
+  return push(s);
+}
+
+// ================================================================================================
+// state transfer
+// ================================================================================================
+int32_t sdplr_hip_set_factor(S* s, int32_t slot, const double* h) {
+  NEED_FINAL(s);
+  double* p = factor_ptr(s, slot);
+  if (!p || !h) return fail(s, SDPLR_ERR_INVALID_ARG, "set_factor: bad slot");
+  HIPCK(s, hipMemcpyAsync(p, h, s->N * sizeof(double), hipMemcpyHostToDevice, s->stream));
+  HIPCK(s, hipStreamSynchronize(s->stream));
+  note_factor_written(s, slot);
+  return SDPLR_OK;
+}
+int32_t sdplr_hip_get_factor(S* s, int32_t slot, double* h) {
+  NEED_FINAL(s);
+  double* p = factor_ptr(s, slot);
+  if (!p || !h) return fail(s, SDPLR_ERR_INVALID_ARG, "get_factor: bad slot");
+  HIPCK(s, hipMemcpyAsync(h, p, s->N * sizeof(double), hipMemcpyDeviceToHost, s->stream));
+  HIPCK(s, hipStreamSynchronize(s->stream));
+  return SDPLR_OK;
+}
+}  // extern "C"
+
+namespace {
+double* vec_ptr(S* s, int32_t which, int64_t* len, bool* in_ctrl) {
+  const int64_t m = s->m;
+  *in_ctrl = false;
+  switch (which) {
+    case SDPLR_V_LAMBDA: *len = m; return s->lambda;
+    case SDPLR_V_LAMBDA_UB: *len = m; return s->lambda_ub;
+    case SDPLR_V_B: *len = m; return s->b;
+    case SDPLR_V_Y: *len = m + 1; return s->y;
+    case SDPLR_V_PV_RAW: *len = m + 1; return s->pv_raw;
+    case SDPLR_V_PV_LB: *len = m; return s->pv_lb;
+    case SDPLR_V_PV: *len = m; return s->pv;
+    case SDPLR_V_A_RD: *len = m + 1; return s->A_RD;
+    case SDPLR_V_A_DD: *len = m + 1; return s->A_DD;
+    case SDPLR_V_LBFGS_RHO: *len = s->h; *in_ctrl = true; return s->hc->rho;
+    case SDPLR_V_LBFGS_A: *len = s->h; *in_ctrl = true; return s->hc->a;
+    case SDPLR_V_UVT: *len = s->nnzT; return s->sp.UVt0;
+    case SDPLR_V_TRIU_S_NZVAL: *len = s->nnzT; return s->sp.triu_nzval;
+    case SDPLR_V_S_NZVAL: *len = s->nnzS; return s->sp.nzval;
+    default: *len = -1; return nullptr;
+  }
+}
+}  // namespace
+
+extern "C" {
+int32_t sdplr_hip_set_vec(S* s, int32_t which, const double* h, int64_t len) {
+  NEED_FINAL(s);
+  int64_t L; bool in_ctrl;
+  double* p = vec_ptr(s, which, &L, &in_ctrl);
+  if (L < 0 || len != L || (!h && L > 0)) return fail(s, SDPLR_ERR_INVALID_ARG, "set_vec: bad slot/length");
+  if (L == 0) return SDPLR_OK;
+  if (in_ctrl) {
+    int rc = pull(s);
+    if (rc) return rc;
+    memcpy(p, h, L * sizeof(double));
+    return push(s);
+  }
+  HIPCK(s, hipMemcpyAsync(p, h, L * sizeof(double), hipMemcpyHostToDevice, s->stream));
+  HIPCK(s, hipStreamSynchronize(s->stream));
+  return SDPLR_OK;
+}
+int32_t sdplr_hip_get_vec(S* s, int32_t which, double* h, int64_t len) {
+  NEED_FINAL(s);
+  int64_t L; bool in_ctrl;
+  double* p = vec_ptr(s, which, &L, &in_ctrl);
+  if (L < 0 || len != L || (!h && L > 0)) return fail(s, SDPLR_ERR_INVALID_ARG, "get_vec: bad slot/length");
+  if (L == 0) return SDPLR_OK;
+  if (in_ctrl) {
+    int rc = pull(s);
+    if (rc) return rc;
+    memcpy(h, p, L * sizeof(double));
+    return SDPLR_OK;
+  }
+  HIPCK(s, hipMemcpyAsync(h, p, L * sizeof(double), hipMemcpyDeviceToHost, s->stream));
+  HIPCK(s, hipStreamSynchronize(s->stream));
+  return SDPLR_OK;
+}
+int32_t sdplr_hip_set_scalar(S* s, int32_t which, double v) {
+  NEED_FINAL(s);
+  int rc = pull(s);
+  if (rc) return rc;
+  if (which == SDPLR_S_SIGMA) s->hc->sigma = v;
+  else if (which == SDPLR_S_OBJ) s->hc->obj = v;
+  else if (which == SDPLR_S_LBFGS_LATEST) {
+    if (s->h > 0 && (v < 1 || v > (double)s->h)) return fail(s, SDPLR_ERR_INVALID_ARG, "set_scalar: latest out of range");
+    s->hc->latest = (int)v;
+    s->gram_dirty = true;
+  } else return fail(s, SDPLR_ERR_INVALID_ARG, "set_scalar: bad slot");
+  return push(s);
+}
+int32_t sdplr_hip_get_scalar(S* s, int32_t which, double* v) {
+  NEED_FINAL(s);
+  if (!v) return fail(s, SDPLR_ERR_INVALID_ARG, "get_scalar: null");
+  int rc = pull(s);
+  if (rc) return rc;
+  if (which == SDPLR_S_SIGMA) *v = s->hc->sigma;
+  else if (which == SDPLR_S_OBJ) *v = s->hc->obj;
+  else if (which == SDPLR_S_LBFGS_LATEST) *v = (double)s->hc->latest;
+  else return fail(s, SDPLR_ERR_INVALID_ARG, "get_scalar: bad slot");
+  return SDPLR_OK;
+}
+int32_t sdplr_hip_get_dims(const S* s, int64_t* n, int64_t* m, int64_t* r, int64_t* h, int64_t* nnzT,
+                           int64_t* nnzS, int64_t* nnzAgg) {
+  if (!s) return SDPLR_ERR_INVALID_ARG;
+  if (n) *n = s->n;
+  if (m) *m = s->m;
+  if (r) *r = s->r;
+  if (h) *h = s->h;
+  if (nnzT) *nnzT = s->nnzT;
+  if (nnzS) *nnzS = s->nnzS;
+  if (nnzAgg) *nnzAgg = s->nnzAgg;
+  return SDPLR_OK;
+}
+}  // extern "C"
+
+// ================================================================================================
+// kernel sequences (enqueue only; no synchronisation)
+// ================================================================================================
+namespace {
+
+#define LV_CASE(L, V, CALL) if (s->LPR == L && s->VEC == V) { constexpr int LPR = L, VEC = V; CALL; } else
+#define LV_DISPATCH(CALL)                                                                              \
+  LV_CASE(1, 1, CALL) LV_CASE(2, 1, CALL) LV_CASE(4, 1, CALL) LV_CASE(8, 1, CALL) LV_CASE(16, 1, CALL) \
+  LV_CASE(32, 1, CALL) LV_CASE(64, 1, CALL) LV_CASE(1, 2, CALL) LV_CASE(2, 2, CALL) LV_CASE(4, 2, CALL) \
+  LV_CASE(8, 2, CALL) LV_CASE(16, 2, CALL) LV_CASE(32, 2, CALL) LV_CASE(64, 2, CALL) {}
+#define HM_DISPATCH(CALL)                                       \
+  if (s->HM == 4) { constexpr int HM = 4; CALL; }               \
+  else if (s->HM == 8) { constexpr int HM = 8; CALL; }          \
+  else { constexpr int HM = 16; CALL; }
+
+// W = X0ᵀB (and X1ᵀB) followed by the mode-specific tail of k_lr_finalize
+void enq_lowrank(S* s, const double* X0, const double* X1, int F, int mode, double* out0, double* out1, int chk) {
+  if (s->lr.ST == 0) return;
+  {
+    ProfScope ps(s, "lr_project");
+    if (F == 1) { LV_DISPATCH((k_lr_project<LPR, VEC, 1><<<s->nb_lr, SDPLR_NT, 0, s->stream>>>(s->lr, X0, X1, (int)s->n, (int)s->r, s->lr_part, s->ctrl, chk))) }
+    else { LV_DISPATCH((k_lr_project<LPR, VEC, 2><<<s->nb_lr, SDPLR_NT, 0, s->stream>>>(s->lr, X0, X1, (int)s->n, (int)s->r, s->lr_part, s->ctrl, chk))) }
+  }
+  ProfScope ps(s, "lr_finalize");
+  k_lr_finalize<<<1, SDPLR_NT, 0, s->stream>>>(s->lr, (int)s->r, F, s->nb_lr, s->lr_part, s->lr_W, mode, out0, out1, s->y, s->lr_WS, s->ctrl, chk);
+}
+
+// mode 0: out0 = 𝒜(UUᵀ); mode 1: out0 = 𝒜((UVᵀ+VUᵀ)/2); mode 2: out0 = 2·𝒜((UVᵀ+VUᵀ)/2), out1 = 𝒜(VVᵀ)
+void enq_A(S* s, const double* U, const double* V, int mode, double* out0, double* out1, int chk) {
+  if (!s->all_covered) {
+    (void)hipMemsetAsync(out0, 0, (s->m + 1) * sizeof(double), s->stream);  // fill!(out, 0), src/coreop.jl:39,60
+    if (mode == 2) (void)hipMemsetAsync(out1, 0, (s->m + 1) * sizeof(double), s->stream);
+  }
+  if (s->n_sparse > 0) {
+    {
+      ProfScope ps(s, mode == 2 ? "sddmm_linesearch" : (mode == 1 ? "sddmm_uv" : "sddmm_uu"));
+      if (mode == 0) { LV_DISPATCH((k_sddmm<LPR, VEC, 0><<<s->nb_sddmm, SDPLR_NT, 0, s->stream>>>(s->sp, U, V, (int)s->r, s->ctrl, chk))) }
+      else if (mode == 1) { LV_DISPATCH((k_sddmm<LPR, VEC, 1><<<s->nb_sddmm, SDPLR_NT, 0, s->stream>>>(s->sp, U, V, (int)s->r, s->ctrl, chk))) }
+      else { LV_DISPATCH((k_sddmm<LPR, VEC, 2><<<s->nb_sddmm, SDPLR_NT, 0, s->stream>>>(s->sp, U, V, (int)s->r, s->ctrl, chk))) }
+    }
+    const int nb = s->sp.n_short_blocks + s->sp.n_chunks;
+    if (nb > 0) {
+      ProfScope ps(s, "segreduce");
+      if (mode == 2) k_segreduce<true><<<nb, SDPLR_NT, 0, s->stream>>>(s->sp, out0, out1, s->ctrl, chk);
+      else k_segreduce<false><<<nb, SDPLR_NT, 0, s->stream>>>(s->sp, out0, out1, s->ctrl, chk);
+    }
+    if (s->sp.n_long > 0) {
+      ProfScope ps(s, "seg_finalize");
+      const int nbf = (s->sp.n_long * 64 + SDPLR_NT - 1) / SDPLR_NT;
+      if (mode == 2) k_seg_finalize<true><<<nbf, SDPLR_NT, 0, s->stream>>>(s->sp, out0, out1, s->ctrl, chk);
+      else k_seg_finalize<false><<<nbf, SDPLR_NT, 0, s->stream>>>(s->sp, out0, out1, s->ctrl, chk);
+    }
+  }
+  if (mode == 0) enq_lowrank(s, U, U, 1, 0, out0, out1, chk);
+  else enq_lowrank(s, U, V, 2, mode, out0, out1, chk);
+}
+
+void enq_At_preprocess(S* s, int chk) {
+  if (s->n_sparse <= 0) return;
+  {
+    ProfScope ps(s, "assemble_triu");
+    k_assemble_triu<<<s->nb_nnzT, SDPLR_NT, 0, s->stream>>>(s->sp, s->y, s->ctrl, chk);
+  }
+  ProfScope ps(s, "assemble_full");
+  k_assemble_full<<<s->nb_nnzS, SDPLR_NT, 0, s->stream>>>(s->sp, s->ctrl, chk);
+}
+
+// Y = scale·(X·S + low-rank); slot ≥ 0 also yields the ‖Y‖² partials
+void enq_At_left(S* s, double* Y, const double* X, double scale, int slot, int chk) {
+  enq_lowrank(s, X, X, 1, 3, nullptr, nullptr, chk);
+  ProfScope ps(s, "spmm");
+  LV_DISPATCH((k_spmm<LPR, VEC><<<s->nb_spmm, SDPLR_NT, 0, s->stream>>>(s->sp, X, Y, (int)s->r, scale, s->lr, s->lr_WS, slot, s->partials, s->ctrl, chk)))
+}
+
+void enq_copy2y(S* s, int chk) {
+  ProfScope ps(s, "copy2y");
+  k_copy2y<<<s->nb_m, SDPLR_NT, 0, s->stream>>>(s->ctrl, (int)s->m, s->y, s->lambda, s->lambda_ub, s->pv_raw, chk);
+}
+
+// g!: src/coreop.jl:305-317; y_done = 1 when the line-search commit already produced y
+void enq_g(S* s, int chk, bool y_done) {
+  if (!y_done) enq_copy2y(s, chk);
+  enq_At_preprocess(s, chk);
+  enq_At_left(s, aslot(s->arena, AS_G), aslot(s->arena, AS_R), 2.0, SLOT_GNORM2, chk);
+}
+
+// f!: src/coreop.jl:11-31
+void enq_f(S* s) {
+  enq_A(s, aslot(s->arena, AS_R), nullptr, 0, s->pv_raw, nullptr, 0);
+  {
+    ProfScope ps(s, "f_tail");
+    k_f_tail<<<s->nb_m, SDPLR_NT, 0, s->stream>>>(s->ctrl, (int)s->m, s->pv_raw, s->b, s->pv_lb, s->pv, s->lambda, s->lambda_ub, s->partials);
+  }
+  ProfScope ps(s, "f_finalize");
+  k_f_finalize<<<1, SDPLR_NT, 0, s->stream>>>(s->ctrl, (int)s->m, s->pv_raw, s->nb_m, s->partials);
+}
+
+void enq_gram_row(S* s, int j) {
+  HM_DISPATCH((k_lbfgs_update<HM, false><<<s->nb_dense, SDPLR_NT, 0, s->stream>>>(s->ctrl, s->arena, s->N, (int)s->h, j, 0, s->partials)))
+  HM_DISPATCH((k_gram_finalize<HM><<<1, SDPLR_NT, 0, s->stream>>>(s->ctrl, (int)s->h, j, 0, s->nb_dense, 0, s->partials)))
+}
+// make the Gram data consistent with the stored history and the current G (see k_dense.h)
+void ensure_gram(S* s) {
+  if (s->h == 0) return;
+  if (s->gram_dirty || s->ynext_pending) {
+    ProfScope ps(s, "gram_recompute");
+    for (int j = 0; j < (int)s->h; j++) enq_gram_row(s, j);
+  } else if (s->sg_stale) {
+    ProfScope ps(s, "gram_recompute");
+    enq_gram_row(s, 0);
+  }
+  s->gram_dirty = s->sg_stale = s->ynext_pending = false;
+}
+
+// lbfgs_dir! (+ descent): coefficients → direction → descent (with the optional on-device fallback)
+void enq_lbfgs_dir(S* s, int negate, int check_loop, int apply_fallback) {
+  {
+    ProfScope ps(s, "lbfgs_coeff");
+    k_lbfgs_coeff<<<1, 64, 0, s->stream>>>(s->ctrl, (int)s->h, check_loop);
+  }
+  {
+    ProfScope ps(s, "lbfgs_dir");
+    HM_DISPATCH((k_lbfgs_dir<HM><<<s->nb_dense, SDPLR_NT, 0, s->stream>>>(s->ctrl, s->arena, s->N, (int)s->h, negate, check_loop, s->partials)))
+  }
+  ProfScope ps(s, "descent");
+  const int nb = apply_fallback ? s->nb_dense : 1;
+  k_descent<<<nb, SDPLR_NT, 0, s->stream>>>(s->ctrl, s->arena, s->N, s->nb_dense, apply_fallback, check_loop, s->partials);
+}
+
+void enq_lbfgs_update(S* s, int chk) {
+  if (s->h == 0) return;
+  {
+    ProfScope ps(s, "lbfgs_update");
+    HM_DISPATCH((k_lbfgs_update<HM, true><<<s->nb_dense, SDPLR_NT, 0, s->stream>>>(s->ctrl, s->arena, s->N, (int)s->h, 0, chk, s->partials)))
+  }
+  ProfScope ps(s, "gram_finalize");
+  HM_DISPATCH((k_gram_finalize<HM><<<1, SDPLR_NT, 0, s->stream>>>(s->ctrl, (int)s->h, 0, 1, s->nb_dense, chk, s->partials)))
+}
+
+// both line searches up to and including the commit; fuse_y also writes y of the following g!
+void enq_linesearch(S* s, int armijo, int chk, int fuse_y) {
+  enq_A(s, aslot(s->arena, AS_R), aslot(s->arena, AS_D), 2, s->A_RD, s->A_DD, chk);
+  if (armijo) {
+    {
+      ProfScope ps(s, "armijo_partials");
+      k_armijo_partials<<<s->nb_m, SDPLR_NT, 0, s->stream>>>(s->ctrl, (int)s->m, s->lambda, s->lambda_ub, s->pv_raw, s->A_RD, s->A_DD, s->y, s->partials, chk);
+    }
+    ProfScope ps(s, "armijo_pick");
+    k_armijo_pick<<<1, SDPLR_NT, 0, s->stream>>>(s->ctrl, (int)s->m, s->nb_m, s->A_RD, s->A_DD, s->partials, chk);
+  } else {
+    {
+      ProfScope ps(s, "ls_partials");
+      k_ls_partials<<<s->nb_m, SDPLR_NT, 0, s->stream>>>(s->ctrl, (int)s->m, s->lambda, s->pv_raw, s->A_RD, s->A_DD, s->partials, chk);
+    }
+    ProfScope ps(s, "ls_solve");
+    k_ls_solve<<<1, SDPLR_NT, 0, s->stream>>>(s->ctrl, (int)s->m, s->nb_m, s->A_RD, s->A_DD, s->partials, chk);
+  }
+  ProfScope ps(s, "ls_commit");
+  k_ls_commit<<<s->nb_m, SDPLR_NT, 0, s->stream>>>(s->ctrl, (int)s->m, s->pv_raw, s->A_RD, s->A_DD, s->pv_lb, s->pv, fuse_y, s->y, s->lambda, s->lambda_ub, s->partials, chk);
+}
+
+void enq_axpy_R(S* s, int chk) {
+  ProfScope ps(s, "axpy_R");
+  k_axpy_R<<<s->nb_dense, SDPLR_NT, 0, s->stream>>>(s->ctrl, aslot(s->arena, AS_R), aslot(s->arena, AS_D), s->N, chk);
+}
+
+// one pass of the while body, src/sdplr.jl:190-278, entirely device-driven
+void enq_iteration(S* s, int armijo) {
+  enq_lbfgs_dir(s, 1, 1, 1);                 // :197-205
+  enq_linesearch(s, armijo, 1, 1);           // :210-214
+  enq_axpy_R(s, 1);                          // :219
+  enq_g(s, 1, true);                         // :221
+  {
+    ProfScope ps(s, "iter_tail");            // :224-241
+    k_norms<<<1, SDPLR_NT, 0, s->stream>>>(s->ctrl, s->nb_spmm, s->nb_m, 1, 1, s->partials);
+  }
+  enq_lbfgs_update(s, 1);                    // :244-246
+}
+
+// host restatement of the Sturm bisection for the Lanczos tridiagonal
+int64_t sturm_below(const std::vector<double>& d, const double* e, int64_t k, double x) {
+  int64_t cnt = 0;
+  double q = d[0] - x;
+  if (q < 0) cnt++;
+  for (int64_t i = 1; i < k; i++) {
+    const double den = (q == 0.0) ? std::numeric_limits<double>::min() : q;
+    q = d[i] - x - e[i - 1] * e[i - 1] / den;
+    if (q < 0) cnt++;
+  }
+  return cnt;
+}
+
+int ensure_lz_capacity(S* s, int64_t q) {
+  if (q <= s->lz_cap) return SDPLR_OK;
+  HIPCK(s, hipStreamSynchronize(s->stream));
+  if (s->lz_alpha) (void)hipFree(s->lz_alpha);
+  if (s->lz_beta) (void)hipFree(s->lz_beta);
+  HIPCK(s, hipMalloc((void**)&s->lz_alpha, q * sizeof(double)));
+  HIPCK(s, hipMalloc((void**)&s->lz_beta, q * sizeof(double)));
+  s->lz_cap = q;
+  return SDPLR_OK;
+}
+
+// y = S·x (+ low-rank) for device n-vectors; slot ≥ 0 adds the ⟨x, y⟩ partials
+void enq_spmv(S* s, const double* x, double* yv, int slot, const int* stop_flag) {
+  if (s->lr.ST > 0) {
+    ProfScope ps(s, "lr_btx");
+    k_lr_btx<<<dim3(64, s->lr.ST), SDPLR_NT, 0, s->stream>>>(s->lr, x, (int)s->n, s->lr_btx_part, stop_flag);
+    k_lr_btx_finalize<<<1, SDPLR_NT, 0, s->stream>>>(s->lr, 64, s->lr_btx_part, s->y, s->lr_coef, stop_flag);
+  }
+  ProfScope ps(s, "spmv");
+  k_spmv<<<s->nb_spmv, SDPLR_NT, 0, s->stream>>>(s->sp, x, yv, s->lr, s->lr_coef, slot, s->partials, stop_flag);
+}
+
+int run_lanczos(S* s, int64_t q, const double* v0, double* alpha, double* beta, int64_t* steps) {
+  const int64_t n = s->n;
+  if (q > n - 1) q = n - 1;  // src/coreop.jl:465
+  if (q < 1) return fail(s, SDPLR_ERR_INVALID_ARG, "lanczos: q < 1 (needs n ≥ 2)");
+  int rc = ensure_lz_capacity(s, q);
+  if (rc) return rc;
+  if ((rc = pull(s))) return rc;
+  s->hc->lz_done = 0; s->hc->lz_steps = 0; s->hc->lz_beta_prev = 0.0;
+  if ((rc = push(s))) return rc;
+  HIPCK(s, hipMemcpyAsync(s->lz_v0, v0, n * sizeof(double), hipMemcpyHostToDevice, s->stream));
+  HIPCK(s, hipMemsetAsync(s->lz_alpha, 0, q * sizeof(double), s->stream));
+  HIPCK(s, hipMemsetAsync(s->lz_beta, 0, q * sizeof(double), s->stream));
+  double *v = s->lz_buf[0], *Av = s->lz_buf[1], *vpre = s->lz_buf[2];
+  HIPCK(s, hipMemsetAsync(vpre, 0, n * sizeof(double), s->stream));
+  const int* stop = &s->ctrl->lz_done;
+  {
+    ProfScope ps(s, "lanczos_init");
+    k_sumsq<<<s->nb_n, SDPLR_NT, 0, s->stream>>>(s->lz_v0, n, SLOT_V0, s->partials);
+    k_lz_init<<<s->nb_n, SDPLR_NT, 0, s->stream>>>((int)n, s->lz_v0, v, s->nb_n, s->partials);
+  }
+  for (int64_t i = 0; i < q; i++) {
+    enq_spmv(s, v, Av, SLOT_LZ_A, stop);                                  // :483
+    {
+      ProfScope ps(s, "lanczos_update");
+      k_lz_update1<<<s->nb_n, SDPLR_NT, 0, s->stream>>>(s->ctrl, (int)n, (int)i, v, Av, vpre, s->lz_alpha, s->nb_spmv, s->partials);
+      k_lz_update2<<<s->nb_n, SDPLR_NT, 0, s->stream>>>(s->ctrl, (int)n, (int)i, Av, s->lz_beta, s->nb_n, s->partials);
+    }
+    double* t = vpre;  // copyto!(v_pre, v); copyto!(v, Av)  (:498-499) as a pointer rotation
+    vpre = v; v = Av; Av = t;
+  }
+  HIPCK(s, hipGetLastError());
+  HIPCK(s, hipMemcpyAsync(alpha, s->lz_alpha, q * sizeof(double), hipMemcpyDeviceToHost, s->stream));
+  HIPCK(s, hipMemcpyAsync(beta, s->lz_beta, q * sizeof(double), hipMemcpyDeviceToHost, s->stream));
+  if ((rc = pull(s))) return rc;
+  *steps = s->hc->lz_steps;
+  return SDPLR_OK;
+}
+
+}  // namespace
+
+// ================================================================================================
+// operators
+// ================================================================================================
+extern "C" {
+
+int32_t sdplr_hip_A(S* s, int32_t u_slot, int32_t v_slot, int32_t out_vec) {
+  NEED_FINAL(s);
+  double* U = factor_ptr(s, u_slot);
+  double* V = v_slot >= 0 ? factor_ptr(s, v_slot) : nullptr;
+  if (!U || (v_slot >= 0 && !V)) return fail(s, SDPLR_ERR_INVALID_ARG, "A: bad factor slot");
+  double* out = out_vec == SDPLR_V_PV_RAW ? s->pv_raw : out_vec == SDPLR_V_A_RD ? s->A_RD : out_vec == SDPLR_V_A_DD ? s->A_DD : nullptr;
+  if (!out) return fail(s, SDPLR_ERR_INVALID_ARG, "A: bad output vector");
+  enq_A(s, U, V, V ? 1 : 0, out, nullptr, 0);
+  return sync_check(s);
+}
+int32_t sdplr_hip_At_preprocess(S* s) {
+  NEED_FINAL(s);
+  enq_At_preprocess(s, 0);
+  return sync_check(s);
+}
+int32_t sdplr_hip_At_left(S* s, int32_t ys, int32_t xs) {
+  NEED_FINAL(s);
+  double *Y = factor_ptr(s, ys), *X = factor_ptr(s, xs);
+  if (!Y || !X || Y == X) return fail(s, SDPLR_ERR_INVALID_ARG, "At_left: bad slots");
+  enq_At_left(s, Y, X, 1.0, -1, 0);
+  note_factor_written(s, ys);
+  return sync_check(s);
+}
+int32_t sdplr_hip_At_right(S* s, const double* x, double* yh, int64_t k) {
+  NEED_FINAL(s);
+  if (!x || !yh || k < 1) return fail(s, SDPLR_ERR_INVALID_ARG, "At_right: bad args");
+  const int64_t n = s->n;
+  for (int64_t c = 0; c < k; c++) {
+    HIPCK(s, hipMemcpyAsync(s->lz_buf[0], x + c * n, n * sizeof(double), hipMemcpyHostToDevice, s->stream));
+    enq_spmv(s, s->lz_buf[0], s->lz_buf[1], -1, nullptr);
+    HIPCK(s, hipMemcpyAsync(yh + c * n, s->lz_buf[1], n * sizeof(double), hipMemcpyDeviceToHost, s->stream));
+    HIPCK(s, hipStreamSynchronize(s->stream));
+  }
+  return sync_check(s);
+}
+
+int32_t sdplr_hip_f(S* s, double* L) {
+  NEED_FINAL(s);
+  enq_f(s);
+  int rc = pull(s);
+  if (rc) return rc;
+  if (L) *L = s->hc->L;
+  return sync_check(s);
+}
+int32_t sdplr_hip_g(S* s) {
+  NEED_FINAL(s);
+  enq_g(s, 0, false);
+  s->sg_stale = true;
+  return sync_check(s);
+}
+}  // extern "C"
+
+namespace {
+int set_norm_params(S* s, double normC, double normb, int grel, int prel) {
+  int rc = pull(s);
+  if (rc) return rc;
+  s->hc->normC = normC; s->hc->normb = normb; s->hc->grel = grel; s->hc->prel = prel;
+  s->hc->done = 0; s->hc->err = 0;
+  return push(s);
+}
+}  // namespace
+
+extern "C" {
+int32_t sdplr_hip_fg(S* s, double normC, double normb, int32_t grel, int32_t prel, double* L, double* gn, double* pn) {
+  NEED_FINAL(s);
+  int rc = set_norm_params(s, normC, normb, grel, prel);
+  if (rc) return rc;
+  enq_f(s);
+  enq_g(s, 0, false);
+  {
+    ProfScope ps(s, "pv_norm");  // src/coreop.jl:340-347
+    k_pv_norm<<<s->nb_m, SDPLR_NT, 0, s->stream>>>((int)s->m, s->pv_raw, s->pv_lb, s->pv, 1, s->partials);
+    k_norms<<<1, SDPLR_NT, 0, s->stream>>>(s->ctrl, s->nb_spmm, s->nb_m, 0, 0, s->partials);
+  }
+  s->sg_stale = true;
+  if ((rc = pull(s))) return rc;
+  if (L) *L = s->hc->L;
+  if (gn) *gn = s->hc->gnorm;
+  if (pn) *pn = s->hc->pvnorm;
+  return sync_check(s);
+}
+int32_t sdplr_hip_norms(S* s, double normC, double normb, int32_t grel, int32_t prel, double* gn, double* pn) {
+  NEED_FINAL(s);
+  int rc = set_norm_params(s, normC, normb, grel, prel);
+  if (rc) return rc;
+  {
+    ProfScope ps(s, "norms");
+    k_sumsq<<<s->nb_dense, SDPLR_NT, 0, s->stream>>>(aslot(s->arena, AS_G), s->N, SLOT_GNORM2, s->partials);
+    k_pv_norm<<<s->nb_m, SDPLR_NT, 0, s->stream>>>((int)s->m, s->pv_raw, s->pv_lb, s->pv, 0, s->partials);
+    k_norms<<<1, SDPLR_NT, 0, s->stream>>>(s->ctrl, s->nb_dense, s->nb_m, 0, 0, s->partials);
+  }
+  if ((rc = pull(s))) return rc;
+  if (gn) *gn = s->hc->gnorm;
+  if (pn) *pn = s->hc->pvnorm;
+  return sync_check(s);
+}
+int32_t sdplr_hip_axpy_R(S* s, double alpha) {
+  NEED_FINAL(s);
+  int rc = pull(s);
+  if (rc) return rc;
+  s->hc->alpha = alpha;
+  if ((rc = push(s))) return rc;
+  enq_axpy_R(s, 0);
+  return sync_check(s);
+}
+int32_t sdplr_hip_update_lambda(S* s) {
+  NEED_FINAL(s);
+  k_update_lambda<<<s->nb_m, SDPLR_NT, 0, s->stream>>>(s->ctrl, (int)s->m, s->lambda, s->lambda_ub, s->pv_raw);
+  return sync_check(s);
+}
+
+// ---- L-BFGS ------------------------------------------------------------------------------------------
+int32_t sdplr_hip_lbfgs_clear(S* s) {
+  NEED_FINAL(s);
+  for (int j = 0; j < (int)s->h; j++) {
+    HIPCK(s, hipMemsetAsync(aslot(s->arena, AS_S0 + j), 0, s->N * sizeof(double), s->stream));
+    HIPCK(s, hipMemsetAsync(aslot(s->arena, as_y0(s->arena) + j), 0, s->N * sizeof(double), s->stream));
+  }
+  int rc = pull(s);
+  if (rc) return rc;
+  memset(s->hc->rho, 0, sizeof s->hc->rho); memset(s->hc->a, 0, sizeof s->hc->a);
+  memset(s->hc->SY, 0, sizeof s->hc->SY); memset(s->hc->YY, 0, sizeof s->hc->YY);
+  memset(s->hc->Sg, 0, sizeof s->hc->Sg); memset(s->hc->Yg, 0, sizeof s->hc->Yg);
+  memset(s->hc->c_alpha, 0, sizeof s->hc->c_alpha); memset(s->hc->c_gamma, 0, sizeof s->hc->c_gamma);
+  s->gram_dirty = s->sg_stale = s->ynext_pending = false;  // zero vectors ⇒ zero Gram data, exact for any G
+  return push(s);
+}
+int32_t sdplr_hip_lbfgs_dir(S* s, int32_t negate, double* descent) {
+  NEED_FINAL(s);
+  ensure_gram(s);
+  enq_lbfgs_dir(s, negate ? 1 : 0, 0, 0);
+  if (s->h > 0) s->ynext_pending = true;
+  int rc = pull(s);
+  if (rc) return rc;
+  if (descent) *descent = s->hc->descent;
+  return sync_check(s);
+}
+int32_t sdplr_hip_descent_fallback(S* s) {
+  NEED_FINAL(s);
+  k_neg_copy<<<s->nb_dense, SDPLR_NT, 0, s->stream>>>(aslot(s->arena, AS_G), aslot(s->arena, AS_D), s->N);
+  s->sg_stale = true;
+  return sync_check(s);
+}
+int32_t sdplr_hip_lbfgs_update(S* s, double stepsize) {
+  NEED_FINAL(s);
+  if (s->h == 0) return SDPLR_OK;
+  if (s->gram_dirty) {  // rows other than the updated one must be valid first
+    s->ynext_pending = false;
+    ensure_gram(s);
+  }
+  int rc = pull(s);
+  if (rc) return rc;
+  s->hc->alpha = stepsize;
+  if ((rc = push(s))) return rc;
+  enq_lbfgs_update(s, 0);
+  s->ynext_pending = false;
+  s->sg_stale = false;
+  return sync_check(s);
+}
+
+// ---- line searches -----------------------------------------------------------------------------------
+static int32_t linesearch_common(S* s, int armijo, double alpha_max, double* alpha, double* L) {
+  int rc = pull(s);
+  if (rc) return rc;
+  s->hc->alpha_max = alpha_max; s->hc->done = 0; s->hc->err = 0;
+  if ((rc = push(s))) return rc;
+  enq_linesearch(s, armijo, 1, 0);   // chk = 1: a refused direction must stop the commit
+  if ((rc = pull(s))) return rc;
+  if (s->hc->err == SDPLR_ERR_NOT_DESCENT) {
+    s->hc->err = 0; s->hc->done = 0;
+    (void)push(s);
+    char buf[128];
+    snprintf(buf, sizeof buf, "Error: cubic[1] = %.17g should be less than 0.", s->hc->biquad[1]);
+    return fail(s, SDPLR_ERR_NOT_DESCENT, buf);
+  }
+  if (alpha) *alpha = s->hc->alpha;
+  if (L) *L = s->hc->L;
+  return sync_check(s);
+}
+int32_t sdplr_hip_linesearch(S* s, double alpha_max, double* alpha, double* L) {
+  NEED_FINAL(s);
+  return linesearch_common(s, 0, alpha_max, alpha, L);
+}
+int32_t sdplr_hip_linesearch_armijo(S* s, double alpha_max, double* alpha, double* L) {
+  NEED_FINAL(s);
+  return linesearch_common(s, 1, alpha_max, alpha, L);
+}
+
+// ---- the inner loop ----------------------------------------------------------------------------------
+int32_t sdplr_hip_inner_loop(S* s, double normC, double normb, int32_t grel, int32_t prel, int32_t use_armijo,
+                             double cur_gtol, double fprec_eps, int64_t max_local_iters, double time_budget_s,
+                             double* Lio, double* gnio, double* pnio, double* last_alpha, int64_t* iters,
+                             int32_t* exit_reason) {
+  NEED_FINAL(s);
+  if (!Lio || !gnio || !pnio || max_local_iters < 1) return fail(s, SDPLR_ERR_INVALID_ARG, "inner_loop: bad args");
+  ensure_gram(s);
+  int rc = pull(s);
+  if (rc) return rc;
+  DevCtrl* c = s->hc;
+  c->done = 0; c->exit_reason = 0; c->err = 0; c->use_armijo = use_armijo;
+  c->iters = 0; c->max_iters = max_local_iters;
+  c->cur_gtol = cur_gtol; c->fprec_eps = fprec_eps; c->normC = normC; c->normb = normb;
+  c->grel = grel; c->prel = prel;
+  c->L = *Lio; c->gnorm = *gnio; c->pvnorm = *pnio; c->alpha = 0.0; c->alpha_max = 1.0;
+  if ((rc = push(s))) return rc;
+  const auto t0 = std::chrono::steady_clock::now();
+  int64_t launched = 0;
+  int why = 0;
+  int64_t batch = 1;
+  for (;;) {
+    // iterations are enqueued in batches; the device decides every exit and later kernels of the
+    // batch fall through once `done` is set.  One extra pass lets the device apply the loop tests.
+    const int64_t nb = std::min<int64_t>(batch, max_local_iters + 1 - launched);
+    for (int64_t i = 0; i < std::max<int64_t>(nb, 1); i++) enq_iteration(s, use_armijo);
+    launched += std::max<int64_t>(nb, 1);
+    HIPCK(s, hipGetLastError());
+    if ((rc = pull(s))) return rc;
+    if (c->done) { why = c->exit_reason; break; }
+    if (time_budget_s > 0) {
+      const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+      if (el > time_budget_s) { why = EXIT_TIME; break; }
+    }
+    batch = std::min<int64_t>(batch * 2, 16);
+  }
+  // G was rewritten by g! after the last update when the loop left through the relative-decrease
+  // exit (no lbfgs_update!, src/sdplr.jl:239-241): the dots with G are stale then.
+  s->sg_stale = (why == EXIT_RELDELTA);
+  s->ynext_pending = (why == EXIT_RELDELTA) && s->h > 0;
+  if (c->err == SDPLR_ERR_NOT_DESCENT) {
+    c->err = 0; c->done = 0;
+    (void)push(s);
+    return fail(s, SDPLR_ERR_NOT_DESCENT, "Error: cubic[1] should be less than 0.");
+  }
+  *Lio = c->L; *gnio = c->gnorm; *pnio = c->pvnorm;
+  if (last_alpha) *last_alpha = c->alpha;
+  if (iters) *iters = c->iters;
+  if (exit_reason) *exit_reason = why;
+  return sync_check(s);
+}
+
+// ---- Lanczos / dual bound ------------------------------------------------------------------------------
+int32_t sdplr_hip_lanczos(S* s, int64_t q, const double* v0, double* alpha, double* beta, int64_t* steps) {
+  NEED_FINAL(s);
+  if (!v0 || !alpha || !beta || !steps || q < 1) return fail(s, SDPLR_ERR_INVALID_ARG, "lanczos: bad args");
+  return run_lanczos(s, q, v0, alpha, beta, steps);
+}
+int32_t sdplr_hip_tridiag_mineig(const double* alpha, const double* beta, int64_t k, double* out) {
+  if (!alpha || !out || k < 1 || (k > 1 && !beta)) return SDPLR_ERR_INVALID_ARG;
+  if (k == 1) { *out = (alpha[0] + 1) - 1; return SDPLR_OK; }  // src/coreop.jl:505-507
+  std::vector<double> d(k);
+  for (int64_t i = 0; i < k; i++) d[i] = alpha[i] + 1;          // shift by I  (:502)
+  double lo = std::numeric_limits<double>::infinity(), hi = -lo;
+  for (int64_t i = 0; i < k; i++) {
+    const double rad = (i > 0 ? std::fabs(beta[i - 1]) : 0.0) + (i + 1 < k ? std::fabs(beta[i]) : 0.0);
+    lo = std::min(lo, d[i] - rad);
+    hi = std::max(hi, d[i] + rad);
+  }
+  for (int it = 0; it < 200; it++) {
+    const double mid = 0.5 * (lo + hi);
+    if (mid <= lo || mid >= hi) break;
+    if (sturm_below(d, beta, k, mid) >= 1) hi = mid; else lo = mid;
+  }
+  *out = 0.5 * (lo + hi) - 1;                                   // cancel the shift (:513)
+  return SDPLR_OK;
+}
+int32_t sdplr_hip_approx_mineigval_lanczos(S* s, int64_t q, const double* v0, double* mineig) {
+  NEED_FINAL(s);
+  if (!v0 || !mineig || q < 1) return fail(s, SDPLR_ERR_INVALID_ARG, "approx_mineigval_lanczos: bad args");
+  std::vector<double> al(q), be(q);
+  int64_t steps = 0;
+  int rc = run_lanczos(s, q, v0, al.data(), be.data(), &steps);
+  if (rc) return rc;
+  return sdplr_hip_tridiag_mineig(al.data(), be.data(), steps, mineig);
+}
+int32_t sdplr_hip_dual_obj(S* s, double trace_bound, int64_t iter, const double* v0, double* dual_value, double* mineig) {
+  NEED_FINAL(s);
+  if (!v0) return fail(s, SDPLR_ERR_INVALID_ARG, "dual_obj: null v0");
+  enq_copy2y(s, 0);              // src/coreop.jl:384
+  enq_At_preprocess(s, 0);       // :385
+  const double it = (double)std::max<int64_t>(iter, 100);
+  const int64_t eig_iter = (int64_t)(2 * std::ceil(std::pow(it, 0.5) * std::log((double)s->n)));  // :402
+  double ev = 0.0;
+  int rc = sdplr_hip_approx_mineigval_lanczos(s, eig_iter, v0, &ev);
+  if (rc) return rc;
+  k_dot<<<s->nb_m, SDPLR_NT, 0, s->stream>>>((int)s->m, s->y, s->b, SLOT_DUALYB, s->partials);
+  k_reduce_slot<<<1, SDPLR_NT, 0, s->stream>>>(&s->ctrl->descent, SLOT_DUALYB, s->nb_m, s->partials);
+  if ((rc = pull(s))) return rc;
+  const double dv = -s->hc->descent + trace_bound * std::min(ev, 0.0);  // :412
+  if (dual_value) *dual_value = dv;
+  if (mineig) *mineig = ev;
+  return sync_check(s);
+}
+
+// ---- profiling ---------------------------------------------------------------------------------------
+int32_t sdplr_hip_profile_enable(S* s, int32_t on) {
+  NEED_FINAL(s);
+  prof_drain(s);
+  for (auto& p : s->prof) p = ProfEntry();
+  s->prof_on = on != 0;
+  return SDPLR_OK;
+}
+int32_t sdplr_hip_profile_filter(S* s, const char* name) {
+  NEED_FINAL(s);
+  s->prof_filter = name ? name : "";
+  return SDPLR_OK;
+}
+int32_t sdplr_hip_profile_count(const S* s, int32_t* n_entries) {
+  if (!s || !n_entries) return SDPLR_ERR_INVALID_ARG;
+  *n_entries = (int32_t)s->prof_names.size();
+  return SDPLR_OK;
+}
+int32_t sdplr_hip_profile_get(S* s, int32_t idx, char* name, int32_t cap, int64_t* launches, double* ms) {
+  NEED_FINAL(s);
+  if (idx < 0 || idx >= (int32_t)s->prof_names.size()) return fail(s, SDPLR_ERR_INVALID_ARG, "profile_get: bad index");
+  prof_drain(s);
+  if (name && cap > 0) snprintf(name, cap, "%s", s->prof_names[idx].c_str());
+  if (launches) *launches = s->prof[idx].launches;
+  if (ms) *ms = s->prof[idx].ms;
+  return SDPLR_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,263 @@
+"""GPU parity tests (run on the MI355X box with -m gpu): the HIP library against the CPU oracle on
+identical seeded inputs, through the C ABI, and against dense / scipy recomputation.
+
+Tolerances (FP64): operator identities 1e-10 (the reference's own bar, test/coreop.jl:59-72);
+‖grad‖ and objective 1e-8 relative (BASELINE.json north_star)."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+import sdplrplus_jl_amd as sj
+from sdplrplus_jl_amd import cabi, problems
+from helpers import (FAMILIES_EQ, GRID, S_dense, lagrangian_dense, make_data, make_solver,
+                     primal_vio_dense)
+
+pytestmark = pytest.mark.gpu
+
+ALL_FAMILIES = list(FAMILIES_EQ) + ["ineq_0.01", "ineq_0.05", "ineq_0.1"]
+# a slice of the reference grid (test/coreop.jl:46-47) plus ranks that exercise every sub-wave shape
+CASES = [(1, 5, 0.4, 2), (4, 5, 0.7, 2), (8, 8, 0.4, 3), (12, 12, 0.7, 3), (13, 12, 0.4, 1),
+         (14, 12, 0.4, 10), (15, 9, 0.4, 32), (16, 7, 0.4, 33)]
+
+
+def rel(a, b):
+    a, b = np.asarray(a, dtype=float), np.asarray(b, dtype=float)
+    return float(np.max(np.abs(a - b)) / (1.0 + np.max(np.abs(b)))) if a.size else 0.0
+
+
+def pair(hip_abi, oracle_abi, data, r, seed, h=4):
+    g, _ = make_solver(hip_abi, data, r, seed=seed, h=h)
+    o, _ = make_solver(oracle_abi, data, r, seed=seed, h=h)
+    assert np.array_equal(g.Rt, o.Rt)
+    return g, o
+
+
+@pytest.mark.parametrize("family", ALL_FAMILIES)
+@pytest.mark.parametrize("seed,n,p,r", CASES)
+def test_operators_match_oracle_and_dense(hip_abi, oracle_abi, family, seed, n, p, r):
+    data, C, As, bs = make_data(family, seed, n, p)
+    g, o = pair(hip_abi, oracle_abi, data, r, seed)
+    R = g.Rt
+    # ---- f! ------------------------------------------------------------------------------------
+    Lg, Lo = g.f(), o.f()
+    assert np.max(np.abs(g.primal_vio_raw - primal_vio_dense(C, As, bs, R))) < 1e-10
+    assert rel(g.primal_vio_raw, o.primal_vio_raw) < 1e-12
+    assert rel(g.primal_vio, o.primal_vio) < 1e-12
+    assert abs(Lg - Lo) <= 1e-12 * max(1, abs(Lo)) and abs(g.obj - o.obj) <= 1e-12 * max(1, abs(o.obj))
+    # ---- g! ------------------------------------------------------------------------------------
+    g.g(); o.g()
+    assert rel(g.y, o.y) < 1e-13
+    assert rel(g.get_vec(cabi.V_TRIU_S_NZVAL), o.get_vec(cabi.V_TRIU_S_NZVAL)) < 1e-13
+    assert rel(g.get_vec(cabi.V_S_NZVAL), o.get_vec(cabi.V_S_NZVAL)) < 1e-13
+    G = g.Gt
+    assert rel(G, o.Gt) < 1e-12
+    assert np.max(np.abs(G - 2 * S_dense(C, As, g.y) @ R)) < 1e-10 * (1 + np.max(np.abs(G)))
+    gn_g, pn_g = g.norms(3.0, 2.0, True, True)
+    gn_o, pn_o = o.norms(3.0, 2.0, True, True)
+    assert gn_g == pytest.approx(gn_o, rel=1e-12) and pn_g == pytest.approx(pn_o, rel=1e-12, abs=1e-300)
+    assert gn_g == pytest.approx(np.linalg.norm(G) / 3.0, rel=1e-12)
+    # ---- 𝒜 one- and two-argument on arbitrary slots ------------------------------------------------
+    g.dirt = -G; o.dirt = -G
+    for out in (cabi.V_A_RD, cabi.V_A_DD):
+        g.A(cabi.F_RT, cabi.F_DIRT, out); o.A(cabi.F_RT, cabi.F_DIRT, out)
+        assert rel(g.get_vec(out), o.get_vec(out)) < 1e-12
+    X = (R @ (-G).T + (-G) @ R.T) / 2
+    ref = np.array([np.sum(A_.toarray() * X) for A_ in As] + [np.sum(C.toarray() * X)])
+    assert np.max(np.abs(g.get_vec(cabi.V_A_DD) - ref)) < 1e-10 * (1 + np.max(np.abs(ref)))
+    # ---- line search ------------------------------------------------------------------------------
+    ineq = family.startswith("ineq")
+    if ineq:
+        (ag, Lg2), (ao, Lo2) = g.linesearch_armijo(1.0), o.linesearch_armijo(1.0)
+        assert ag == ao
+    else:
+        (ag, Lg2), (ao, Lo2) = g.linesearch(1.0), o.linesearch(1.0)
+        assert abs(ag - ao) <= 1e-7 * max(1.0, abs(ao))
+    assert abs(Lg2 - Lo2) <= 1e-10 * max(1, abs(Lo2))
+    assert rel(g.A_RD, o.A_RD) < 1e-12 and rel(g.A_DD, o.A_DD) < 1e-12
+    g.axpy_R(ag)
+    Rn = g.Rt
+    assert np.max(np.abs(g.primal_vio_raw - primal_vio_dense(C, As, bs, Rn))) < 1e-10   # test/coreop.jl:70-72
+    assert abs(Lg2 - lagrangian_dense(C, As, bs, Rn, g.λ, g.λ_ub, 2.0)) < 1e-9 * max(1, abs(Lg2))
+    # ---- 𝒜t! both orientations with a random y (test/coreop.jl:156-172) ---------------------------
+    rng = np.random.Generator(np.random.PCG64(seed + 100))
+    y = rng.standard_normal(data.m + 1)
+    g.y = y
+    g.At_preprocess()
+    S = S_dense(C, As, y)
+    g.At_left(cabi.F_GT, cabi.F_RT)
+    assert np.max(np.abs(g.Gt - S @ Rn)) < 1e-10
+    x = rng.standard_normal((data.n, 3))
+    assert np.max(np.abs(g.At_right(x) - S @ x)) < 1e-10
+    g.close(); o.close()
+
+
+@pytest.mark.parametrize("h", [0, 1, 4, 6, 9])
+@pytest.mark.parametrize("r", [2, 3, 32])
+def test_lbfgs_matches_oracle(hip_abi, oracle_abi, h, r):
+    """lbfgs_dir!/lbfgs_update!/lbfgs_clear! (src/lbfgs.jl) incl. the cyclic wrap and host-written slots."""
+    data, *_ = make_data("maxcut", 1, 9, 0.4)
+    g, o = pair(hip_abi, oracle_abi, data, r, 3, h=h)
+    rng = np.random.Generator(np.random.PCG64(5))
+    N = (data.n, r)
+    grad = rng.standard_normal(N)
+    for it in range(2 * h + 3):
+        g.Gt = grad; o.Gt = grad
+        dg, do = g.lbfgs_dir(True), o.lbfgs_dir(True)
+        assert rel(g.dirt, o.dirt) < 1e-10
+        assert dg == pytest.approx(do, rel=1e-9)
+        α = 0.3 + 0.05 * it
+        grad = grad + 0.1 * rng.standard_normal(N) + 0.5 * α * o.dirt
+        g.Gt = grad; o.Gt = grad
+        g.lbfgs_update(α); o.lbfgs_update(α)
+        assert rel(g.dirt, o.dirt) < 1e-12
+        for j in range(h):
+            assert rel(g.get_factor(cabi.F_LBFGS_S + j), o.get_factor(cabi.F_LBFGS_S + j)) < 1e-12
+            assert rel(g.get_factor(cabi.F_LBFGS_Y + j), o.get_factor(cabi.F_LBFGS_Y + j)) < 1e-12
+        if h:
+            assert np.allclose(g.get_vec(cabi.V_LBFGS_RHO), o.get_vec(cabi.V_LBFGS_RHO), rtol=1e-10)
+            assert g.get_scalar(cabi.S_LBFGS_LATEST) == o.get_scalar(cabi.S_LBFGS_LATEST)
+    if h:
+        # history written from the host behind the library's back: Gram data must be rebuilt
+        Snew = rng.standard_normal(N)
+        g.set_factor(cabi.F_LBFGS_S + 0, Snew); o.set_factor(cabi.F_LBFGS_S + 0, Snew)
+        g.lbfgs_dir(False); o.lbfgs_dir(False)
+        assert rel(g.dirt, o.dirt) < 1e-10
+        assert np.allclose(g.get_vec(cabi.V_LBFGS_A), o.get_vec(cabi.V_LBFGS_A), rtol=1e-9, atol=1e-12)
+    g.lbfgs_clear(); o.lbfgs_clear()
+    g.Gt = grad; o.Gt = grad
+    g.lbfgs_dir(True)
+    assert np.array_equal(g.dirt, -grad)
+    g.descent_fallback()
+    assert np.array_equal(g.Gt, -grad) and np.array_equal(g.dirt, -grad)
+    g.close(); o.close()
+
+
+@pytest.mark.parametrize("family", ["maxcut", "minimum_bisection", "lovasz_theta", "cutnorm",
+                                    "mu_conductance_0.05", "ineq_0.05"])
+def test_inner_loop_trajectory(hip_abi, oracle_abi, family):
+    """The native inner loop (src/sdplr.jl:190-278) against the oracle's, iteration by iteration, and
+    against the op-by-op path: same ℒ, ‖grad‖, ‖pv‖ to 1e-8 over a short fixed-length run."""
+    data, C, As, bs = make_data(family, 2, 12, 0.4)
+    r = 3
+    g, o = pair(hip_abi, oracle_abi, data, r, 11)
+    normC, normb = data.normC(), float(np.linalg.norm(data.b))
+    armijo = data.has_inequalities
+    sg, so = g.fg(normC, normb), o.fg(normC, normb)
+    assert np.allclose(sg, so, rtol=1e-11)
+    for it in range(8):
+        rg = g.inner_loop(normC, normb, True, True, armijo, 0.0, -1e300, 1, 0.0, *sg)
+        ro = o.inner_loop(normC, normb, True, True, armijo, 0.0, -1e300, 1, 0.0, *so)
+        assert rg[4] == ro[4] == 1 and rg[5] == ro[5] == 2
+        assert np.allclose(rg[:3], ro[:3], rtol=1e-8, atol=1e-12), (it, rg, ro)
+        assert rel(g.Rt, o.Rt) < 1e-8
+        sg, so = rg[:3], ro[:3]
+    # many iterations in one call, early exit by the gradient test
+    g2, o2 = pair(hip_abi, oracle_abi, data, r, 11)
+    sg, so = g2.fg(normC, normb), o2.fg(normC, normb)
+    rg = g2.inner_loop(normC, normb, True, True, armijo, 0.3 * sg[1], -1e300, 500, 0.0, *sg)
+    ro = o2.inner_loop(normC, normb, True, True, armijo, 0.3 * so[1], -1e300, 500, 0.0, *so)
+    assert rg[4] == ro[4] and rg[5] == ro[5] == 0
+    assert np.allclose(rg[:3], ro[:3], rtol=1e-6)
+    # iteration budget exit
+    rg = g2.inner_loop(normC, normb, True, True, armijo, 0.0, -1e300, 5, 0.0, *rg[:3])
+    assert rg[4] == 5 and rg[5] == 2
+    # relative-decrease exit with a huge fprec (always fires after the first step)
+    rg = g2.inner_loop(normC, normb, True, True, armijo, 0.0, 1e300, 50, 0.0, *rg[:3])
+    assert rg[4] == 1 and rg[5] == 1
+    for s_ in (g, o, g2, o2):
+        s_.close()
+
+
+@pytest.mark.parametrize("family", ["maxcut", "minimum_bisection", "lovasz_theta"])
+def test_lanczos_and_dual_obj(hip_abi, oracle_abi, family):
+    data, C, As, bs = make_data(family, 3, 12, 0.4)
+    g, o = pair(hip_abi, oracle_abi, data, 3, 4)
+    n = data.n
+    g.f(); o.f()
+    v0 = np.random.Generator(np.random.PCG64(9)).standard_normal(n)
+    (dg, eg), (do, eo) = g.dual_obj(float(n), 0, v0), o.dual_obj(float(n), 0, v0)
+    lam_min = np.linalg.eigvalsh(S_dense(C, As, g.y))[0]
+    assert eg == pytest.approx(lam_min, abs=1e-6 * max(1, abs(lam_min)))
+    assert eg == pytest.approx(eo, abs=1e-8 * max(1, abs(eo))) and dg == pytest.approx(do, rel=1e-8)
+    ag, bg, kg = g.lanczos(5, v0)
+    ao, bo, ko = o.lanczos(5, v0)
+    assert kg == ko == 5
+    assert np.allclose(ag, ao, rtol=1e-9, atol=1e-12) and np.allclose(bg, bo, rtol=1e-9, atol=1e-12)
+    assert g.tridiag_mineig(ag, bg) == pytest.approx(o.tridiag_mineig(ao, bo), abs=1e-12)
+    # exact invariant subspace ⇒ early exit (src/coreop.jl:494-496): start from an eigenvector
+    w, V = np.linalg.eigh(S_dense(C, As, g.y))
+    a1, b1, k1 = g.lanczos(6, V[:, 0])
+    assert k1 == 1 and a1[0] == pytest.approx(w[0], abs=1e-10)
+    g.close(); o.close()
+
+
+K2 = sp.csc_matrix(np.array([[0.0, 1.0], [1.0, 0.0]]))
+
+
+@pytest.mark.parametrize("native", [True, False])
+def test_known_answers_on_gpu(hip_abi, native):
+    """test/maxcut.jl:24,47 and test/minimumbisection.jl:22 through the device library."""
+    C, As, bs = problems.maxcut(K2)
+    res = sj.sdplr(C, As, bs, 1, fprec=0.0, gtol=1e-8, objtol=1e-8, ptol=1e-8, prior_trace_bound=2.0,
+                   printlevel=0, native_inner_loop=native)
+    assert res["obj"] == pytest.approx(-1, rel=1.5e-8)
+    res = sj.sdplr(C, As, bs, 1, σ_0=10.0, fprec=0.0, gtol=1e-8, objtol=1e-8, ptol=1e-8,
+                   prior_trace_bound=2.0, printlevel=0, native_inner_loop=native)
+    assert res["obj"] == pytest.approx(-1, rel=1.5e-8)
+    C, As, bs = problems.minimum_bisection(K2)
+    res = sj.sdplr(C, As, bs, 1, fprec=0.0, objtol=1e-4, ptol=1e-4, prior_trace_bound=2.0,
+                   printlevel=0, native_inner_loop=native)
+    assert (res["obj"] - 1) / (1 + abs(res["obj"])) < 1e-4
+
+
+def test_config1_and_rank_doubling_on_gpu(hip_abi, oracle_abi):
+    """BASELINE.json configs[0] on the device, next to the CPU oracle run of the same instance."""
+    A = problems.gnp_graph(100, 0.1, 1)
+    C, As, bs = problems.maxcut(A)
+    kw = dict(prior_trace_bound=100.0, printlevel=0, seed=1)
+    rg = sj.sdplr(C, As, bs, 2, **kw)
+    ro = sj.sdplr(C, As, bs, 2, abi=oracle_abi, **kw)
+    assert rg["primal_vio"] <= 1e-2 and ro["primal_vio"] <= 1e-2
+    assert rg["obj"] == pytest.approx(ro["obj"], rel=2e-2)       # both within objtol of the SDP value
+    assert rg["max_dual_value"] <= rg["obj"] + 1e-6 * abs(rg["obj"])
+    # rank doubling path (src/coreop.jl:518-526): r = 1 cannot close the gap, rankupd_tol = 1 doubles at once
+    res = sj.sdplr(C, As, bs, 1, prior_trace_bound=100.0, printlevel=0, seed=2, rankupd_tol=1,
+                   objtol=1e-3, maxmajoriter=40)
+    assert res["r"] >= 2
+
+
+def test_north_star_size_properties(hip_abi):
+    """MaxCut G(n = 1e5, p = 2e-4), r = 32 (BASELINE.json configs[1]) checked through size-independent
+    identities computed with scipy: 𝒜(RRᵀ)ᵢ = ‖Rᵢ‖², ⟨C,RRᵀ⟩, G = 2(C + Diag(y))R, and the line-search
+    bookkeeping identity of test/coreop.jl:65-72."""
+    n, r = 100_000, 32
+    A = problems.gnp_graph(n, 2e-4, 20240610)
+    data = problems.maxcut_data(A)
+    g, _ = make_solver(hip_abi, data, r, seed=0)
+    R = g.Rt
+    C = data.C
+    normC, normb = data.normC(), float(np.linalg.norm(data.b))
+    L, gn, pn = g.fg(normC, normb)
+    pv = g.primal_vio_raw
+    rows = np.einsum("ij,ij->i", R, R)
+    assert np.max(np.abs(pv[:-1] - (rows - 1.0))) < 1e-10
+    CR = C @ R
+    obj = float(np.sum(CR * R))
+    assert abs(pv[-1] - obj) < 1e-10 * abs(obj)
+    y = g.y
+    Gref = 2 * (CR + y[:-1, None] * R)
+    G = g.Gt
+    assert np.max(np.abs(G - Gref)) < 1e-10 * np.max(np.abs(Gref))
+    assert gn == pytest.approx(np.linalg.norm(Gref) / normC, rel=1e-12)
+    # a few inner iterations, then the bookkeeping identity at the moved point
+    res = g.inner_loop(normC, normb, True, True, False, 0.0, -1e300, 5, 0.0, L, gn, pn)
+    assert res[4] == 5 and res[0] < L
+    R2 = g.Rt
+    pv2 = g.primal_vio_raw
+    assert np.max(np.abs(pv2[:-1] - (np.einsum("ij,ij->i", R2, R2) - 1.0))) < 1e-9
+    obj2 = float(np.sum((C @ R2) * R2))
+    assert abs(pv2[-1] - obj2) < 1e-10 * abs(obj2)
+    G2ref = 2 * (C @ R2 + g.y[:-1, None] * R2)
+    assert np.max(np.abs(g.Gt - G2ref)) < 1e-10 * np.max(np.abs(G2ref))
+    assert res[1] == pytest.approx(np.linalg.norm(G2ref) / normC, rel=1e-10)
+    g.close()
