@@ -770,6 +770,9 @@ void ensure_gram(S* s) {
 
 // lbfgs_dir! (+ descent): coefficients → direction → descent (with the optional on-device fallback)
 void enq_lbfgs_dir(S* s, int negate, int check_loop, int apply_fallback) {
+  // m == 0: the reference returns right after copyto!(dir, grad), before the negation
+  // (src/lbfgs.jl:88-91); the caller's descent test then falls back to −G (src/sdplr.jl:202-205).
+  if (s->h == 0) negate = 0;
   {
     ProfScope ps(s, "lbfgs_coeff");
     k_lbfgs_coeff<<<1, 64, 0, s->stream>>>(s->ctrl, (int)s->h, check_loop);
