@@ -48,7 +48,7 @@ struct DevCtrl {
   double lz_beta_prev;
   // ---- L-BFGS (src/lbfgs.jl:4-28) ----
   int latest;          // 1-based, as in the reference
-  int pad0;
+  int gram_pending;    // set by k_lbfgs_update, consumed by k_lbfgs_boundary
   double rho[SDPLR_HMAX], a[SDPLR_HMAX];
   double c_alpha[SDPLR_HMAX], c_gamma[SDPLR_HMAX];   // two-loop coefficients of the current direction
   double SY[SDPLR_HMAX * SDPLR_HMAX];                // SY[a][b] = ⟨s_a, y_b⟩

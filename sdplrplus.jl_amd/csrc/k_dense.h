@@ -29,43 +29,111 @@ struct FactorArena {
 __host__ __device__ __forceinline__ double* aslot(const FactorArena& A, int k) { return A.base + (long long)k * A.stride; }
 __host__ __device__ __forceinline__ int as_y0(const FactorArena& A) { return AS_S0 + A.h; }  // y_j at as_y0(A) + j
 
-// ---- two-loop coefficients from the Gram data (one thread) -----------------------------------------
+// ---- two-loop coefficients from the Gram data (one thread, Gram data staged in LDS) -----------------
 // Mirrors src/lbfgs.jl:93-113 step by step; j runs newest → oldest, then oldest → newest.
-__device__ inline void lbfgs_coefficients(DevCtrl* c, int h) {
+struct GramLds {
+  double SY[SDPLR_HMAX * SDPLR_HMAX], YY[SDPLR_HMAX * SDPLR_HMAX];
+  double Sg[SDPLR_HMAX], Yg[SDPLR_HMAX], rho[SDPLR_HMAX];
+  double red[5 * SDPLR_HMAX];
+  double al[SDPLR_HMAX], ga[SDPLR_HMAX];  // two-loop work arrays: in LDS so that dynamic indexing
+  int order[SDPLR_HMAX];                  // does not fall back to scratch memory
+};
+__device__ inline void lbfgs_coefficients(DevCtrl* c, GramLds& gd, int h, int latest) {
   if (h == 0) return;
-  int order[SDPLR_HMAX];
-  int j = c->latest - 1;  // 0-based newest
+  int* order = gd.order;
+  double *al = gd.al, *ga = gd.ga;
+  int j = latest - 1;  // 0-based newest
   for (int i = 0; i < h; i++) {
     order[i] = j;
-    j = (j == 0) ? h - 1 : j - 1;
+    j = (j <= 0) ? h - 1 : j - 1;
   }
-  double al[SDPLR_HMAX], ga[SDPLR_HMAX];
   for (int i = 0; i < h; i++) {  // α_j = ρ_j ⟨s_j, q⟩,  q = G − Σ_{newer l} α_l y_l
-    int jj = order[i];
-    double sq = c->Sg[jj];
-    for (int k = 0; k < i; k++) sq -= al[order[k]] * c->SY[jj * SDPLR_HMAX + order[k]];
-    al[jj] = c->rho[jj] * sq;
-    c->a[jj] = al[jj];           // lbfgshis.vecs[j].a[] = α  (:97)
+    const int jj = order[i];
+    double sq = gd.Sg[jj];
+    for (int k = 0; k < i; k++) sq -= al[order[k]] * gd.SY[jj * SDPLR_HMAX + order[k]];
+    al[jj] = gd.rho[jj] * sq;
   }
   for (int i = h - 1; i >= 0; i--) {  // β_j = ρ_j ⟨y_j, r⟩,  r = q + Σ_{older l} γ_l s_l
-    int jj = order[i];
-    double yr = c->Yg[jj];
-    for (int k = 0; k < h; k++) yr -= al[order[k]] * c->YY[jj * SDPLR_HMAX + order[k]];
-    for (int k = h - 1; k > i; k--) yr += ga[order[k]] * c->SY[order[k] * SDPLR_HMAX + jj];
-    double beta = c->rho[jj] * yr;
+    const int jj = order[i];
+    double yr = gd.Yg[jj];
+    for (int k = 0; k < h; k++) yr -= al[order[k]] * gd.YY[jj * SDPLR_HMAX + order[k]];
+    for (int k = h - 1; k > i; k--) yr += ga[order[k]] * gd.SY[order[k] * SDPLR_HMAX + jj];
+    const double beta = gd.rho[jj] * yr;
     ga[jj] = al[jj] - beta;      // γ = a − β  (:107)
   }
   for (int l = 0; l < h; l++) {
+    c->a[l] = al[l];             // lbfgshis.vecs[j].a[] = α  (:97)
     c->c_alpha[l] = al[l];
     c->c_gamma[l] = ga[l];
   }
 }
 
-// Start of one inner iteration: the loop tests of src/sdplr.jl:190 and :272-277, localiter += 1,
-// lastval = ℒ (:207), then the two-loop coefficients.  check_loop = 0 for the stand-alone operator.
-__global__ void k_lbfgs_coeff(DevCtrl* c, int h, int check_loop) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  if (check_loop) {
+// The seam between two inner iterations, one block of 1024 threads:
+//  1. fold the partials of the preceding k_lbfgs_update into the Gram data —
+//     fin_mode 1: only if that kernel ran (c->gram_pending), then ρ_j = 1/⟨y_j,s_j⟩ (src/lbfgs.jl:146)
+//                 and latest = j (:148);  fin_mode 2: row `jfixed` recomputed from stored vectors;
+//  2. do_loop: the loop tests of src/sdplr.jl:272-277 and :190, localiter += 1, lastval = ℒ (:207);
+//  3. do_coeff: the two-loop coefficients of the next direction.
+// Each of the 5h sums is reduced by one wave (lanes stride the per-block partials, fixed order).
+__global__ void __launch_bounds__(1024)
+k_lbfgs_boundary(DevCtrl* __restrict__ c, int h, int jfixed, int fin_mode, int do_loop, int do_coeff,
+                 int nb_partials, const double* __restrict__ partials) {
+  __shared__ GramLds gd;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const bool fin = (fin_mode == 2) || (fin_mode == 1 && c->gram_pending);
+  if (!fin && !do_coeff && !do_loop) return;
+  for (int t = tid; t < SDPLR_HMAX * SDPLR_HMAX; t += 1024) {
+    gd.SY[t] = c->SY[t];
+    gd.YY[t] = c->YY[t];
+  }
+  if (tid < SDPLR_HMAX) {
+    gd.Sg[tid] = c->Sg[tid];
+    gd.Yg[tid] = c->Yg[tid];
+    gd.rho[tid] = c->rho[tid];
+  }
+  int latest = c->latest;
+  if (fin) {
+    for (int sidx = wave; sidx < 5 * h; sidx += 16) {
+      const int q = sidx / h, l = sidx % h;
+      const double* p = slot_partials(partials, SLOT_GRAM + q * SDPLR_HMAX + l);
+      double t = 0.0;
+      for (int i = lane; i < nb_partials; i += 64) t += p[i];
+      t = wave_sum(t);
+      if (lane == 0) gd.red[q * SDPLR_HMAX + l] = t;
+    }
+  }
+  __syncthreads();
+  if (tid == 0 && fin) {
+    const int j = (fin_mode == 1) ? (latest % h) : jfixed;
+    for (int l = 0; l < h; l++) {
+      gd.SY[j * SDPLR_HMAX + l] = gd.red[0 * SDPLR_HMAX + l];
+      if (l != j) gd.SY[l * SDPLR_HMAX + j] = gd.red[1 * SDPLR_HMAX + l];
+      gd.YY[j * SDPLR_HMAX + l] = gd.red[2 * SDPLR_HMAX + l];
+      gd.YY[l * SDPLR_HMAX + j] = gd.red[2 * SDPLR_HMAX + l];
+      gd.Sg[l] = gd.red[3 * SDPLR_HMAX + l];
+      gd.Yg[l] = gd.red[4 * SDPLR_HMAX + l];
+    }
+    if (fin_mode == 1) {
+      gd.rho[j] = 1.0 / gd.SY[j * SDPLR_HMAX + j];
+      latest = j + 1;
+      c->latest = latest;
+      c->gram_pending = 0;
+    }
+  }
+  __syncthreads();
+  if (fin) {  // write the Gram data back (coalesced)
+    for (int t = tid; t < SDPLR_HMAX * SDPLR_HMAX; t += 1024) {
+      c->SY[t] = gd.SY[t];
+      c->YY[t] = gd.YY[t];
+    }
+    if (tid < SDPLR_HMAX) {
+      c->Sg[tid] = gd.Sg[tid];
+      c->Yg[tid] = gd.Yg[tid];
+      c->rho[tid] = gd.rho[tid];
+    }
+  }
+  if (tid != 0) return;
+  if (do_loop) {
     if (c->done) return;
     if (c->iters > 0 && c->iters >= c->max_iters) {  // :272-277 (checked after the update)
       c->done = 1;
@@ -80,7 +148,7 @@ __global__ void k_lbfgs_coeff(DevCtrl* c, int h, int check_loop) {
     c->iters += 1;
     c->lastval = c->L;
   }
-  lbfgs_coefficients(c, h);
+  if (do_coeff) lbfgs_coefficients(c, gd, h, (fin && fin_mode == 1) ? latest : c->latest);
 }
 
 // ---- direction: dir = ∓(G − Σ α_l y_l + Σ γ_l s_l); y_next = −G; partial ⟨dir, G⟩ -----------------
@@ -150,8 +218,12 @@ k_lbfgs_dir(const DevCtrl* __restrict__ c, FactorArena A, long long N, int h, in
     const long long e = N - 1;
     const double g = G[e];
     double r = g;
-    for (int k = 0; k < h; k++) r -= ca[k] * aslot(A, as_y0(A) + order[k])[e];
-    for (int k = h - 1; k >= 0; k--) r += cg[k] * aslot(A, AS_S0 + order[k])[e];
+#pragma unroll
+    for (int k = 0; k < HM; k++)
+      if (k < h) r -= ca[k] * aslot(A, as_y0(A) + order[k])[e];
+#pragma unroll
+    for (int k = HM - 1; k >= 0; k--)
+      if (k < h) r += cg[k] * aslot(A, AS_S0 + order[k])[e];
     const double d = sgn * r;
     dir[e] = d;
     if (ynext) ynext[e] = -g;
@@ -264,15 +336,17 @@ k_lbfgs_update(const DevCtrl* __restrict__ c, FactorArena A, long long N, int h,
       sn = Sj[e];
       yn = Yj[e];
     }
-    for (int l = 0; l < h; l++) {
-      const double sl = (l == j) ? sn : aslot(A, AS_S0 + l)[e];
-      const double yl = (l == j) ? yn : aslot(A, as_y0(A) + l)[e];
-      acc[0 * HM + l] += sn * yl;
-      acc[1 * HM + l] += sl * yn;
-      acc[2 * HM + l] += yn * yl;
-      acc[3 * HM + l] += sl * g;
-      acc[4 * HM + l] += yl * g;
-    }
+#pragma unroll
+    for (int l = 0; l < HM; l++)
+      if (l < h) {
+        const double sl = (l == j) ? sn : aslot(A, AS_S0 + l)[e];
+        const double yl = (l == j) ? yn : aslot(A, as_y0(A) + l)[e];
+        acc[0 * HM + l] += sn * yl;
+        acc[1 * HM + l] += sl * yn;
+        acc[2 * HM + l] += yn * yl;
+        acc[3 * HM + l] += sl * g;
+        acc[4 * HM + l] += yl * g;
+      }
   }
   block_sum<5 * HM>(acc, sh);
   if (threadIdx.x == 0) {
@@ -281,44 +355,7 @@ k_lbfgs_update(const DevCtrl* __restrict__ c, FactorArena A, long long N, int h,
 #pragma unroll
       for (int l = 0; l < HM; l++)
         if (l < h) slot_partials(partials, SLOT_GRAM + q * SDPLR_HMAX + l)[blockIdx.x] = acc[q * HM + l];
-  }
-}
-
-// Fold the update partials into the Gram data; with `update`: ρ_j = 1/⟨y_j, s_j⟩ (:146) and
-// latest = j (:148).  One block; all 5h sums are reduced together (one pass over the partials).
-template <int HM>
-__global__ void __launch_bounds__(SDPLR_NT)
-k_gram_finalize(DevCtrl* __restrict__ c, int h, int jfixed, int update, int nb_partials,
-                int check_done, const double* __restrict__ partials) {
-  __shared__ double sh[5 * HM * (SDPLR_NT / 64)];
-  if (check_done && c->done) return;
-  const int j = update ? (c->latest % h) : jfixed;
-  double acc[5 * HM];
-#pragma unroll
-  for (int k = 0; k < 5 * HM; k++) acc[k] = 0.0;
-  for (int i = threadIdx.x; i < nb_partials; i += SDPLR_NT) {
-#pragma unroll
-    for (int q = 0; q < 5; q++)
-#pragma unroll
-      for (int l = 0; l < HM; l++)
-        if (l < h) acc[q * HM + l] += slot_partials(partials, SLOT_GRAM + q * SDPLR_HMAX + l)[i];
-  }
-  block_sum<5 * HM>(acc, sh);
-  if (threadIdx.x == 0) {
-#pragma unroll
-    for (int l = 0; l < HM; l++)
-      if (l < h) {
-        c->SY[j * SDPLR_HMAX + l] = acc[0 * HM + l];
-        if (l != j) c->SY[l * SDPLR_HMAX + j] = acc[1 * HM + l];
-        c->YY[j * SDPLR_HMAX + l] = acc[2 * HM + l];
-        c->YY[l * SDPLR_HMAX + j] = acc[2 * HM + l];
-        c->Sg[l] = acc[3 * HM + l];
-        c->Yg[l] = acc[4 * HM + l];
-      }
-    if (update) {
-      c->rho[j] = 1.0 / c->SY[j * SDPLR_HMAX + j];
-      c->latest = j + 1;
-    }
+    if (UPDATE && blockIdx.x == 0) const_cast<DevCtrl*>(c)->gram_pending = 1;  // consumed by k_lbfgs_boundary
   }
 }
 

@@ -10,6 +10,7 @@
 #include <cmath>
 #include <cstddef>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <map>
@@ -61,6 +62,8 @@ struct sdplr_hip_solver {
          *pv_lb = nullptr, *pv = nullptr, *A_RD = nullptr, *A_DD = nullptr;
   DevCtrl* ctrl = nullptr;   // device
   DevCtrl* hc = nullptr;     // pinned host shadow
+  DevCtrl* snap[2] = {nullptr, nullptr};   // pinned snapshots of the control block, one per queued batch
+  hipEvent_t snap_ev[2] = {nullptr, nullptr};
   double* partials = nullptr;
   double *lz_buf[3] = {nullptr, nullptr, nullptr}, *lz_v0 = nullptr, *lz_alpha = nullptr, *lz_beta = nullptr;
   int64_t lz_cap = 0;
@@ -70,6 +73,10 @@ struct sdplr_hip_solver {
   // kernel shapes
   int LPR = 1, VEC = 1, HM = 4;
   int nb_dense = 1, nb_m = 1, nb_sddmm = 1, nb_spmm = 1, nb_spmv = 1, nb_nnzT = 1, nb_nnzS = 1, nb_n = 1;
+
+  // captured batch of inner iterations (hipGraph), per line-search kind; rebuilt after reset_rank
+  hipGraphExec_t graph_exec[2] = {nullptr, nullptr};
+  int graph_iters = 8;
 
   // Gram bookkeeping (see k_dense.h)
   bool gram_dirty = false, sg_stale = false, ynext_pending = false;
@@ -477,6 +484,10 @@ int32_t sdplr_hip_finalize(S* s) {
     s->hc->alpha_max = 1.0;
     s->hc->latest = (int)s->h;      // src/lbfgs.jl:45
     HIPCK(s, hipMemcpy(s->ctrl, s->hc, sizeof(DevCtrl), hipMemcpyHostToDevice));
+    for (int k = 0; k < 2; k++) {
+      HIPCK(s, hipHostMalloc((void**)&s->snap[k], sizeof(DevCtrl), hipHostMallocDefault));
+      HIPCK(s, hipEventCreateWithFlags(&s->snap_ev[k], hipEventDisableTiming));
+    }
   }
   if ((rc = alloc_factors(s))) return rc;
   s->nb_m = blocks_for(m + 1, SDPLR_NT, 256);
@@ -506,6 +517,11 @@ int32_t sdplr_hip_destroy(S* s) {
   if (s->lz_alpha) (void)hipFree(s->lz_alpha);
   if (s->lz_beta) (void)hipFree(s->lz_beta);
   if (s->hc) (void)hipHostFree(s->hc);
+  for (int k = 0; k < 2; k++) {
+    if (s->snap[k]) (void)hipHostFree(s->snap[k]);
+    if (s->snap_ev[k]) (void)hipEventDestroy(s->snap_ev[k]);
+    if (s->graph_exec[k]) (void)hipGraphExecDestroy(s->graph_exec[k]);
+  }
   if (s->stream) (void)hipStreamDestroy(s->stream);
   delete s;
   return SDPLR_OK;
@@ -517,6 +533,8 @@ int32_t sdplr_hip_reset_rank(S* s, int64_t new_r) {
   HIPCK(s, hipStreamSynchronize(s->stream));
   if (s->arena.base) (void)hipFree(s->arena.base);
   s->arena.base = nullptr;
+  for (int k = 0; k < 2; k++)
+    if (s->graph_exec[k]) { (void)hipGraphExecDestroy(s->graph_exec[k]); s->graph_exec[k] = nullptr; }
   s->r = new_r;
   int rc = alloc_factors(s);
   if (rc) return rc;
@@ -751,9 +769,14 @@ void enq_f(S* s) {
   k_f_finalize<<<1, SDPLR_NT, 0, s->stream>>>(s->ctrl, (int)s->m, s->pv_raw, s->nb_m, s->partials);
 }
 
+// 1-block seam kernel: fold update partials / loop tests / two-loop coefficients (k_dense.h)
+void enq_boundary(S* s, int jfixed, int fin_mode, int do_loop, int do_coeff) {
+  ProfScope ps(s, "lbfgs_boundary");
+  k_lbfgs_boundary<<<1, 1024, 0, s->stream>>>(s->ctrl, (int)s->h, jfixed, fin_mode, do_loop, do_coeff, s->nb_dense, s->partials);
+}
 void enq_gram_row(S* s, int j) {
   HM_DISPATCH((k_lbfgs_update<HM, false><<<s->nb_dense, SDPLR_NT, 0, s->stream>>>(s->ctrl, s->arena, s->N, (int)s->h, j, 0, s->partials)))
-  HM_DISPATCH((k_gram_finalize<HM><<<1, SDPLR_NT, 0, s->stream>>>(s->ctrl, (int)s->h, j, 0, s->nb_dense, 0, s->partials)))
+  enq_boundary(s, j, 2, 0, 0);
 }
 // make the Gram data consistent with the stored history and the current G (see k_dense.h)
 void ensure_gram(S* s) {
@@ -768,32 +791,27 @@ void ensure_gram(S* s) {
   s->gram_dirty = s->sg_stale = s->ynext_pending = false;
 }
 
-// lbfgs_dir! (+ descent): coefficients → direction → descent (with the optional on-device fallback)
-void enq_lbfgs_dir(S* s, int negate, int check_loop, int apply_fallback) {
+// lbfgs_dir! (+ descent): [seam: pending Gram rows, loop tests, coefficients] → direction → descent
+// (with the optional on-device steepest-descent fallback)
+void enq_lbfgs_dir(S* s, int negate, int in_loop, int apply_fallback) {
   // m == 0: the reference returns right after copyto!(dir, grad), before the negation
   // (src/lbfgs.jl:88-91); the caller's descent test then falls back to −G (src/sdplr.jl:202-205).
   if (s->h == 0) negate = 0;
-  {
-    ProfScope ps(s, "lbfgs_coeff");
-    k_lbfgs_coeff<<<1, 64, 0, s->stream>>>(s->ctrl, (int)s->h, check_loop);
-  }
+  enq_boundary(s, 0, in_loop ? 1 : 0, in_loop, 1);
   {
     ProfScope ps(s, "lbfgs_dir");
-    HM_DISPATCH((k_lbfgs_dir<HM><<<s->nb_dense, SDPLR_NT, 0, s->stream>>>(s->ctrl, s->arena, s->N, (int)s->h, negate, check_loop, s->partials)))
+    HM_DISPATCH((k_lbfgs_dir<HM><<<s->nb_dense, SDPLR_NT, 0, s->stream>>>(s->ctrl, s->arena, s->N, (int)s->h, negate, in_loop, s->partials)))
   }
   ProfScope ps(s, "descent");
   const int nb = apply_fallback ? s->nb_dense : 1;
-  k_descent<<<nb, SDPLR_NT, 0, s->stream>>>(s->ctrl, s->arena, s->N, s->nb_dense, apply_fallback, check_loop, s->partials);
+  k_descent<<<nb, SDPLR_NT, 0, s->stream>>>(s->ctrl, s->arena, s->N, s->nb_dense, apply_fallback, in_loop, s->partials);
 }
 
+// lbfgs_update!: the pass over the history; its partials are folded by the next seam kernel
 void enq_lbfgs_update(S* s, int chk) {
   if (s->h == 0) return;
-  {
-    ProfScope ps(s, "lbfgs_update");
-    HM_DISPATCH((k_lbfgs_update<HM, true><<<s->nb_dense, SDPLR_NT, 0, s->stream>>>(s->ctrl, s->arena, s->N, (int)s->h, 0, chk, s->partials)))
-  }
-  ProfScope ps(s, "gram_finalize");
-  HM_DISPATCH((k_gram_finalize<HM><<<1, SDPLR_NT, 0, s->stream>>>(s->ctrl, (int)s->h, 0, 1, s->nb_dense, chk, s->partials)))
+  ProfScope ps(s, "lbfgs_update");
+  HM_DISPATCH((k_lbfgs_update<HM, true><<<s->nb_dense, SDPLR_NT, 0, s->stream>>>(s->ctrl, s->arena, s->N, (int)s->h, 0, chk, s->partials)))
 }
 
 // both line searches up to and including the commit; fuse_y also writes y of the following g!
@@ -1071,6 +1089,7 @@ int32_t sdplr_hip_lbfgs_update(S* s, double stepsize) {
   s->hc->alpha = stepsize;
   if ((rc = push(s))) return rc;
   enq_lbfgs_update(s, 0);
+  enq_boundary(s, 0, 1, 0, 0);
   s->ynext_pending = false;
   s->sg_stale = false;
   return sync_check(s);
@@ -1122,24 +1141,85 @@ int32_t sdplr_hip_inner_loop(S* s, double normC, double normb, int32_t grel, int
   c->L = *Lio; c->gnorm = *gnio; c->pvnorm = *pnio; c->alpha = 0.0; c->alpha_max = 1.0;
   if ((rc = push(s))) return rc;
   const auto t0 = std::chrono::steady_clock::now();
-  int64_t launched = 0;
-  int why = 0;
-  int64_t batch = 1;
-  for (;;) {
-    // iterations are enqueued in batches; the device decides every exit and later kernels of the
-    // batch fall through once `done` is set.  One extra pass lets the device apply the loop tests.
-    const int64_t nb = std::min<int64_t>(batch, max_local_iters + 1 - launched);
-    for (int64_t i = 0; i < std::max<int64_t>(nb, 1); i++) enq_iteration(s, use_armijo);
-    launched += std::max<int64_t>(nb, 1);
-    HIPCK(s, hipGetLastError());
-    if ((rc = pull(s))) return rc;
-    if (c->done) { why = c->exit_reason; break; }
-    if (time_budget_s > 0) {
-      const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-      if (el > time_budget_s) { why = EXIT_TIME; break; }
-    }
-    batch = std::min<int64_t>(batch * 2, 16);
+  // Iterations are enqueued in batches — a captured hipGraph of `graph_iters` passes of the while
+  // body, or eager launches when per-kernel event timing is on.  The device decides every exit;
+  // once `done` is set the remaining kernels of a batch fall through.  The control block is
+  // snapshotted after each batch, and batch k+1 is already queued while the host inspects the
+  // snapshot of batch k, so the GPU never waits for the host.
+  const int ar = use_armijo ? 1 : 0;
+  const bool use_graph = !s->prof_on && max_local_iters >= 4 && getenv("SDPLR_HIP_NO_GRAPH") == nullptr;
+  if (use_graph && !s->graph_exec[ar]) {
+    hipGraph_t graph = nullptr;
+    HIPCK(s, hipStreamBeginCapture(s->stream, hipStreamCaptureModeThreadLocal));
+    for (int i = 0; i < s->graph_iters; i++) enq_iteration(s, use_armijo);
+    HIPCK(s, hipStreamEndCapture(s->stream, &graph));
+    HIPCK(s, hipGraphInstantiate(&s->graph_exec[ar], graph, nullptr, nullptr, 0));
+    HIPCK(s, hipGraphDestroy(graph));
   }
+  const int64_t eager_batch = std::min<int64_t>(max_local_iters + 1, 8);
+  const bool dbg = getenv("SDPLR_HIP_DEBUG") != nullptr;
+  double t_enq = 0.0, t_wait = 0.0;
+  int n_batches = 0;
+  auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  auto launch_batch = [&](int slot) -> int {
+    const double ta = now();
+    n_batches++;
+    if (use_graph) {
+      HIPCK(s, hipGraphLaunch(s->graph_exec[ar], s->stream));
+    } else {
+      for (int64_t i = 0; i < eager_batch; i++) enq_iteration(s, use_armijo);
+      HIPCK(s, hipGetLastError());
+    }
+    HIPCK(s, hipMemcpyAsync(s->snap[slot], s->ctrl, sizeof(DevCtrl), hipMemcpyDeviceToHost, s->stream));
+    HIPCK(s, hipEventRecord(s->snap_ev[slot], s->stream));
+    t_enq += now() - ta;
+    return SDPLR_OK;
+  };
+  int why = -1;
+  if (s->prof_on) {
+    // per-kernel event timing: no speculation, and the trailing loop-test pass (whose kernels fall
+    // through) is left untimed, so that the averages are over real launches only
+    int64_t passes = 0;
+    for (;;) {
+      const int64_t nb = std::min<int64_t>(8, max_local_iters - passes);
+      for (int64_t i = 0; i < nb; i++) enq_iteration(s, use_armijo);
+      passes += std::max<int64_t>(nb, 0);
+      if (nb <= 0) {
+        s->prof_on = false;
+        enq_iteration(s, use_armijo);
+        s->prof_on = true;
+      }
+      HIPCK(s, hipGetLastError());
+      if ((rc = pull(s))) return rc;
+      if (c->done) break;
+      if (time_budget_s > 0 &&
+          std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > time_budget_s) {
+        why = EXIT_TIME;
+        break;
+      }
+    }
+  } else {
+    int cur = 0;
+    if ((rc = launch_batch(cur))) return rc;
+    for (;;) {
+      if ((rc = launch_batch(cur ^ 1))) return rc;          // speculative: queued behind batch `cur`
+      const double tw = now();
+      HIPCK(s, hipEventSynchronize(s->snap_ev[cur]));
+      t_wait += now() - tw;
+      if (s->snap[cur]->done) break;
+      if (time_budget_s > 0) {
+        const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        if (el > time_budget_s) { why = EXIT_TIME; break; }
+      }
+      cur ^= 1;
+    }
+  }
+  enq_boundary(s, 0, 1, 0, 0);   // fold the partials of a last lbfgs_update (time-budget exit)
+  if ((rc = pull(s))) return rc;
+  if (c->done) why = c->exit_reason;   // the device's verdict wins over the host's time check
+  if (dbg)
+    fprintf(stderr, "[sdplr_hip] inner_loop: %d batches (%s), host enqueue %.3f ms, host wait %.3f ms, iters %lld\n",
+            n_batches, use_graph ? "graph" : "eager", 1e3 * t_enq, 1e3 * t_wait, (long long)c->iters);
   // G was rewritten by g! after the last update when the loop left through the relative-decrease
   // exit (no lbfgs_update!, src/sdplr.jl:239-241): the dots with G are stale then.
   s->sg_stale = (why == EXIT_RELDELTA);
