@@ -274,3 +274,96 @@ def test_north_star_size_properties(hip_abi):
     assert np.max(np.abs(g.Gt - G2ref)) < 1e-10 * np.max(np.abs(G2ref))
     assert res[1] == pytest.approx(np.linalg.norm(G2ref) / normC, rel=1e-10)
     g.close()
+
+
+def test_config3_lovasz_theta_properties(hip_abi):
+    """BASELINE.json configs[2] stand-in: Lovász-θ on a Chung–Lu power-law graph (n ≈ 5e4, |E| ≈ 2.5e5), r = 32:
+    one 2-entry COO constraint per edge + identity + low-rank cost.  Checked with scipy identities:
+    𝒜(RRᵀ)_e = 2⟨R_i,R_j⟩, trace row = ‖R‖²_F, ⟨C,RRᵀ⟩ = −‖Rᵀ1‖², G = 2·S·R."""
+    A = problems.chung_lu_graph(50_000, 10.0, 2.5, 3)
+    data = problems.lovasz_theta_data(A)
+    n, m, r = data.n, data.m, 32
+    g, _ = make_solver(hip_abi, data, r, seed=1)
+    R = g.Rt
+    normC, normb = data.normC(), float(np.linalg.norm(data.b))
+    assert normC == pytest.approx(float(n), rel=1e-12)          # ‖−11ᵀ‖_F = n
+    L, gn, pn = g.fg(normC, normb)
+    pv = g.primal_vio_raw
+    coo = sp.triu(A, k=1).tocoo()
+    order = np.lexsort((coo.row, coo.col))                     # the builder walks A column-major
+    ei, ej = coo.row[order], coo.col[order]
+    assert ei.size + 1 == m
+    assert np.max(np.abs(pv[:m - 1] - 2 * np.einsum("ij,ij->i", R[ei], R[ej]))) < 1e-10
+    assert abs(pv[m - 1] - (np.sum(R * R) - 1.0)) < 1e-9 * np.sum(R * R)
+    w = R.sum(axis=0)
+    assert abs(pv[m] + w @ w) < 1e-10 * (w @ w)
+    y = g.y
+    S = sp.coo_matrix((np.concatenate([y[:m - 1], y[:m - 1]]), (np.concatenate([ei, ej]), np.concatenate([ej, ei]))),
+                      shape=(n, n)).tocsr() + y[m - 1] * sp.identity(n, format="csr")
+    Gref = 2 * (S @ R - y[m] * np.outer(np.ones(n), w))
+    G = g.Gt
+    assert np.max(np.abs(G - Gref)) < 1e-10 * np.max(np.abs(Gref))
+    res = g.inner_loop(normC, normb, True, True, False, 0.0, -1e300, 10, 0.0, L, gn, pn)
+    assert res[4] == 10 and res[0] < L
+    R2 = g.Rt
+    pv2 = g.primal_vio_raw
+    assert np.max(np.abs(pv2[:m - 1] - 2 * np.einsum("ij,ij->i", R2[ei], R2[ej]))) < 1e-9
+    g.close()
+
+
+def test_config4_minimum_bisection_with_lanczos(hip_abi):
+    """BASELINE.json configs[3]: MinBisection n = 1e5 (diag constraints + rank-1 constraint 11ᵀ), r = 32, and the
+    Lanczos dual-bound path with q = 2⌈√100·ln n⌉ = 232 steps (src/coreop.jl:402), checked against scipy:
+    S·v products, the Ritz value bound λ_min(T) ≥ λ_min(S), and dual = −yᵀb + n·min(λ,0)."""
+    n, r = 100_000, 32
+    A = problems.gnp_graph(n, 2e-4, 4)
+    data = problems.minimum_bisection_data(A)
+    g, _ = make_solver(hip_abi, data, r, seed=2)
+    normC, normb = data.normC(), float(np.linalg.norm(data.b))
+    L, gn, pn = g.fg(normC, normb)
+    R = g.Rt
+    pv = g.primal_vio_raw
+    w = R.sum(axis=0)
+    assert abs(pv[n] - w @ w) < 1e-10 * (w @ w)                 # ⟨11ᵀ, RRᵀ⟩ − 0
+    assert np.max(np.abs(pv[:n] - (np.einsum("ij,ij->i", R, R) - 1.0))) < 1e-10
+    y = g.y
+    C = data.C
+    Gref = 2 * (C @ R + y[:n, None] * R + y[n] * np.outer(np.ones(n), w))
+    assert np.max(np.abs(g.Gt - Gref)) < 1e-10 * np.max(np.abs(Gref))
+    res = g.inner_loop(normC, normb, True, True, False, 0.0, -1e300, 20, 0.0, L, gn, pn)
+    assert res[4] == 20
+    v0 = np.random.Generator(np.random.PCG64(5)).standard_normal(n)
+    dual, ev = g.dual_obj(float(n), 0, v0)
+    y = g.y
+    S = sp.csr_matrix(C) + sp.diags(y[:n])
+    Sop = lambda x: S @ x + y[n] * np.ones(n) * x.sum()
+    x = np.random.Generator(np.random.PCG64(6)).standard_normal(n)
+    assert np.max(np.abs(g.At_right(x) - Sop(x))) < 1e-10 * np.max(np.abs(Sop(x)))
+    al, be, k = g.lanczos(232, v0)
+    assert k == 232
+    v = v0 / np.linalg.norm(v0)
+    assert al[0] == pytest.approx(v @ Sop(v), rel=1e-11)
+    assert ev == pytest.approx(g.tridiag_mineig(al, be), abs=1e-12)
+    from scipy.sparse.linalg import LinearOperator, eigsh
+    lam = eigsh(LinearOperator((n, n), matvec=Sop, dtype=np.float64), k=1, which="SA", tol=1e-6)[0][0]
+    assert ev >= lam - 1e-6 * abs(lam) and ev <= lam + 0.05 * abs(lam)      # Ritz value: above λ_min, close to it
+    assert dual == pytest.approx(-(y[:n + 1] @ data.b) + n * min(ev, 0.0), rel=1e-10)
+    g.close()
+
+
+def test_config5_gset_batch_slice(hip_abi):
+    """BASELINE.json configs[4] in miniature: G1 and G2 of the reference's batch (exps/batch_test.txt: rank 10,
+    ptol = objtol = 0.01) solved concurrently on one GPU; weak duality and the known Gset MaxCut bounds."""
+    import os
+    from sdplrplus_jl_amd import batch
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "gset_G1_G9.npz"))
+    graphs = [problems.graph_from_edges(int(z[f"G{k}_n"]), z[f"G{k}"]) for k in (1, 2)]
+    assert graphs[0].shape == (800, 800) and graphs[0].nnz == 38352
+    local = batch.solve_local(graphs, 0, 1, 10, concurrency=2, make_data=problems.maxcut_data, ptol=0.01,
+                              objtol=0.01, seed=0, prior_trace_bound=800.0)
+    res = batch.gather(local, 2)
+    for k in range(2):
+        obj, dual = res[k, 1], res[k, 2]
+        assert dual <= obj + 1e-6 * abs(obj)
+        # best known cuts of G1/G2 are 11624/11620 and the SDP bound is ≈ 12083/12089: −obj lies in between ±1 %
+        assert 11600 * 0.99 <= -obj <= 12100 * 1.01
