@@ -37,6 +37,9 @@ struct DevCtrl {
   long long max_iters;
   double cur_gtol, fprec_eps, normC, normb;
   int grel, prel;
+  int reldelta_exit;   // set by the line-search scalar stage when rel_delta < fprec·eps (src/sdplr.jl:238-241)
+  int norms_pending;   // ‖G‖² / ‖pv‖² partials of the current iteration wait to be folded (by the seam kernel)
+  int nb_gnorm, nb_pvnorm;  // number of partials behind them
   // ---- SolverVars scalars (src/structs.jl:203-205) ----
   double sigma, obj;
   // ---- per-iteration scalars ----
@@ -122,6 +125,8 @@ enum {
   SLOT_LZ_B = 10,     // Lanczos ‖Av‖²
   SLOT_V0 = 11,       // ‖v0‖²
   SLOT_DUALYB = 12,   // ⟨y[1:m], b⟩
+  SLOT_PD = 13,       // ⟨P, D⟩ (structured fast path)
+  SLOT_DW = 14,       // ⟨D, W⟩
   SLOT_GRAM = 16,     // 16 .. 16+5*HMAX-1: partials of lbfgs_update (see k_dense.h)
   SLOT_ARMIJO = 96,   // 96 .. 96+53-1: ℒ(α_max/2^k), k = 0..50, ℒ(0), slope (see k_scalar.h)
   SLOT_LS = 150,      // 150..157: the eight sums behind the quartic's coefficients (see k_scalar.h)

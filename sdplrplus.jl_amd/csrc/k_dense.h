@@ -35,6 +35,7 @@ struct GramLds {
   double SY[SDPLR_HMAX * SDPLR_HMAX], YY[SDPLR_HMAX * SDPLR_HMAX];
   double Sg[SDPLR_HMAX], Yg[SDPLR_HMAX], rho[SDPLR_HMAX];
   double red[5 * SDPLR_HMAX];
+  double nrm[2];                          // Σ‖G‖² partials, Σ‖pv‖² partials
   double al[SDPLR_HMAX], ga[SDPLR_HMAX];  // two-loop work arrays: in LDS so that dynamic indexing
   int order[SDPLR_HMAX];                  // does not fall back to scratch memory
 };
@@ -81,7 +82,18 @@ k_lbfgs_boundary(DevCtrl* __restrict__ c, int h, int jfixed, int fin_mode, int d
   __shared__ GramLds gd;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const bool fin = (fin_mode == 2) || (fin_mode == 1 && c->gram_pending);
-  if (!fin && !do_coeff && !do_loop) return;
+  const bool norms = c->norms_pending != 0;
+  if (!fin && !do_coeff && !do_loop && !norms) return;
+  if (norms) {  // ‖G‖², ‖pv‖² of the iteration that just ended (src/sdplr.jl:224-234): waves 14 and 15
+    if (wave >= 14) {
+      const int nbp = (wave == 14) ? c->nb_gnorm : c->nb_pvnorm;
+      const double* p = slot_partials(partials, wave == 14 ? SLOT_GNORM2 : SLOT_PVNORM2);
+      double t = 0.0;
+      for (int i = lane; i < nbp; i += 64) t += p[i];
+      t = wave_sum(t);
+      if (lane == 0) gd.nrm[wave - 14] = t;
+    }
+  }
   for (int t = tid; t < SDPLR_HMAX * SDPLR_HMAX; t += 1024) {
     gd.SY[t] = c->SY[t];
     gd.YY[t] = c->YY[t];
@@ -133,8 +145,20 @@ k_lbfgs_boundary(DevCtrl* __restrict__ c, int h, int jfixed, int fin_mode, int d
     }
   }
   if (tid != 0) return;
+  if (norms) {
+    const double g = sqrt(gd.nrm[0]), pn = sqrt(gd.nrm[1]);
+    c->gnorm = c->grel ? g / c->normC : g;
+    c->pvnorm = c->prel ? pn / c->normb : pn;
+    c->norms_pending = 0;
+  }
   if (do_loop) {
     if (c->done) return;
+    if (c->reldelta_exit) {                            // :238-241 (after g! and the norms)
+      c->reldelta_exit = 0;
+      c->done = 1;
+      c->exit_reason = EXIT_RELDELTA;
+      return;
+    }
     if (c->iters > 0 && c->iters >= c->max_iters) {  // :272-277 (checked after the update)
       c->done = 1;
       c->exit_reason = EXIT_ITERS;
@@ -275,7 +299,7 @@ __global__ void __launch_bounds__(SDPLR_NT)
 k_lbfgs_update(const DevCtrl* __restrict__ c, FactorArena A, long long N, int h, int jfixed,
                int check_done, double* __restrict__ partials) {
   __shared__ double sh[5 * HM * (SDPLR_NT / 64)];
-  if (check_done && c->done) return;
+  if (check_done && (c->done || c->reldelta_exit)) return;  // :239-241 breaks before lbfgs_update!
   const int j = UPDATE ? (c->latest % h) : jfixed;
   const double alpha = c->alpha;
   const double* G = aslot(A, AS_G);

@@ -236,7 +236,8 @@ __device__ inline int quartic_argmin(const double* bq, double alpha_max, double*
 // One block: quartic coefficients (src/linesearch.jl:44-56), root selection, α* and ℒ(α*).
 __global__ void __launch_bounds__(SDPLR_NT)
 k_ls_solve(DevCtrl* __restrict__ c, int m, int nb, const double* __restrict__ A_RD,
-           const double* __restrict__ A_DD, const double* __restrict__ partials, int check_done) {
+           const double* __restrict__ A_DD, const double* __restrict__ partials, int check_done,
+           int loop_mode) {
   __shared__ double sh[8 * (SDPLR_NT / 64)];
   if (check_done && c->done) return;
   double s[8];
@@ -265,6 +266,11 @@ k_ls_solve(DevCtrl* __restrict__ c, int m, int nb, const double* __restrict__ A_
   }
   c->alpha = a;
   c->L = f;
+  if (loop_mode) {  // src/sdplr.jl:238-241, decided as soon as ℒ(α*) is known; acted on after g! and the norms
+    const double last = c->lastval;
+    const double rel_delta = (last - f) / fmax(1.0, fmax(fabs(f), fabs(last)));
+    c->reldelta_exit = (rel_delta < c->fprec_eps) ? 1 : 0;
+  }
 }
 
 // commit of either line search (src/linesearch.jl:118-124 / :184-188): pv_raw += α(α·A_DD + A_RD),
@@ -273,7 +279,8 @@ __global__ void __launch_bounds__(SDPLR_NT)
 k_ls_commit(DevCtrl* __restrict__ c, int m, double* __restrict__ pv_raw, const double* __restrict__ A_RD,
             const double* __restrict__ A_DD, const double* __restrict__ lb, double* __restrict__ pv,
             int fuse_y, double* __restrict__ y, const double* __restrict__ lam,
-            const double* __restrict__ lam_ub, double* __restrict__ partials, int check_done) {
+            const double* __restrict__ lam_ub, double* __restrict__ partials, int check_done,
+            int loop_mode, int nb_gnorm) {
   __shared__ double sh[8];
   if (check_done && c->done) return;
   const double a = c->alpha, sigma = c->sigma;
@@ -293,7 +300,14 @@ k_ls_commit(DevCtrl* __restrict__ c, int m, double* __restrict__ pv_raw, const d
     }
   }
   t = block_sum1(t, sh);
-  if (threadIdx.x == 0) slot_partials(partials, SLOT_PVNORM2)[blockIdx.x] = t;
+  if (threadIdx.x == 0) {
+    slot_partials(partials, SLOT_PVNORM2)[blockIdx.x] = t;
+    if (loop_mode && blockIdx.x == 0) {  // the g! that follows produces the ‖G‖² partials; the seam kernel folds both
+      c->norms_pending = 1;
+      c->nb_pvnorm = gridDim.x;
+      c->nb_gnorm = nb_gnorm;
+    }
+  }
 }
 
 // ---- Armijo backtracking (src/linesearch.jl:139-191), all 51 trial steps in one sweep ---------------
@@ -333,7 +347,8 @@ k_armijo_partials(const DevCtrl* __restrict__ c, int m, const double* __restrict
 }
 __global__ void __launch_bounds__(SDPLR_NT)
 k_armijo_pick(DevCtrl* __restrict__ c, int m, int nb, const double* __restrict__ A_RD,
-              const double* __restrict__ A_DD, const double* __restrict__ partials, int check_done) {
+              const double* __restrict__ A_DD, const double* __restrict__ partials, int check_done,
+              int loop_mode) {
   __shared__ double tot[53];
   __shared__ double sh[8];
   if (check_done && c->done) return;
@@ -358,6 +373,11 @@ k_armijo_pick(DevCtrl* __restrict__ c, int m, int nb, const double* __restrict__
   }
   c->alpha = a;
   c->L = La;
+  if (loop_mode) {
+    const double last = c->lastval;
+    const double rel_delta = (last - La) / fmax(1.0, fmax(fabs(La), fabs(last)));
+    c->reldelta_exit = (rel_delta < c->fprec_eps) ? 1 : 0;
+  }
 }
 
 // ---- Lanczos vector updates (src/coreop.jl:473-499) ---------------------------------------------------

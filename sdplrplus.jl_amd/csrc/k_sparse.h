@@ -197,7 +197,7 @@ template <int LPR, int VEC>
 __global__ void __launch_bounds__(SDPLR_NT)
 k_spmm(DevSparse sp, const double* __restrict__ X, double* __restrict__ Y, int r, double scale,
        DevLowRank lr, const double* __restrict__ WS, int slot, double* __restrict__ partials,
-       const DevCtrl* __restrict__ c, int check_done) {
+       const DevCtrl* __restrict__ c, int check_done, const double* __restrict__ Xdot = nullptr) {
   __shared__ double sh[8];
   if (check_done && c->done) return;
   constexpr int G = SDPLR_NT / LPR;
@@ -238,9 +238,14 @@ k_spmm(DevSparse sp, const double* __restrict__ X, double* __restrict__ Y, int r
         for (int k = 0; k < VEC; k++) acc.v[k] += w.v[k] * b;
       }
 #pragma unroll
-      for (int k = 0; k < VEC; k++) {
-        acc.v[k] *= scale;
-        nrm += acc.v[k] * acc.v[k];
+      for (int k = 0; k < VEC; k++) acc.v[k] *= scale;
+      if (Xdot) {  // partial of ⟨Xdot, Y⟩ instead of ‖Y‖²
+        const vecd<VEC> xd = ldrow<VEC>(Xdot + j * r + ch);
+#pragma unroll
+        for (int k = 0; k < VEC; k++) nrm += acc.v[k] * xd.v[k];
+      } else {
+#pragma unroll
+        for (int k = 0; k < VEC; k++) nrm += acc.v[k] * acc.v[k];
       }
       strow<VEC>(Y + j * r + ch, acc);
     }
@@ -406,4 +411,135 @@ k_lr_btx_finalize(DevLowRank lr, int nb, const double* __restrict__ part, const 
     if (threadIdx.x == 0) coef[cc] = yvec[lr.col_gid[cc]] * lr.Dcat[cc] * s;
     __syncthreads();
   }
+}
+
+// ================================================================================================
+// Structured fast path: exactly one sparse matrix A_g has off-diagonal entries
+// (for MaxCut / MinBisection / CutNorm / μ-conductance: the cost matrix), every other sparse matrix is
+// diagonal-only.  Then  S(y) = y_g·A_g + Diag(d(y)) + low-rank,  and with  P = A_g·R  kept resident
+// (P += α·W after each step, W = A_g·D) the whole iteration needs ONE gather pass (W = A_g·D):
+//   ⟨A_g, RDᵀ+DRᵀ⟩ = 2⟨P, D⟩,  ⟨A_g, DDᵀ⟩ = ⟨D, W⟩,  diagonal-only rows need only ⟨R_i,D_i⟩, ‖D_i‖²,
+//   G = 2·(y_g·P + d(y)∘R + low-rank).
+// ================================================================================================
+struct DevFast {
+  int gid_g;                 // slot of A_g in the (m+1)-vectors
+  const int* diagpos;        // [n] position of (i,i) in the triu pattern, −1 if absent
+  const int *drow_ptr, *drow_gid;   // per row: entries of the diagonal-only matrices (y index, value)
+  const double* drow_val;
+};
+
+// per-row dots for the diagonal-only matrices and the partial of ⟨P, D⟩:
+// UVt0[diag(i)] = 2⟨R_i, D_i⟩, UVt1[diag(i)] = ‖D_i‖²  (what k_sddmm<…,2> would put there)
+template <int LPR, int VEC>
+__global__ void __launch_bounds__(SDPLR_NT)
+k_rowdots(DevSparse sp, DevFast ff, const double* __restrict__ R, const double* __restrict__ D,
+          const double* __restrict__ P, int r, int slot, double* __restrict__ partials,
+          const DevCtrl* __restrict__ c, int check_done) {
+  __shared__ double sh[8];
+  if (check_done && c->done) return;
+  constexpr int G = SDPLR_NT / LPR;
+  const int lane = threadIdx.x % LPR;
+  const long long total = (long long)gridDim.x * G;
+  double pd = 0.0;
+  for (long long j = (long long)blockIdx.x * G + threadIdx.x / LPR; j < sp.n; j += total) {
+    double rd = 0.0, dd = 0.0;
+    for (int ch = lane * VEC; ch < r; ch += LPR * VEC) {
+      const vecd<VEC> x = ldrow<VEC>(R + j * r + ch), d = ldrow<VEC>(D + j * r + ch), pp = ldrow<VEC>(P + j * r + ch);
+#pragma unroll
+      for (int k = 0; k < VEC; k++) {
+        rd += x.v[k] * d.v[k];
+        dd += d.v[k] * d.v[k];
+        pd += pp.v[k] * d.v[k];
+      }
+    }
+    rd = group_sum<LPR>(rd);
+    dd = group_sum<LPR>(dd);
+    if (lane == 0) {
+      const int q = ff.diagpos[j];
+      if (q >= 0) {
+        sp.UVt0[q] = rd + rd;
+        sp.UVt1[q] = dd;
+      }
+    }
+  }
+  pd = block_sum1(pd, sh);
+  if (threadIdx.x == 0) slot_partials(partials, slot)[blockIdx.x] = pd;
+}
+
+// A_RD[g] = 2·⟨P, D⟩, A_DD[g] = ⟨D, W⟩ from the partials of k_rowdots / k_spmm.  One block.
+__global__ void __launch_bounds__(SDPLR_NT)
+k_fast_fill(DevFast ff, double* __restrict__ A_RD, double* __restrict__ A_DD, int slot_pd, int nb_pd,
+            int slot_dw, int nb_dw, const double* __restrict__ partials, const DevCtrl* __restrict__ c,
+            int check_done) {
+  __shared__ double sh[8];
+  if (check_done && c->done) return;
+  const double pd = reduce_partials(slot_partials(partials, slot_pd), nb_pd, sh);
+  __syncthreads();
+  const double dw = reduce_partials(slot_partials(partials, slot_dw), nb_dw, sh);
+  if (threadIdx.x == 0) {
+    A_RD[ff.gid_g] = pd + pd;
+    A_DD[ff.gid_g] = dw;
+  }
+}
+
+// low-rank coefficients at the moved point: W0 ← W0 + α·W1 (= R_newᵀB), WS[c] = y[gid_c]·D_c·W0[c]
+__global__ void __launch_bounds__(SDPLR_NT)
+k_fast_lr_ws(DevLowRank lr, int r, double* __restrict__ W, const double* __restrict__ yvec,
+             double* __restrict__ WS, const DevCtrl* __restrict__ c, int check_done) {
+  if (check_done && c->done) return;
+  const double a = c->alpha;
+  const int per = lr.ST * r;
+  for (int t = threadIdx.x; t < per; t += SDPLR_NT) {
+    const double w = W[t] + a * W[per + t];
+    W[t] = w;
+    WS[t] = yvec[lr.col_gid[t / r]] * lr.Dcat[t / r] * w;
+  }
+}
+
+// the step: R += α·D (src/sdplr.jl:219), P += α·W, then g! (src/coreop.jl:305-317) in structured form
+// G = 2·(y_g·P + d(y)∘R + Σ_c WS[c]·B[c]) with the ‖G‖² partials of norm(Gt) (src/sdplr.jl:225)
+template <int LPR, int VEC>
+__global__ void __launch_bounds__(SDPLR_NT)
+k_fast_step(DevSparse sp, DevFast ff, double* __restrict__ R, const double* __restrict__ D,
+            double* __restrict__ P, const double* __restrict__ W, double* __restrict__ Gout, int r,
+            const double* __restrict__ yvec, DevLowRank lr, const double* __restrict__ WS, int slot,
+            double* __restrict__ partials, const DevCtrl* __restrict__ c, int check_done) {
+  __shared__ double sh[8];
+  if (check_done && c->done) return;
+  constexpr int G = SDPLR_NT / LPR;
+  const int lane = threadIdx.x % LPR;
+  const long long total = (long long)gridDim.x * G;
+  const double a = c->alpha, yg = yvec[ff.gid_g];
+  double nrm = 0.0;
+  for (long long j = (long long)blockIdx.x * G + threadIdx.x / LPR; j < sp.n; j += total) {
+    double dj = 0.0;
+    for (int e = ff.drow_ptr[j]; e < ff.drow_ptr[j + 1]; e++) dj += ff.drow_val[e] * yvec[ff.drow_gid[e]];
+    for (int ch = lane * VEC; ch < r; ch += LPR * VEC) {
+      vecd<VEC> x = ldrow<VEC>(R + j * r + ch), pp = ldrow<VEC>(P + j * r + ch);
+      const vecd<VEC> d = ldrow<VEC>(D + j * r + ch), w = ldrow<VEC>(W + j * r + ch);
+      vecd<VEC> g;
+#pragma unroll
+      for (int k = 0; k < VEC; k++) {
+        x.v[k] += a * d.v[k];
+        pp.v[k] += a * w.v[k];
+        g.v[k] = pp.v[k] * yg + x.v[k] * dj;
+      }
+      for (int cc = 0; cc < lr.ST; cc++) {
+        const double b = lr.Bcat[(long long)cc * sp.n + j];
+        const vecd<VEC> ws = ldrow<VEC>(WS + (long long)cc * r + ch);
+#pragma unroll
+        for (int k = 0; k < VEC; k++) g.v[k] += ws.v[k] * b;
+      }
+#pragma unroll
+      for (int k = 0; k < VEC; k++) {
+        g.v[k] *= 2.0;
+        nrm += g.v[k] * g.v[k];
+      }
+      strow<VEC>(R + j * r + ch, x);
+      strow<VEC>(P + j * r + ch, pp);
+      strow<VEC>(Gout + j * r + ch, g);
+    }
+  }
+  nrm = block_sum1(nrm, sh);
+  if (threadIdx.x == 0) slot_partials(partials, slot)[blockIdx.x] = nrm;
 }

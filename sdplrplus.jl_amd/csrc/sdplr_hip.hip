@@ -56,6 +56,11 @@ struct sdplr_hip_solver {
   DevSparse sp{};
   DevLowRank lr{};
   bool all_covered = false;  // every slot of an (m+1)-vector is written by some matrix
+  // structured fast path (k_sparse.h, DevFast): one sparse matrix with off-diagonal entries
+  bool fast = false;
+  DevFast ff{};
+  DevSparse sp_fast{};       // sp with the segmented-reduction plan restricted to the diagonal-only matrices
+  DevSparse spg{};           // the general matrix A_g alone, as a symmetric CSR with fixed values
   FactorArena arena{};
   long long N = 0;
   double *lambda = nullptr, *lambda_ub = nullptr, *b = nullptr, *y = nullptr, *pv_raw = nullptr,
@@ -244,7 +249,7 @@ int alloc_factors(S* s) {
   long long stride = (s->N + 31) / 32 * 32;
   s->arena.stride = stride;
   s->arena.h = (int)s->h;
-  const size_t used = (size_t)(3 + 2 * s->h);  // R, G, dirt, s_0..s_{h-1}, y_0..y_{h-1}
+  const size_t used = (size_t)(3 + 2 * s->h + (s->fast ? 2 : 0));  // R, G, dirt, s_*, y_* [, P, W]
   double* base = nullptr;
   hipError_t e = hipMalloc((void**)&base, std::max<size_t>(used * stride, 1) * sizeof(double));
   if (e != hipSuccess) return fail(s, SDPLR_ERR_ALLOC, std::string("hipMalloc(factors): ") + hipGetErrorString(e));
@@ -487,6 +492,90 @@ int32_t sdplr_hip_finalize(S* s) {
     for (int k = 0; k < 2; k++) {
       HIPCK(s, hipHostMalloc((void**)&s->snap[k], sizeof(DevCtrl), hipHostMallocDefault));
       HIPCK(s, hipEventCreateWithFlags(&s->snap_ev[k], hipEventDisableTiming));
+    }
+  }
+  // ---- structured fast path: classify the sparse matrices ----
+  if (s->have_sparse && getenv("SDPLR_HIP_NO_FAST") == nullptr) {
+    std::vector<int> general;
+    for (int64_t k = 0; k < s->n_sparse; k++) {
+      bool diag_only = true;
+      for (int e = s->h_matptr[k]; e < s->h_matptr[k + 1] && diag_only; e++)
+        diag_only = (s->h_trv[s->h_nzind[e]] == colidx[s->h_nzind[e]]);
+      if (!diag_only) general.push_back((int)k);
+    }
+    if (general.size() == 1) {
+      const int kg = general[0];
+      // A_g as a symmetric CSR (mirror the upper-triangular entries, merge duplicates)
+      struct Ent { int i, j; double v; };
+      std::vector<Ent> ents;
+      for (int e = s->h_matptr[kg]; e < s->h_matptr[kg + 1]; e++) {
+        const int q = s->h_nzind[e], i = s->h_trv[q], j = colidx[q];
+        ents.push_back({i, j, s->h_one[e]});
+        if (i != j) ents.push_back({j, i, s->h_one[e]});
+      }
+      std::sort(ents.begin(), ents.end(), [](const Ent& a, const Ent& b) { return a.i != b.i ? a.i < b.i : a.j < b.j; });
+      std::vector<int> g_ptr(n + 1, 0), g_col;
+      std::vector<double> g_val;
+      for (size_t t = 0; t < ents.size(); t++) {
+        if (t > 0 && ents[t].i == ents[t - 1].i && ents[t].j == ents[t - 1].j) { g_val.back() += ents[t].v; continue; }
+        g_col.push_back(ents[t].j);
+        g_val.push_back(ents[t].v);
+        g_ptr[ents[t].i + 1]++;
+      }
+      for (int64_t i = 0; i < n; i++) g_ptr[i + 1] += g_ptr[i];
+      // diagonal-only matrices, by row, ascending matrix order
+      std::vector<int> d_ptr(n + 1, 0);
+      for (int64_t k = 0; k < s->n_sparse; k++)
+        if ((int)k != kg)
+          for (int e = s->h_matptr[k]; e < s->h_matptr[k + 1]; e++) d_ptr[s->h_trv[s->h_nzind[e]] + 1]++;
+      for (int64_t i = 0; i < n; i++) d_ptr[i + 1] += d_ptr[i];
+      std::vector<int> d_gid(d_ptr[n]), fillp(d_ptr.begin(), d_ptr.end() - 1);
+      std::vector<double> d_val(d_ptr[n]);
+      for (int64_t k = 0; k < s->n_sparse; k++)
+        if ((int)k != kg)
+          for (int e = s->h_matptr[k]; e < s->h_matptr[k + 1]; e++) {
+            const int pos = fillp[s->h_trv[s->h_nzind[e]]]++;
+            d_gid[pos] = s->h_gids[k];
+            d_val[pos] = s->h_one[e];
+          }
+      std::vector<int> diagpos(n, -1);
+      for (int64_t j = 0; j < n; j++)
+        for (int q = s->h_tcp[j]; q < s->h_tcp[j + 1]; q++)
+          if (s->h_trv[q] == (int)j) diagpos[j] = q;
+      // segmented-reduction plan without A_g
+      std::vector<int> f_short, f_cb, f_ce, f_long, f_lcp(1, 0);
+      for (int64_t k = 0; k < s->n_sparse; k++) {
+        if ((int)k == kg) continue;
+        const int len = s->h_matptr[k + 1] - s->h_matptr[k];
+        if (len <= SHORT_MAX) { f_short.push_back((int)k); continue; }
+        f_long.push_back((int)k);
+        for (int bgn = s->h_matptr[k]; bgn < s->h_matptr[k + 1]; bgn += CHUNK) {
+          f_cb.push_back(bgn);
+          f_ce.push_back(std::min(bgn + CHUNK, s->h_matptr[k + 1]));
+        }
+        f_lcp.push_back((int)f_cb.size());
+      }
+      s->sp_fast = sp;
+      DevSparse& sf = s->sp_fast;
+      sf.n_short = (int)f_short.size(); sf.n_chunks = (int)f_cb.size(); sf.n_long = (int)f_long.size();
+      sf.n_short_blocks = (sf.n_short + SDPLR_NT - 1) / SDPLR_NT;
+      if ((rc = upload(s, &sf.short_ids, f_short))) return rc;
+      if ((rc = upload(s, &sf.chunk_beg, f_cb))) return rc;
+      if ((rc = upload(s, &sf.chunk_end, f_ce))) return rc;
+      if ((rc = upload(s, &sf.long_ids, f_long))) return rc;
+      if ((rc = upload(s, &sf.long_chunk_ptr, f_lcp))) return rc;
+      DevSparse& sg = s->spg;
+      sg = DevSparse{};
+      sg.n = (int)n; sg.nnzS = (int)g_col.size();
+      if ((rc = upload(s, &sg.colptr, g_ptr))) return rc;
+      if ((rc = upload(s, &sg.rowval, g_col))) return rc;
+      { const double* gv = nullptr; if ((rc = upload(s, &gv, g_val))) return rc; sg.nzval = const_cast<double*>(gv); }
+      s->ff.gid_g = s->h_gids[kg];
+      if ((rc = upload(s, &s->ff.diagpos, diagpos))) return rc;
+      if ((rc = upload(s, &s->ff.drow_ptr, d_ptr))) return rc;
+      if ((rc = upload(s, &s->ff.drow_gid, d_gid))) return rc;
+      if ((rc = upload(s, &s->ff.drow_val, d_val))) return rc;
+      s->fast = true;
     }
   }
   if ((rc = alloc_factors(s))) return rc;
@@ -823,17 +912,17 @@ void enq_linesearch(S* s, int armijo, int chk, int fuse_y) {
       k_armijo_partials<<<s->nb_m, SDPLR_NT, 0, s->stream>>>(s->ctrl, (int)s->m, s->lambda, s->lambda_ub, s->pv_raw, s->A_RD, s->A_DD, s->y, s->partials, chk);
     }
     ProfScope ps(s, "armijo_pick");
-    k_armijo_pick<<<1, SDPLR_NT, 0, s->stream>>>(s->ctrl, (int)s->m, s->nb_m, s->A_RD, s->A_DD, s->partials, chk);
+    k_armijo_pick<<<1, SDPLR_NT, 0, s->stream>>>(s->ctrl, (int)s->m, s->nb_m, s->A_RD, s->A_DD, s->partials, chk, fuse_y);
   } else {
     {
       ProfScope ps(s, "ls_partials");
       k_ls_partials<<<s->nb_m, SDPLR_NT, 0, s->stream>>>(s->ctrl, (int)s->m, s->lambda, s->pv_raw, s->A_RD, s->A_DD, s->partials, chk);
     }
     ProfScope ps(s, "ls_solve");
-    k_ls_solve<<<1, SDPLR_NT, 0, s->stream>>>(s->ctrl, (int)s->m, s->nb_m, s->A_RD, s->A_DD, s->partials, chk);
+    k_ls_solve<<<1, SDPLR_NT, 0, s->stream>>>(s->ctrl, (int)s->m, s->nb_m, s->A_RD, s->A_DD, s->partials, chk, fuse_y);
   }
   ProfScope ps(s, "ls_commit");
-  k_ls_commit<<<s->nb_m, SDPLR_NT, 0, s->stream>>>(s->ctrl, (int)s->m, s->pv_raw, s->A_RD, s->A_DD, s->pv_lb, s->pv, fuse_y, s->y, s->lambda, s->lambda_ub, s->partials, chk);
+  k_ls_commit<<<s->nb_m, SDPLR_NT, 0, s->stream>>>(s->ctrl, (int)s->m, s->pv_raw, s->A_RD, s->A_DD, s->pv_lb, s->pv, fuse_y, s->y, s->lambda, s->lambda_ub, s->partials, chk, fuse_y, s->nb_spmm);
 }
 
 void enq_axpy_R(S* s, int chk) {
@@ -847,11 +936,87 @@ void enq_iteration(S* s, int armijo) {
   enq_linesearch(s, armijo, 1, 1);           // :210-214
   enq_axpy_R(s, 1);                          // :219
   enq_g(s, 1, true);                         // :221
-  {
-    ProfScope ps(s, "iter_tail");            // :224-241
-    k_norms<<<1, SDPLR_NT, 0, s->stream>>>(s->ctrl, s->nb_spmm, s->nb_m, 1, 1, s->partials);
-  }
+  // norms and the exit tests (:224-241, :272-277, :190) are folded by the next seam kernel
   enq_lbfgs_update(s, 1);                    // :244-246
+}
+
+// ---- structured fast path (k_sparse.h, DevFast) -----------------------------------------------------
+inline double* fast_P(S* s) { return aslot(s->arena, 3 + 2 * (int)s->h); }
+inline double* fast_W(S* s) { return aslot(s->arena, 3 + 2 * (int)s->h + 1); }
+
+// P = A_g·R from scratch (entry of the inner loop: removes any drift accumulated by P += α·W)
+void enq_fast_refresh_P(S* s) {
+  ProfScope ps(s, "spmm_P");
+  DevLowRank none{};
+  LV_DISPATCH((k_spmm<LPR, VEC><<<s->nb_spmm, SDPLR_NT, 0, s->stream>>>(s->spg, aslot(s->arena, AS_R), fast_P(s), (int)s->r, 1.0, none, nullptr, -1, s->partials, s->ctrl, 0)))
+}
+
+// one pass of the while body, src/sdplr.jl:190-278, with ONE gather pass (W = A_g·D)
+void enq_iteration_fast(S* s, int armijo) {
+  double *R = aslot(s->arena, AS_R), *G = aslot(s->arena, AS_G), *D = aslot(s->arena, AS_D);
+  double *P = fast_P(s), *W = fast_W(s);
+  enq_lbfgs_dir(s, 1, 1, 1);                                                          // :197-205
+  // ---- line search head: 𝒜(RDᵀ+DRᵀ), 𝒜(DDᵀ)  (src/linesearch.jl:8-18) ----
+  if (!s->all_covered) {
+    (void)hipMemsetAsync(s->A_RD, 0, (s->m + 1) * sizeof(double), s->stream);
+    (void)hipMemsetAsync(s->A_DD, 0, (s->m + 1) * sizeof(double), s->stream);
+  }
+  {
+    ProfScope ps(s, "rowdots");
+    LV_DISPATCH((k_rowdots<LPR, VEC><<<s->nb_spmm, SDPLR_NT, 0, s->stream>>>(s->sp_fast, s->ff, R, D, P, (int)s->r, SLOT_PD, s->partials, s->ctrl, 1)))
+  }
+  {
+    ProfScope ps(s, "spmm_W");
+    DevLowRank none{};
+    LV_DISPATCH((k_spmm<LPR, VEC><<<s->nb_spmm, SDPLR_NT, 0, s->stream>>>(s->spg, D, W, (int)s->r, 1.0, none, nullptr, SLOT_DW, s->partials, s->ctrl, 1, D)))
+  }
+  {
+    const int nb = s->sp_fast.n_short_blocks + s->sp_fast.n_chunks;
+    if (nb > 0) {
+      ProfScope ps(s, "segreduce");
+      k_segreduce<true><<<nb, SDPLR_NT, 0, s->stream>>>(s->sp_fast, s->A_RD, s->A_DD, s->ctrl, 1);
+    }
+    if (s->sp_fast.n_long > 0) {
+      ProfScope ps(s, "seg_finalize");
+      const int nbf = (s->sp_fast.n_long * 64 + SDPLR_NT - 1) / SDPLR_NT;
+      k_seg_finalize<true><<<nbf, SDPLR_NT, 0, s->stream>>>(s->sp_fast, s->A_RD, s->A_DD, s->ctrl, 1);
+    }
+  }
+  {
+    ProfScope ps(s, "fast_fill");
+    k_fast_fill<<<1, SDPLR_NT, 0, s->stream>>>(s->ff, s->A_RD, s->A_DD, SLOT_PD, s->nb_spmm, SLOT_DW, s->nb_spmm, s->partials, s->ctrl, 1);
+  }
+  enq_lowrank(s, R, D, 2, 2, s->A_RD, s->A_DD, 1);
+  // ---- scalar stage + commit (with y of the following g!) ----
+  if (armijo) {
+    {
+      ProfScope ps(s, "armijo_partials");
+      k_armijo_partials<<<s->nb_m, SDPLR_NT, 0, s->stream>>>(s->ctrl, (int)s->m, s->lambda, s->lambda_ub, s->pv_raw, s->A_RD, s->A_DD, s->y, s->partials, 1);
+    }
+    ProfScope ps(s, "armijo_pick");
+    k_armijo_pick<<<1, SDPLR_NT, 0, s->stream>>>(s->ctrl, (int)s->m, s->nb_m, s->A_RD, s->A_DD, s->partials, 1, 1);
+  } else {
+    {
+      ProfScope ps(s, "ls_partials");
+      k_ls_partials<<<s->nb_m, SDPLR_NT, 0, s->stream>>>(s->ctrl, (int)s->m, s->lambda, s->pv_raw, s->A_RD, s->A_DD, s->partials, 1);
+    }
+    ProfScope ps(s, "ls_solve");
+    k_ls_solve<<<1, SDPLR_NT, 0, s->stream>>>(s->ctrl, (int)s->m, s->nb_m, s->A_RD, s->A_DD, s->partials, 1, 1);
+  }
+  {
+    ProfScope ps(s, "ls_commit");
+    k_ls_commit<<<s->nb_m, SDPLR_NT, 0, s->stream>>>(s->ctrl, (int)s->m, s->pv_raw, s->A_RD, s->A_DD, s->pv_lb, s->pv, 1, s->y, s->lambda, s->lambda_ub, s->partials, 1, 1, s->nb_spmm);
+  }
+  if (s->lr.ST > 0) {
+    ProfScope ps(s, "fast_lr_ws");
+    k_fast_lr_ws<<<1, SDPLR_NT, 0, s->stream>>>(s->lr, (int)s->r, s->lr_W, s->y, s->lr_WS, s->ctrl, 1);
+  }
+  {
+    ProfScope ps(s, "fast_step");                                                     // :219-221
+    LV_DISPATCH((k_fast_step<LPR, VEC><<<s->nb_spmm, SDPLR_NT, 0, s->stream>>>(s->sp_fast, s->ff, R, D, P, W, G, (int)s->r, s->y, s->lr, s->lr_WS, SLOT_GNORM2, s->partials, s->ctrl, 1)))
+  }
+  // norms and the exit tests (:224-241, :272-277, :190) are folded by the next seam kernel
+  enq_lbfgs_update(s, 1);                                                             // :244-246
 }
 
 // host restatement of the Sturm bisection for the Lanczos tridiagonal
@@ -1099,7 +1264,7 @@ int32_t sdplr_hip_lbfgs_update(S* s, double stepsize) {
 static int32_t linesearch_common(S* s, int armijo, double alpha_max, double* alpha, double* L) {
   int rc = pull(s);
   if (rc) return rc;
-  s->hc->alpha_max = alpha_max; s->hc->done = 0; s->hc->err = 0;
+  s->hc->alpha_max = alpha_max; s->hc->done = 0; s->hc->err = 0; s->hc->reldelta_exit = 0;
   if ((rc = push(s))) return rc;
   enq_linesearch(s, armijo, 1, 0);   // chk = 1: a refused direction must stop the commit
   if ((rc = pull(s))) return rc;
@@ -1135,7 +1300,7 @@ int32_t sdplr_hip_inner_loop(S* s, double normC, double normb, int32_t grel, int
   if (rc) return rc;
   DevCtrl* c = s->hc;
   c->done = 0; c->exit_reason = 0; c->err = 0; c->use_armijo = use_armijo;
-  c->iters = 0; c->max_iters = max_local_iters;
+  c->iters = 0; c->max_iters = max_local_iters; c->reldelta_exit = 0; c->norms_pending = 0;
   c->cur_gtol = cur_gtol; c->fprec_eps = fprec_eps; c->normC = normC; c->normb = normb;
   c->grel = grel; c->prel = prel;
   c->L = *Lio; c->gnorm = *gnio; c->pvnorm = *pnio; c->alpha = 0.0; c->alpha_max = 1.0;
@@ -1147,11 +1312,14 @@ int32_t sdplr_hip_inner_loop(S* s, double normC, double normb, int32_t grel, int
   // snapshotted after each batch, and batch k+1 is already queued while the host inspects the
   // snapshot of batch k, so the GPU never waits for the host.
   const int ar = use_armijo ? 1 : 0;
+  const bool fastp = s->fast;
+  auto enq_iter = [&]() { if (fastp) enq_iteration_fast(s, use_armijo); else enq_iteration(s, use_armijo); };
+  if (fastp) enq_fast_refresh_P(s);
   const bool use_graph = !s->prof_on && max_local_iters >= 4 && getenv("SDPLR_HIP_NO_GRAPH") == nullptr;
   if (use_graph && !s->graph_exec[ar]) {
     hipGraph_t graph = nullptr;
     HIPCK(s, hipStreamBeginCapture(s->stream, hipStreamCaptureModeThreadLocal));
-    for (int i = 0; i < s->graph_iters; i++) enq_iteration(s, use_armijo);
+    for (int i = 0; i < s->graph_iters; i++) enq_iter();
     HIPCK(s, hipStreamEndCapture(s->stream, &graph));
     HIPCK(s, hipGraphInstantiate(&s->graph_exec[ar], graph, nullptr, nullptr, 0));
     HIPCK(s, hipGraphDestroy(graph));
@@ -1167,7 +1335,7 @@ int32_t sdplr_hip_inner_loop(S* s, double normC, double normb, int32_t grel, int
     if (use_graph) {
       HIPCK(s, hipGraphLaunch(s->graph_exec[ar], s->stream));
     } else {
-      for (int64_t i = 0; i < eager_batch; i++) enq_iteration(s, use_armijo);
+      for (int64_t i = 0; i < eager_batch; i++) enq_iter();
       HIPCK(s, hipGetLastError());
     }
     HIPCK(s, hipMemcpyAsync(s->snap[slot], s->ctrl, sizeof(DevCtrl), hipMemcpyDeviceToHost, s->stream));
@@ -1182,11 +1350,11 @@ int32_t sdplr_hip_inner_loop(S* s, double normC, double normb, int32_t grel, int
     int64_t passes = 0;
     for (;;) {
       const int64_t nb = std::min<int64_t>(8, max_local_iters - passes);
-      for (int64_t i = 0; i < nb; i++) enq_iteration(s, use_armijo);
+      for (int64_t i = 0; i < nb; i++) enq_iter();
       passes += std::max<int64_t>(nb, 0);
       if (nb <= 0) {
         s->prof_on = false;
-        enq_iteration(s, use_armijo);
+        enq_iter();
         s->prof_on = true;
       }
       HIPCK(s, hipGetLastError());
@@ -1215,6 +1383,7 @@ int32_t sdplr_hip_inner_loop(S* s, double normC, double normb, int32_t grel, int
     }
   }
   enq_boundary(s, 0, 1, 0, 0);   // fold the partials of a last lbfgs_update (time-budget exit)
+  if (fastp) enq_At_preprocess(s, 0);  // leave S consistent with the y of the last step, as g! would
   if ((rc = pull(s))) return rc;
   if (c->done) why = c->exit_reason;   // the device's verdict wins over the host's time check
   if (dbg)
