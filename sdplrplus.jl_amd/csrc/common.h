@@ -44,6 +44,7 @@ struct DevCtrl {
   double sigma, obj;
   // ---- per-iteration scalars ----
   double L, lastval, gnorm, pvnorm, alpha, descent, alpha_max;
+  double pv2_extra;    // ‖pv‖² share of slots committed by a scalar kernel (singleton fast path)
   double biquad[5];
   // ---- Lanczos (src/coreop.jl:461-500) ----
   int lz_done;

@@ -26,6 +26,27 @@ struct FactorArena {
 #define AS_D 2
 #define AS_S0 3                     // s_j at AS_S0 + j
 
+// streaming (read-once / write-once) accesses: non-temporal, so that the 300 MB of history that streams
+// through every iteration does not evict the 25.6 MB direction the gather kernel is about to re-read
+#ifdef SDPLR_NO_NT
+__device__ __forceinline__ double2 ldnt2(const double* p, long long i) { return reinterpret_cast<const double2*>(p)[i]; }
+__device__ __forceinline__ void stnt2(double* p, long long i, double2 v) { reinterpret_cast<double2*>(p)[i] = v; }
+#else
+typedef double sdplr_d2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ double2 ldnt2(const double* p, long long i) {
+  const sdplr_d2 t = __builtin_nontemporal_load(reinterpret_cast<const sdplr_d2*>(p) + i);
+  double2 o;
+  o.x = t.x;
+  o.y = t.y;
+  return o;
+}
+__device__ __forceinline__ void stnt2(double* p, long long i, double2 v) {
+  sdplr_d2 t;
+  t.x = v.x;
+  t.y = v.y;
+  __builtin_nontemporal_store(t, reinterpret_cast<sdplr_d2*>(p) + i);
+}
+#endif
 __host__ __device__ __forceinline__ double* aslot(const FactorArena& A, int k) { return A.base + (long long)k * A.stride; }
 __host__ __device__ __forceinline__ int as_y0(const FactorArena& A) { return AS_S0 + A.h; }  // y_j at as_y0(A) + j
 
@@ -146,7 +167,7 @@ k_lbfgs_boundary(DevCtrl* __restrict__ c, int h, int jfixed, int fin_mode, int d
   }
   if (tid != 0) return;
   if (norms) {
-    const double g = sqrt(gd.nrm[0]), pn = sqrt(gd.nrm[1]);
+    const double g = sqrt(gd.nrm[0]), pn = sqrt(gd.nrm[1] + c->pv2_extra);
     c->gnorm = c->grel ? g / c->normC : g;
     c->pvnorm = c->prel ? pn / c->normb : pn;
     c->norms_pending = 0;
@@ -210,19 +231,19 @@ k_lbfgs_dir(const DevCtrl* __restrict__ c, FactorArena A, long long N, int h, in
   const long long N2 = N >> 1;
   const long long stride = (long long)gridDim.x * SDPLR_NT;
   for (long long i = (long long)blockIdx.x * SDPLR_NT + threadIdx.x; i < N2; i += stride) {
-    const double2 g = reinterpret_cast<const double2*>(G)[i];
+    const double2 g = ldnt2(G, i);
     double2 r = g;
 #pragma unroll
     for (int k = 0; k < HM; k++)  // newest → oldest: q −= α y   (:94-102)
       if (k < h) {
-        const double2 y = reinterpret_cast<const double2*>(aslot(A, as_y0(A) + order[k]))[i];
+        const double2 y = ldnt2(aslot(A, as_y0(A) + order[k]), i);
         r.x -= ca[k] * y.x;
         r.y -= ca[k] * y.y;
       }
 #pragma unroll
     for (int k = HM - 1; k >= 0; k--)  // oldest → newest: r += γ s  (:104-113)
       if (k < h) {
-        const double2 s = reinterpret_cast<const double2*>(aslot(A, AS_S0 + order[k]))[i];
+        const double2 s = ldnt2(aslot(A, AS_S0 + order[k]), i);
         r.x += cg[k] * s.x;
         r.y += cg[k] * s.y;
       }
@@ -234,7 +255,7 @@ k_lbfgs_dir(const DevCtrl* __restrict__ c, FactorArena A, long long N, int h, in
       double2 ng;
       ng.x = -g.x;
       ng.y = -g.y;
-      reinterpret_cast<double2*>(ynext)[i] = ng;
+      stnt2(ynext, i, ng);
     }
     desc += d.x * g.x + d.y * g.y;
   }
@@ -295,7 +316,7 @@ __global__ void __launch_bounds__(SDPLR_NT) k_neg_copy(double* __restrict__ G, d
 // into partial slot SLOT_GRAM + q*SDPLR_HMAX + l.  !UPDATE recomputes row `jfixed` from the stored
 // vectors (used when the host has written history slots or G behind the library's back).
 template <int HM, bool UPDATE>
-__global__ void __launch_bounds__(SDPLR_NT)
+__global__ void __launch_bounds__(SDPLR_NT, HM <= 4 ? 4 : (HM <= 8 ? 2 : 1))
 k_lbfgs_update(const DevCtrl* __restrict__ c, FactorArena A, long long N, int h, int jfixed,
                int check_done, double* __restrict__ partials) {
   __shared__ double sh[5 * HM * (SDPLR_NT / 64)];
@@ -312,21 +333,21 @@ k_lbfgs_update(const DevCtrl* __restrict__ c, FactorArena A, long long N, int h,
   const long long N2 = N >> 1;
   const long long stride = (long long)gridDim.x * SDPLR_NT;
   for (long long i = (long long)blockIdx.x * SDPLR_NT + threadIdx.x; i < N2; i += stride) {
-    const double2 g = reinterpret_cast<const double2*>(G)[i];
+    const double2 g = ldnt2(G, i);
     double2 sn, yn;
     if (UPDATE) {
-      const double2 d = reinterpret_cast<const double2*>(dir)[i];
+      const double2 d = ldnt2(dir, i);
       sn.x = alpha * d.x;  // BLAS.scal!(stepsize, dir)  (:142)
       sn.y = alpha * d.y;
       reinterpret_cast<double2*>(dir)[i] = sn;
       reinterpret_cast<double2*>(Sj)[i] = sn;  // copy!(s_j, dir)  (:143)
-      const double2 yo = reinterpret_cast<const double2*>(Yj)[i];
+      const double2 yo = ldnt2(Yj, i);
       yn.x = yo.x + g.x;  // axpy!(1, grad, y_j)  (:145)
       yn.y = yo.y + g.y;
       reinterpret_cast<double2*>(Yj)[i] = yn;
     } else {
-      sn = reinterpret_cast<const double2*>(Sj)[i];
-      yn = reinterpret_cast<const double2*>(Yj)[i];
+      sn = ldnt2(Sj, i);
+      yn = ldnt2(Yj, i);
     }
 #pragma unroll
     for (int l = 0; l < HM; l++)
@@ -336,8 +357,8 @@ k_lbfgs_update(const DevCtrl* __restrict__ c, FactorArena A, long long N, int h,
           sl = sn;
           yl = yn;
         } else {
-          sl = reinterpret_cast<const double2*>(aslot(A, AS_S0 + l))[i];
-          yl = reinterpret_cast<const double2*>(aslot(A, as_y0(A) + l))[i];
+          sl = ldnt2(aslot(A, AS_S0 + l), i);
+          yl = ldnt2(aslot(A, as_y0(A) + l), i);
         }
         acc[0 * HM + l] += sn.x * yl.x + sn.y * yl.y;
         acc[1 * HM + l] += sl.x * yn.x + sl.y * yn.y;

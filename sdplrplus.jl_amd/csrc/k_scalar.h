@@ -436,3 +436,98 @@ k_lz_update2(DevCtrl* __restrict__ c, int n, int step, double* __restrict__ Av, 
     if (stop) c->lz_done = 1;
   }
 }
+
+// ---- scalar stage of the singleton fast path (k_sparse.h) ----------------------------------------------
+// One block: fold the row-attached line-search sums, add the extra slots (A_g and the low-rank matrices),
+// solve the quartic (src/linesearch.jl:44-112), decide the relative-decrease exit (src/sdplr.jl:238-241),
+// commit the extra slots (src/linesearch.jl:118-124, src/coreop.jl:229-236) and prepare the low-rank
+// coefficients WS of the moved point.
+__global__ void __launch_bounds__(SDPLR_NT)
+k_ls_solve_fast(DevCtrl* __restrict__ c, int m, int gid_g, int n_extra, const int* __restrict__ extra,
+                int nb, double* __restrict__ A_RD, double* __restrict__ A_DD,
+                const double* __restrict__ lam, const double* __restrict__ lam_ub,
+                double* __restrict__ pv_raw, const double* __restrict__ lb, double* __restrict__ pv,
+                double* __restrict__ y, int lr_ST, int r, const int* __restrict__ lr_col_gid,
+                const double* __restrict__ lr_D, double* __restrict__ lrW, double* __restrict__ lrWS,
+                const double* __restrict__ partials, int check_done) {
+  __shared__ double sh[10 * (SDPLR_NT / 64)];
+  if (check_done && c->done) return;
+  double s[10];
+#pragma unroll
+  for (int k = 0; k < 10; k++) s[k] = 0.0;
+  for (int i = threadIdx.x; i < nb; i += SDPLR_NT) {
+#pragma unroll
+    for (int k = 0; k < 8; k++) s[k] += slot_partials(partials, SLOT_LS + k)[i];
+    s[8] += slot_partials(partials, SLOT_PD)[i];
+    s[9] += slot_partials(partials, SLOT_DW)[i];
+  }
+  block_sum<10>(s, sh);
+  __shared__ double sh_alpha;
+  __shared__ int sh_err;
+  if (threadIdx.x == 0) {
+    const double sigma = c->sigma;
+    A_RD[gid_g] = s[8] + s[8];   // ⟨A_g, RDᵀ+DRᵀ⟩ = 2⟨P, D⟩
+    A_DD[gid_g] = s[9];          // ⟨A_g, DDᵀ⟩ = ⟨D, W⟩
+    for (int t = 0; t < n_extra; t++) {
+      const int k = extra[t];
+      if (k >= m) continue;
+      const double l = lam[k], nq0 = pv_raw[k], q1 = A_RD[k], q2 = A_DD[k];
+      s[0] += l * nq0;
+      s[1] += nq0 * nq0;
+      s[2] += l * q1;
+      s[3] += nq0 * q1;
+      s[4] += (l - sigma * nq0) * q2;
+      s[5] += q1 * q1;
+      s[6] += q1 * q2;
+      s[7] += q2 * q2;
+    }
+    const double p0 = c->obj, p1 = A_RD[m], p2 = A_DD[m];
+    double bq[5];
+    bq[0] = p0 - s[0] + sigma * s[1] / 2;
+    bq[1] = p1 - s[2] + sigma * s[3];
+    bq[2] = p2 - s[4] + sigma * s[5] / 2;
+    bq[3] = sigma * s[6];
+    bq[4] = sigma * s[7] / 2;
+    for (int k = 0; k < 5; k++) c->biquad[k] = bq[k];
+    double a = 0.0, f = bq[0];
+    const int rc = quartic_argmin(bq, c->alpha_max, &a, &f);
+    sh_err = rc;
+    sh_alpha = a;
+    if (rc != 0) {
+      c->err = rc;
+      c->done = 1;
+    } else {
+      c->alpha = a;
+      c->L = f;
+      const double last = c->lastval;
+      const double rel_delta = (last - f) / fmax(1.0, fmax(fabs(f), fabs(last)));
+      c->reldelta_exit = (rel_delta < c->fprec_eps) ? 1 : 0;
+      // commit of the extra slots
+      double pv2 = 0.0;
+      for (int t = 0; t < n_extra; t++) {
+        const int k = extra[t];
+        const double v = pv_raw[k] + a * (a * A_DD[k] + A_RD[k]);
+        pv_raw[k] = v;
+        if (k == m) {
+          c->obj = v;
+          y[m] = 1.0;
+        } else {
+          const double pc = fmax(v, lb[k]);
+          pv[k] = pc;
+          pv2 += pc * pc;
+          y[k] = -fmin(lam_ub[k], lam[k] - sigma * v);
+        }
+      }
+      c->pv2_extra = pv2;
+    }
+  }
+  __syncthreads();
+  if (sh_err != 0) return;
+  const double a = sh_alpha;
+  const int per = lr_ST * r;
+  for (int t = threadIdx.x; t < per; t += SDPLR_NT) {  // W0 ← W0 + α·W1 = R_newᵀB ; WS = y·D·W0
+    const double w = lrW[t] + a * lrW[per + t];
+    lrW[t] = w;
+    lrWS[t] = y[lr_col_gid[t / r]] * lr_D[t / r] * w;
+  }
+}

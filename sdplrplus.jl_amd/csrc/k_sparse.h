@@ -13,6 +13,7 @@
 // not by HBM streaming; there is no matrix-core work here (FP64 dot products of length r).
 #pragma once
 #include "common.h"
+#include "k_dense.h"
 
 struct DevSparse {
   int n, nnzT, nnzS, nnzAgg, n_sparse;
@@ -441,24 +442,48 @@ k_rowdots(DevSparse sp, DevFast ff, const double* __restrict__ R, const double* 
   const int lane = threadIdx.x % LPR;
   const long long total = (long long)gridDim.x * G;
   double pd = 0.0;
-  for (long long j = (long long)blockIdx.x * G + threadIdx.x / LPR; j < sp.n; j += total) {
-    double rd = 0.0, dd = 0.0;
+  // two rows per group and trip: six independent 16-B loads in flight per lane
+  for (long long j0 = (long long)blockIdx.x * G + threadIdx.x / LPR; j0 < sp.n; j0 += 2 * total) {
+    const long long j1 = j0 + total;
+    const bool has1 = j1 < sp.n;
+    double rd0 = 0.0, dd0 = 0.0, rd1 = 0.0, dd1 = 0.0;
     for (int ch = lane * VEC; ch < r; ch += LPR * VEC) {
-      const vecd<VEC> x = ldrow<VEC>(R + j * r + ch), d = ldrow<VEC>(D + j * r + ch), pp = ldrow<VEC>(P + j * r + ch);
+      const vecd<VEC> x0 = ldrow<VEC>(R + j0 * r + ch), d0 = ldrow<VEC>(D + j0 * r + ch), p0 = ldrow<VEC>(P + j0 * r + ch);
+      vecd<VEC> x1, d1, p1;
+      if (has1) {
+        x1 = ldrow<VEC>(R + j1 * r + ch);
+        d1 = ldrow<VEC>(D + j1 * r + ch);
+        p1 = ldrow<VEC>(P + j1 * r + ch);
+      } else {
+#pragma unroll
+        for (int k = 0; k < VEC; k++) x1.v[k] = d1.v[k] = p1.v[k] = 0.0;
+      }
 #pragma unroll
       for (int k = 0; k < VEC; k++) {
-        rd += x.v[k] * d.v[k];
-        dd += d.v[k] * d.v[k];
-        pd += pp.v[k] * d.v[k];
+        rd0 += x0.v[k] * d0.v[k];
+        dd0 += d0.v[k] * d0.v[k];
+        pd += p0.v[k] * d0.v[k];
+        rd1 += x1.v[k] * d1.v[k];
+        dd1 += d1.v[k] * d1.v[k];
+        pd += p1.v[k] * d1.v[k];
       }
     }
-    rd = group_sum<LPR>(rd);
-    dd = group_sum<LPR>(dd);
+    rd0 = group_sum<LPR>(rd0);
+    dd0 = group_sum<LPR>(dd0);
+    rd1 = group_sum<LPR>(rd1);
+    dd1 = group_sum<LPR>(dd1);
     if (lane == 0) {
-      const int q = ff.diagpos[j];
-      if (q >= 0) {
-        sp.UVt0[q] = rd + rd;
-        sp.UVt1[q] = dd;
+      const int q0 = ff.diagpos[j0];
+      if (q0 >= 0) {
+        sp.UVt0[q0] = rd0 + rd0;
+        sp.UVt1[q0] = dd0;
+      }
+      if (has1) {
+        const int q1 = ff.diagpos[j1];
+        if (q1 >= 0) {
+          sp.UVt0[q1] = rd1 + rd1;
+          sp.UVt1[q1] = dd1;
+        }
       }
     }
   }
@@ -542,4 +567,376 @@ k_fast_step(DevSparse sp, DevFast ff, double* __restrict__ R, const double* __re
   }
   nrm = block_sum1(nrm, sh);
   if (threadIdx.x == 0) slot_partials(partials, slot)[blockIdx.x] = nrm;
+}
+
+// ================================================================================================
+// Fast path, singleton form: every diagonal-only matrix has exactly one entry (MaxCut / MinBisection /
+// CutNorm rows e_i e_iᵀ).  Its 𝒜 values are then row-local — A_RD[k] = 2v⟨R_i,D_i⟩, A_DD[k] = v‖D_i‖² —
+// so the row-dot pass also produces the line-search sums of src/linesearch.jl:36-56 for those rows, and the
+// step kernel also commits them (src/linesearch.jl:118-124) and forms y (src/coreop.jl:229-236): the
+// segmented reduction, ls_partials and ls_commit launches disappear.  Slots not attached to a row — A_g
+// itself and the low-rank matrices ("extra" slots) — are handled by the single-block scalar kernel.
+// ================================================================================================
+template <int LPR, int VEC>
+__global__ void __launch_bounds__(SDPLR_NT)
+k_rowdots_ls(int n, int m, DevFast ff, const double* __restrict__ R, const double* __restrict__ D,
+             const double* __restrict__ P, int r, const double* __restrict__ lam,
+             const double* __restrict__ pv_raw, double* __restrict__ A_RD, double* __restrict__ A_DD,
+             double* __restrict__ partials, const DevCtrl* __restrict__ c, int check_done) {
+  __shared__ double sh[9 * (SDPLR_NT / 64)];
+  if (check_done && c->done) return;
+  constexpr int G = SDPLR_NT / LPR;
+  const int lane = threadIdx.x % LPR;
+  const long long total = (long long)gridDim.x * G;
+  const double sigma = c->sigma;
+  double acc[9];
+#pragma unroll
+  for (int k = 0; k < 9; k++) acc[k] = 0.0;
+  for (long long j = (long long)blockIdx.x * G + threadIdx.x / LPR; j < n; j += total) {
+    double rd = 0.0, dd = 0.0;
+    for (int ch = lane * VEC; ch < r; ch += LPR * VEC) {
+      const vecd<VEC> x = ldrow<VEC>(R + j * r + ch), d = ldrow<VEC>(D + j * r + ch), pp = ldrow<VEC>(P + j * r + ch);
+#pragma unroll
+      for (int k = 0; k < VEC; k++) {
+        rd += x.v[k] * d.v[k];
+        dd += d.v[k] * d.v[k];
+        acc[8] += pp.v[k] * d.v[k];
+      }
+    }
+    rd = group_sum<LPR>(rd);
+    dd = group_sum<LPR>(dd);
+    if (lane == 0)
+      for (int e = ff.drow_ptr[j]; e < ff.drow_ptr[j + 1]; e++) {
+        const int k = ff.drow_gid[e];
+        const double v = ff.drow_val[e];
+        const double q1 = v * (rd + rd), q2 = v * dd;
+        A_RD[k] = q1;
+        A_DD[k] = q2;
+        if (k < m) {
+          const double l = lam[k], nq0 = pv_raw[k];
+          acc[0] += l * nq0;
+          acc[1] += nq0 * nq0;
+          acc[2] += l * q1;
+          acc[3] += nq0 * q1;
+          acc[4] += (l - sigma * nq0) * q2;
+          acc[5] += q1 * q1;
+          acc[6] += q1 * q2;
+          acc[7] += q2 * q2;
+        }
+      }
+  }
+  block_sum<9>(acc, sh);
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int k = 0; k < 8; k++) slot_partials(partials, SLOT_LS + k)[blockIdx.x] = acc[k];
+    slot_partials(partials, SLOT_PD)[blockIdx.x] = acc[8];
+  }
+}
+
+// step + row-attached commit + g! in structured form (see k_fast_step); extra slots were committed by
+// k_ls_solve_fast, whose y values (y_g, low-rank owners) are read here.
+template <int LPR, int VEC>
+__global__ void __launch_bounds__(SDPLR_NT)
+k_fast_step2(int n, int m, DevFast ff, double* __restrict__ R, const double* __restrict__ D,
+             double* __restrict__ P, const double* __restrict__ W, double* __restrict__ Gout, int r,
+             double* __restrict__ yvec, const double* __restrict__ lam, const double* __restrict__ lam_ub,
+             double* __restrict__ pv_raw, const double* __restrict__ lb, double* __restrict__ pv,
+             const double* __restrict__ A_RD, const double* __restrict__ A_DD, DevLowRank lr,
+             const double* __restrict__ WS, double* __restrict__ partials, DevCtrl* __restrict__ c,
+             int check_done) {
+  __shared__ double sh[2 * (SDPLR_NT / 64)];
+  if (check_done && c->done) return;
+  constexpr int G = SDPLR_NT / LPR;
+  const int lane = threadIdx.x % LPR;
+  const long long total = (long long)gridDim.x * G;
+  const double a = c->alpha, sigma = c->sigma, yg = yvec[ff.gid_g];
+  double red[2] = {0.0, 0.0};  // ‖G‖², ‖pv‖² (row-attached slots)
+  for (long long j = (long long)blockIdx.x * G + threadIdx.x / LPR; j < n; j += total) {
+    double dj = 0.0;
+    for (int e = ff.drow_ptr[j]; e < ff.drow_ptr[j + 1]; e++) {  // every lane of the group: same values
+      const int k = ff.drow_gid[e];
+      const double v = pv_raw[k] + a * (a * A_DD[k] + A_RD[k]);   // src/linesearch.jl:118
+      double yk;
+      if (k < m) {
+        yk = -fmin(lam_ub[k], lam[k] - sigma * v);                // src/coreop.jl:233
+        if (lane == 0) {
+          const double pc = fmax(v, lb[k]);                       // src/linesearch.jl:122-124
+          pv[k] = pc;
+          red[1] += pc * pc;
+        }
+      } else {
+        yk = 1.0;                                                  // the cost slot, src/coreop.jl:235
+        if (lane == 0) c->obj = v;
+      }
+      dj += ff.drow_val[e] * yk;
+      if (lane == 0) yvec[k] = yk;
+    }
+    // pv_raw must be rewritten only after every lane of the group has read it
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0)
+      for (int e = ff.drow_ptr[j]; e < ff.drow_ptr[j + 1]; e++) {
+        const int k = ff.drow_gid[e];
+        pv_raw[k] = pv_raw[k] + a * (a * A_DD[k] + A_RD[k]);
+      }
+    for (int ch = lane * VEC; ch < r; ch += LPR * VEC) {
+      vecd<VEC> x = ldrow<VEC>(R + j * r + ch), pp = ldrow<VEC>(P + j * r + ch);
+      const vecd<VEC> d = ldrow<VEC>(D + j * r + ch), w = ldrow<VEC>(W + j * r + ch);
+      vecd<VEC> g;
+#pragma unroll
+      for (int k = 0; k < VEC; k++) {
+        x.v[k] += a * d.v[k];
+        pp.v[k] += a * w.v[k];
+        g.v[k] = pp.v[k] * yg + x.v[k] * dj;
+      }
+      for (int cc = 0; cc < lr.ST; cc++) {
+        const double b = lr.Bcat[(long long)cc * n + j];
+        const vecd<VEC> ws = ldrow<VEC>(WS + (long long)cc * r + ch);
+#pragma unroll
+        for (int k = 0; k < VEC; k++) g.v[k] += ws.v[k] * b;
+      }
+#pragma unroll
+      for (int k = 0; k < VEC; k++) {
+        g.v[k] *= 2.0;
+        red[0] += g.v[k] * g.v[k];
+      }
+      strow<VEC>(R + j * r + ch, x);
+      strow<VEC>(P + j * r + ch, pp);
+      strow<VEC>(Gout + j * r + ch, g);
+    }
+  }
+  block_sum<2>(red, sh);
+  if (threadIdx.x == 0) {
+    slot_partials(partials, SLOT_GNORM2)[blockIdx.x] = red[0];
+    slot_partials(partials, SLOT_PVNORM2)[blockIdx.x] = red[1];
+    if (blockIdx.x == 0) {
+      c->norms_pending = 1;
+      c->nb_gnorm = gridDim.x;
+      c->nb_pvnorm = gridDim.x;
+    }
+  }
+}
+
+// W = A_g·D with everything row-local of the line-search head riding along (singleton fast path):
+// while row j's neighbours are being gathered, R_j, D_j, P_j stream in, giving ⟨R_j,D_j⟩, ‖D_j‖², the
+// partials of ⟨P,D⟩ and ⟨D,W⟩, the 𝒜 values of the row's singleton constraints and their share of the
+// line-search sums (k_rowdots_ls + k_spmm in one sweep; the gather latency hides the extra streams).
+template <int LPR, int VEC>
+__global__ void __launch_bounds__(SDPLR_NT)
+k_spmm_fast(DevSparse sg, int m, DevFast ff, const double* __restrict__ R, const double* __restrict__ D,
+            const double* __restrict__ P, double* __restrict__ W, int r, const double* __restrict__ lam,
+            const double* __restrict__ pv_raw, double* __restrict__ A_RD, double* __restrict__ A_DD,
+            double* __restrict__ partials, const DevCtrl* __restrict__ c, int check_done) {
+  __shared__ double sh[10 * (SDPLR_NT / 64)];
+  if (check_done && c->done) return;
+  constexpr int G = SDPLR_NT / LPR;
+  const int lane = threadIdx.x % LPR;
+  const long long total = (long long)gridDim.x * G;
+  const double sigma = c->sigma;
+  double acc[10];  // 0..7 line-search sums, 8 ⟨P,D⟩, 9 ⟨D,W⟩
+#pragma unroll
+  for (int k = 0; k < 10; k++) acc[k] = 0.0;
+  for (long long j = (long long)blockIdx.x * G + threadIdx.x / LPR; j < sg.n; j += total) {
+    const int beg = sg.colptr[j], end = sg.colptr[j + 1];
+    double rd = 0.0, dd = 0.0;
+    for (int ch = lane * VEC; ch < r; ch += LPR * VEC) {
+      const vecd<VEC> xr = ldrow<VEC>(R + j * r + ch), xd = ldrow<VEC>(D + j * r + ch), xp = ldrow<VEC>(P + j * r + ch);
+      vecd<VEC> w;
+#pragma unroll
+      for (int k = 0; k < VEC; k++) w.v[k] = 0.0;
+      int p = beg;
+      for (; p + 4 <= end; p += 4) {
+        const long long i0 = sg.rowval[p], i1 = sg.rowval[p + 1], i2 = sg.rowval[p + 2], i3 = sg.rowval[p + 3];
+        const double v0 = sg.nzval[p], v1 = sg.nzval[p + 1], v2 = sg.nzval[p + 2], v3 = sg.nzval[p + 3];
+        const vecd<VEC> x0 = ldrow<VEC>(D + i0 * r + ch), x1 = ldrow<VEC>(D + i1 * r + ch);
+        const vecd<VEC> x2 = ldrow<VEC>(D + i2 * r + ch), x3 = ldrow<VEC>(D + i3 * r + ch);
+#pragma unroll
+        for (int k = 0; k < VEC; k++) {
+          w.v[k] += x0.v[k] * v0;
+          w.v[k] += x1.v[k] * v1;
+          w.v[k] += x2.v[k] * v2;
+          w.v[k] += x3.v[k] * v3;
+        }
+      }
+      for (; p < end; p++) {
+        const long long i = sg.rowval[p];
+        const double v = sg.nzval[p];
+        const vecd<VEC> x = ldrow<VEC>(D + i * r + ch);
+#pragma unroll
+        for (int k = 0; k < VEC; k++) w.v[k] += x.v[k] * v;
+      }
+#pragma unroll
+      for (int k = 0; k < VEC; k++) {
+        rd += xr.v[k] * xd.v[k];
+        dd += xd.v[k] * xd.v[k];
+        acc[8] += xp.v[k] * xd.v[k];
+        acc[9] += xd.v[k] * w.v[k];
+      }
+      strow<VEC>(W + j * r + ch, w);
+    }
+    rd = group_sum<LPR>(rd);
+    dd = group_sum<LPR>(dd);
+    if (lane == 0)
+      for (int e = ff.drow_ptr[j]; e < ff.drow_ptr[j + 1]; e++) {
+        const int k = ff.drow_gid[e];
+        const double v = ff.drow_val[e];
+        const double q1 = v * (rd + rd), q2 = v * dd;
+        A_RD[k] = q1;
+        A_DD[k] = q2;
+        if (k < m) {
+          const double l = lam[k], nq0 = pv_raw[k];
+          acc[0] += l * nq0;
+          acc[1] += nq0 * nq0;
+          acc[2] += l * q1;
+          acc[3] += nq0 * q1;
+          acc[4] += (l - sigma * nq0) * q2;
+          acc[5] += q1 * q1;
+          acc[6] += q1 * q2;
+          acc[7] += q2 * q2;
+        }
+      }
+  }
+  block_sum<10>(acc, sh);
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int k = 0; k < 8; k++) slot_partials(partials, SLOT_LS + k)[blockIdx.x] = acc[k];
+    slot_partials(partials, SLOT_PD)[blockIdx.x] = acc[8];
+    slot_partials(partials, SLOT_DW)[blockIdx.x] = acc[9];
+  }
+}
+
+// The step kernel of the singleton fast path fused with lbfgs_update! (src/lbfgs.jl:129-149): the new
+// gradient row never leaves registers between g! and the history update — s_j = α·D, y_j += G and the five
+// Gram rows of k_lbfgs_update are formed in the same sweep (19 N of traffic become 16 N, one launch less).
+// The update half is skipped when the line search decided the relative-decrease exit (src/sdplr.jl:239-241).
+// dirt is not rescaled in place (the reference's BLAS.scal!(stepsize, dir), :142): it is dead until the next
+// lbfgs_dir! overwrites it.
+template <int LPR, int VEC, int HM>
+__global__ void __launch_bounds__(SDPLR_NT, HM <= 4 ? 3 : 1)
+k_fast_step_update(int n, int m, DevFast ff, FactorArena A, int slotP, int slotW, int r, int h,
+                   double* __restrict__ yvec, const double* __restrict__ lam,
+                   const double* __restrict__ lam_ub, double* __restrict__ pv_raw,
+                   const double* __restrict__ lb, double* __restrict__ pv,
+                   const double* __restrict__ A_RD, const double* __restrict__ A_DD, DevLowRank lr,
+                   const double* __restrict__ WS, double* __restrict__ partials, DevCtrl* __restrict__ c,
+                   int check_done) {
+  __shared__ double sh[(5 * HM + 2) * (SDPLR_NT / 64)];
+  if (check_done && c->done) return;
+  constexpr int G = SDPLR_NT / LPR;
+  const int lane = threadIdx.x % LPR;
+  const long long total = (long long)gridDim.x * G;
+  const double a = c->alpha, sigma = c->sigma, yg = yvec[ff.gid_g];
+  const bool upd = (h > 0) && !c->reldelta_exit;
+  const int js = (h > 0) ? (c->latest % h) : 0;
+  double* R = aslot(A, AS_R);
+  double* Gout = aslot(A, AS_G);
+  const double* D = aslot(A, AS_D);
+  double* P = aslot(A, slotP);
+  const double* W = aslot(A, slotW);
+  double* Sj = aslot(A, AS_S0 + js);
+  double* Yj = aslot(A, as_y0(A) + js);
+  double acc[5 * HM + 2];  // Gram rows (see k_lbfgs_update), then ‖G‖², ‖pv‖²
+#pragma unroll
+  for (int k = 0; k < 5 * HM + 2; k++) acc[k] = 0.0;
+  for (long long j = (long long)blockIdx.x * G + threadIdx.x / LPR; j < n; j += total) {
+    double dj = 0.0;
+    for (int e = ff.drow_ptr[j]; e < ff.drow_ptr[j + 1]; e++) {
+      const int k = ff.drow_gid[e];
+      const double v = pv_raw[k] + a * (a * A_DD[k] + A_RD[k]);   // src/linesearch.jl:118
+      double yk;
+      if (k < m) {
+        yk = -fmin(lam_ub[k], lam[k] - sigma * v);                // src/coreop.jl:233
+        if (lane == 0) {
+          const double pc = fmax(v, lb[k]);                       // src/linesearch.jl:122-124
+          pv[k] = pc;
+          acc[5 * HM + 1] += pc * pc;
+        }
+      } else {
+        yk = 1.0;
+        if (lane == 0) c->obj = v;
+      }
+      dj += ff.drow_val[e] * yk;
+      if (lane == 0) yvec[k] = yk;
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0)
+      for (int e = ff.drow_ptr[j]; e < ff.drow_ptr[j + 1]; e++) {
+        const int k = ff.drow_gid[e];
+        pv_raw[k] = pv_raw[k] + a * (a * A_DD[k] + A_RD[k]);
+      }
+    for (int ch = lane * VEC; ch < r; ch += LPR * VEC) {
+      const long long off = j * r + ch;
+      vecd<VEC> x = ldrow<VEC>(R + off), pp = ldrow<VEC>(P + off);
+      const vecd<VEC> d = ldrow<VEC>(D + off), w = ldrow<VEC>(W + off);
+      vecd<VEC> g;
+#pragma unroll
+      for (int k = 0; k < VEC; k++) {
+        x.v[k] += a * d.v[k];
+        pp.v[k] += a * w.v[k];
+        g.v[k] = pp.v[k] * yg + x.v[k] * dj;
+      }
+      for (int cc = 0; cc < lr.ST; cc++) {
+        const double b = lr.Bcat[(long long)cc * n + j];
+        const vecd<VEC> ws = ldrow<VEC>(WS + (long long)cc * r + ch);
+#pragma unroll
+        for (int k = 0; k < VEC; k++) g.v[k] += ws.v[k] * b;
+      }
+#pragma unroll
+      for (int k = 0; k < VEC; k++) {
+        g.v[k] *= 2.0;
+        acc[5 * HM] += g.v[k] * g.v[k];
+      }
+      strow<VEC>(R + off, x);
+      strow<VEC>(P + off, pp);
+      strow<VEC>(Gout + off, g);
+      if (upd) {
+        const vecd<VEC> yo = ldrow<VEC>(Yj + off);
+        vecd<VEC> sn, yn;
+#pragma unroll
+        for (int k = 0; k < VEC; k++) {
+          sn.v[k] = a * d.v[k];        // s_j = stepsize·dir   (src/lbfgs.jl:142-143)
+          yn.v[k] = yo.v[k] + g.v[k];  // y_j += grad          (:145)
+        }
+        strow<VEC>(Sj + off, sn);
+        strow<VEC>(Yj + off, yn);
+#pragma unroll
+        for (int l = 0; l < HM; l++)
+          if (l < h) {
+            vecd<VEC> sl, yl;
+            if (l == js) {
+              sl = sn;
+              yl = yn;
+            } else {
+              sl = ldrow<VEC>(aslot(A, AS_S0 + l) + off);
+              yl = ldrow<VEC>(aslot(A, as_y0(A) + l) + off);
+            }
+#pragma unroll
+            for (int k = 0; k < VEC; k++) {
+              acc[0 * HM + l] += sn.v[k] * yl.v[k];
+              acc[1 * HM + l] += sl.v[k] * yn.v[k];
+              acc[2 * HM + l] += yn.v[k] * yl.v[k];
+              acc[3 * HM + l] += sl.v[k] * g.v[k];
+              acc[4 * HM + l] += yl.v[k] * g.v[k];
+            }
+          }
+      }
+    }
+  }
+  block_sum<5 * HM + 2>(acc, sh);
+  if (threadIdx.x == 0) {
+    if (upd) {
+#pragma unroll
+      for (int q = 0; q < 5; q++)
+#pragma unroll
+        for (int l = 0; l < HM; l++)
+          if (l < h) slot_partials(partials, SLOT_GRAM + q * SDPLR_HMAX + l)[blockIdx.x] = acc[q * HM + l];
+    }
+    slot_partials(partials, SLOT_GNORM2)[blockIdx.x] = acc[5 * HM];
+    slot_partials(partials, SLOT_PVNORM2)[blockIdx.x] = acc[5 * HM + 1];
+    if (blockIdx.x == 0) {
+      if (upd) c->gram_pending = 1;
+      c->norms_pending = 1;
+      c->nb_gnorm = gridDim.x;
+      c->nb_pvnorm = gridDim.x;
+    }
+  }
 }

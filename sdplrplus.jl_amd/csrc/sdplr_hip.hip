@@ -61,6 +61,9 @@ struct sdplr_hip_solver {
   DevFast ff{};
   DevSparse sp_fast{};       // sp with the segmented-reduction plan restricted to the diagonal-only matrices
   DevSparse spg{};           // the general matrix A_g alone, as a symmetric CSR with fixed values
+  bool fast_singleton = false;   // every diagonal-only matrix has exactly one entry (k_sparse.h, singleton form)
+  const int* extra_slots = nullptr;  // slots not attached to a row: A_g and the low-rank matrices
+  int n_extra = 0;
   FactorArena arena{};
   long long N = 0;
   double *lambda = nullptr, *lambda_ub = nullptr, *b = nullptr, *y = nullptr, *pv_raw = nullptr,
@@ -77,6 +80,7 @@ struct sdplr_hip_solver {
 
   // kernel shapes
   int LPR = 1, VEC = 1, HM = 4;
+  int nb_upd = 1;  // grid of k_lbfgs_update (its per-block partials are folded by one block)
   int nb_dense = 1, nb_m = 1, nb_sddmm = 1, nb_spmm = 1, nb_spmv = 1, nb_nnzT = 1, nb_nnzS = 1, nb_n = 1;
 
   // captured batch of inner iterations (hipGraph), per line-search kind; rebuilt after reset_rank
@@ -258,6 +262,9 @@ int alloc_factors(S* s) {
   choose_shape(s);
   const int G = SDPLR_NT / s->LPR;
   s->nb_dense = blocks_for((s->N + 1) / 2, SDPLR_NT, SDPLR_MAXNB);
+  if (const char* e = getenv("SDPLR_HIP_NB_DENSE")) s->nb_dense = std::max(1, std::min(atoi(e), SDPLR_MAXNB));
+  s->nb_upd = std::min(s->nb_dense, 512);
+  if (const char* e = getenv("SDPLR_HIP_NB_UPD")) s->nb_upd = std::max(1, std::min(atoi(e), SDPLR_MAXNB));
   s->nb_sddmm = blocks_for(s->nnzT, G, 8192);
   s->nb_spmm = blocks_for(s->n, G, SDPLR_MAXNB);
   return SDPLR_OK;
@@ -576,6 +583,14 @@ int32_t sdplr_hip_finalize(S* s) {
       if ((rc = upload(s, &s->ff.drow_gid, d_gid))) return rc;
       if ((rc = upload(s, &s->ff.drow_val, d_val))) return rc;
       s->fast = true;
+      bool single = s->all_covered;
+      for (int64_t k = 0; k < s->n_sparse && single; k++)
+        if ((int)k != kg && s->h_matptr[k + 1] - s->h_matptr[k] != 1) single = false;
+      std::vector<int> extra(1, s->h_gids[kg]);
+      for (auto& L : s->h_lr) extra.push_back((int)L.gid);
+      if ((rc = upload(s, &s->extra_slots, extra))) return rc;
+      s->n_extra = (int)extra.size();
+      s->fast_singleton = single && getenv("SDPLR_HIP_NO_FAST2") == nullptr;
     }
   }
   if ((rc = alloc_factors(s))) return rc;
@@ -861,10 +876,10 @@ void enq_f(S* s) {
 // 1-block seam kernel: fold update partials / loop tests / two-loop coefficients (k_dense.h)
 void enq_boundary(S* s, int jfixed, int fin_mode, int do_loop, int do_coeff) {
   ProfScope ps(s, "lbfgs_boundary");
-  k_lbfgs_boundary<<<1, 1024, 0, s->stream>>>(s->ctrl, (int)s->h, jfixed, fin_mode, do_loop, do_coeff, s->nb_dense, s->partials);
+  k_lbfgs_boundary<<<1, 1024, 0, s->stream>>>(s->ctrl, (int)s->h, jfixed, fin_mode, do_loop, do_coeff, s->nb_upd, s->partials);
 }
 void enq_gram_row(S* s, int j) {
-  HM_DISPATCH((k_lbfgs_update<HM, false><<<s->nb_dense, SDPLR_NT, 0, s->stream>>>(s->ctrl, s->arena, s->N, (int)s->h, j, 0, s->partials)))
+  HM_DISPATCH((k_lbfgs_update<HM, false><<<s->nb_upd, SDPLR_NT, 0, s->stream>>>(s->ctrl, s->arena, s->N, (int)s->h, j, 0, s->partials)))
   enq_boundary(s, j, 2, 0, 0);
 }
 // make the Gram data consistent with the stored history and the current G (see k_dense.h)
@@ -900,7 +915,7 @@ void enq_lbfgs_dir(S* s, int negate, int in_loop, int apply_fallback) {
 void enq_lbfgs_update(S* s, int chk) {
   if (s->h == 0) return;
   ProfScope ps(s, "lbfgs_update");
-  HM_DISPATCH((k_lbfgs_update<HM, true><<<s->nb_dense, SDPLR_NT, 0, s->stream>>>(s->ctrl, s->arena, s->N, (int)s->h, 0, chk, s->partials)))
+  HM_DISPATCH((k_lbfgs_update<HM, true><<<s->nb_upd, SDPLR_NT, 0, s->stream>>>(s->ctrl, s->arena, s->N, (int)s->h, 0, chk, s->partials)))
 }
 
 // both line searches up to and including the commit; fuse_y also writes y of the following g!
@@ -1016,6 +1031,36 @@ void enq_iteration_fast(S* s, int armijo) {
     LV_DISPATCH((k_fast_step<LPR, VEC><<<s->nb_spmm, SDPLR_NT, 0, s->stream>>>(s->sp_fast, s->ff, R, D, P, W, G, (int)s->r, s->y, s->lr, s->lr_WS, SLOT_GNORM2, s->partials, s->ctrl, 1)))
   }
   // norms and the exit tests (:224-241, :272-277, :190) are folded by the next seam kernel
+  enq_lbfgs_update(s, 1);                                                             // :244-246
+}
+
+// singleton form of the fast path (exact line search only): 8 launches per iteration
+void enq_iteration_fast2(S* s) {
+  double *R = aslot(s->arena, AS_R), *G = aslot(s->arena, AS_G), *D = aslot(s->arena, AS_D);
+  double *P = fast_P(s), *W = fast_W(s);
+  enq_lbfgs_dir(s, 1, 1, 1);                                                          // :197-205
+  {
+    ProfScope ps(s, "spmm_W");   // W = A_g·D + row dots + line-search sums of the row-attached constraints
+    LV_DISPATCH((k_spmm_fast<LPR, VEC><<<s->nb_spmm, SDPLR_NT, 0, s->stream>>>(s->spg, (int)s->m, s->ff, R, D, P, W, (int)s->r, s->lambda, s->pv_raw, s->A_RD, s->A_DD, s->partials, s->ctrl, 1)))
+  }
+  enq_lowrank(s, R, D, 2, 2, s->A_RD, s->A_DD, 1);
+  {
+    ProfScope ps(s, "ls_solve_fast");
+    k_ls_solve_fast<<<1, SDPLR_NT, 0, s->stream>>>(s->ctrl, (int)s->m, s->ff.gid_g, s->n_extra, s->extra_slots, s->nb_spmm, s->A_RD, s->A_DD, s->lambda, s->lambda_ub, s->pv_raw, s->pv_lb, s->pv, s->y, s->lr.ST, (int)s->r, s->lr.col_gid, s->lr.Dcat, s->lr_W, s->lr_WS, s->partials, 1);
+  }
+  // opt-in: measured 111 µs against 41 + 65 µs for the two separate kernels at the north-star size (register
+  // pressure: 166 VGPRs + scratch), so the separate kernels stay the default
+  if (s->h >= 1 && s->h <= 8 && getenv("SDPLR_HIP_FUSED_UPDATE") != nullptr) {
+    ProfScope ps(s, "fast_step_update");                                              // :219-246
+    const int sP = 3 + 2 * (int)s->h, sW = sP + 1;
+    if (s->HM == 4) { LV_DISPATCH((k_fast_step_update<LPR, VEC, 4><<<s->nb_upd, SDPLR_NT, 0, s->stream>>>((int)s->n, (int)s->m, s->ff, s->arena, sP, sW, (int)s->r, (int)s->h, s->y, s->lambda, s->lambda_ub, s->pv_raw, s->pv_lb, s->pv, s->A_RD, s->A_DD, s->lr, s->lr_WS, s->partials, s->ctrl, 1))) }
+    else { LV_DISPATCH((k_fast_step_update<LPR, VEC, 8><<<s->nb_upd, SDPLR_NT, 0, s->stream>>>((int)s->n, (int)s->m, s->ff, s->arena, sP, sW, (int)s->r, (int)s->h, s->y, s->lambda, s->lambda_ub, s->pv_raw, s->pv_lb, s->pv, s->A_RD, s->A_DD, s->lr, s->lr_WS, s->partials, s->ctrl, 1))) }
+    return;
+  }
+  {
+    ProfScope ps(s, "fast_step");                                                     // :219-234
+    LV_DISPATCH((k_fast_step2<LPR, VEC><<<s->nb_spmm, SDPLR_NT, 0, s->stream>>>((int)s->n, (int)s->m, s->ff, R, D, P, W, G, (int)s->r, s->y, s->lambda, s->lambda_ub, s->pv_raw, s->pv_lb, s->pv, s->A_RD, s->A_DD, s->lr, s->lr_WS, s->partials, s->ctrl, 1)))
+  }
   enq_lbfgs_update(s, 1);                                                             // :244-246
 }
 
@@ -1300,7 +1345,7 @@ int32_t sdplr_hip_inner_loop(S* s, double normC, double normb, int32_t grel, int
   if (rc) return rc;
   DevCtrl* c = s->hc;
   c->done = 0; c->exit_reason = 0; c->err = 0; c->use_armijo = use_armijo;
-  c->iters = 0; c->max_iters = max_local_iters; c->reldelta_exit = 0; c->norms_pending = 0;
+  c->iters = 0; c->max_iters = max_local_iters; c->reldelta_exit = 0; c->norms_pending = 0; c->pv2_extra = 0.0;
   c->cur_gtol = cur_gtol; c->fprec_eps = fprec_eps; c->normC = normC; c->normb = normb;
   c->grel = grel; c->prel = prel;
   c->L = *Lio; c->gnorm = *gnio; c->pvnorm = *pnio; c->alpha = 0.0; c->alpha_max = 1.0;
@@ -1313,7 +1358,12 @@ int32_t sdplr_hip_inner_loop(S* s, double normC, double normb, int32_t grel, int
   // snapshot of batch k, so the GPU never waits for the host.
   const int ar = use_armijo ? 1 : 0;
   const bool fastp = s->fast;
-  auto enq_iter = [&]() { if (fastp) enq_iteration_fast(s, use_armijo); else enq_iteration(s, use_armijo); };
+  const bool fast2 = fastp && s->fast_singleton && !use_armijo;
+  auto enq_iter = [&]() {
+    if (fast2) enq_iteration_fast2(s);
+    else if (fastp) enq_iteration_fast(s, use_armijo);
+    else enq_iteration(s, use_armijo);
+  };
   if (fastp) enq_fast_refresh_P(s);
   const bool use_graph = !s->prof_on && max_local_iters >= 4 && getenv("SDPLR_HIP_NO_GRAPH") == nullptr;
   if (use_graph && !s->graph_exec[ar]) {
