@@ -14,6 +14,8 @@
 #include <cstring>
 #include <limits>
 #include <map>
+#include <mutex>
+#include <shared_mutex>
 #include <string>
 #include <vector>
 
@@ -25,6 +27,13 @@
 namespace {
 
 std::string g_err;
+// ROCm 7.2: while one host thread records a hipGraph, HIP calls made by OTHER threads fail ("operation
+// failed due to a previous error during capture", any capture mode).  Every entry point therefore holds
+// this lock shared; a capture takes it exclusively.
+std::shared_mutex g_api_rw;
+struct ApiShared {
+  std::shared_lock<std::shared_mutex> l{g_api_rw};
+};
 
 struct LowRankHost {
   int64_t gid, s;
@@ -86,6 +95,7 @@ struct sdplr_hip_solver {
   // captured batch of inner iterations (hipGraph), per line-search kind; rebuilt after reset_rank
   hipGraphExec_t graph_exec[2] = {nullptr, nullptr};
   int graph_iters = 8;
+  bool graph_disabled = false;
 
   // Gram bookkeeping (see k_dense.h)
   bool gram_dirty = false, sg_stale = false, ynext_pending = false;
@@ -147,7 +157,9 @@ int upload(S* s, const T** dst, const std::vector<T>& v) {
 int dzero(S* s, double** p, size_t count) {
   int rc = dalloc(s, p, count);
   if (rc) return rc;
-  HIPCK(s, hipMemset(*p, 0, std::max<size_t>(count, 1) * sizeof(double)));
+  // zero-fill ON THE SOLVER'S STREAM: a legacy-stream hipMemset is not ordered with this non-blocking
+  // stream, so a late zero-fill could wipe an upload issued after it (seen with 8 concurrent handles)
+  HIPCK(s, hipMemsetAsync(*p, 0, std::max<size_t>(count, 1) * sizeof(double), s->stream));
   return SDPLR_OK;
 }
 
@@ -257,7 +269,8 @@ int alloc_factors(S* s) {
   double* base = nullptr;
   hipError_t e = hipMalloc((void**)&base, std::max<size_t>(used * stride, 1) * sizeof(double));
   if (e != hipSuccess) return fail(s, SDPLR_ERR_ALLOC, std::string("hipMalloc(factors): ") + hipGetErrorString(e));
-  HIPCK(s, hipMemset(base, 0, used * stride * sizeof(double)));
+  HIPCK(s, hipMemsetAsync(base, 0, used * stride * sizeof(double), s->stream));
+  HIPCK(s, hipStreamSynchronize(s->stream));
   s->arena.base = base;
   choose_shape(s);
   const int G = SDPLR_NT / s->LPR;
@@ -281,17 +294,20 @@ const char* sdplr_hip_version(void) { return "sdplr_hip 0.1 (gfx950, FP64)"; }
 const char* sdplr_hip_last_error(const sdplr_hip_solver* s) { return s ? s->err.c_str() : g_err.c_str(); }
 
 int32_t sdplr_hip_device_synchronize(void) {
+  ApiShared api_guard;
   if (have_device() <= 0) return fail(nullptr, SDPLR_ERR_NO_DEVICE, "no HIP device");
   hipError_t e = hipDeviceSynchronize();
   if (e != hipSuccess) return fail(nullptr, SDPLR_ERR_HIP, std::string("hipDeviceSynchronize: ") + hipGetErrorString(e));
   return SDPLR_OK;
 }
 int32_t sdplr_hip_device_count(int32_t* count) {
+  ApiShared api_guard;
   if (!count) return SDPLR_ERR_INVALID_ARG;
   *count = have_device();
   return SDPLR_OK;
 }
 int32_t sdplr_hip_set_device(int32_t device) {
+  ApiShared api_guard;
   if (have_device() <= 0) return fail(nullptr, SDPLR_ERR_NO_DEVICE, "no HIP device");
   hipError_t e = hipSetDevice(device);
   if (e != hipSuccess) return fail(nullptr, SDPLR_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(e));
@@ -299,6 +315,7 @@ int32_t sdplr_hip_set_device(int32_t device) {
 }
 
 int32_t sdplr_hip_create(int64_t n, int64_t m, int64_t r, int64_t h, sdplr_hip_solver** out) {
+  ApiShared api_guard;
   if (!out) return fail(nullptr, SDPLR_ERR_INVALID_ARG, "create: null out");
   *out = nullptr;
   if (n < 1 || m < 0 || r < 1 || h < 0) return fail(nullptr, SDPLR_ERR_INVALID_ARG, "create: bad sizes");
@@ -316,6 +333,7 @@ int32_t sdplr_hip_set_sparse(S* s, int64_t base, int64_t n_sparse, const int64_t
                              const int64_t* nzind, const double* one, const double* two,
                              const int64_t* gids, int64_t nnzT, const int64_t* tcp, const int64_t* trv,
                              int64_t nnzS, const int64_t* fcp, const int64_t* frv, const int64_t* mapped) {
+  ApiShared api_guard;
   if (!s) return fail(nullptr, SDPLR_ERR_INVALID_ARG, "null handle");
   if (s->finalized || s->have_sparse) return fail(s, SDPLR_ERR_STATE, "set_sparse: already set / finalized");
   if (base != 0 && base != 1) return fail(s, SDPLR_ERR_INVALID_ARG, "set_sparse: index_base must be 0 or 1");
@@ -368,6 +386,7 @@ int32_t sdplr_hip_set_sparse(S* s, int64_t base, int64_t n_sparse, const int64_t
 }
 
 int32_t sdplr_hip_add_symlowrank(S* s, int64_t base, int64_t gid, int64_t sc, const double* B, const double* D) {
+  ApiShared api_guard;
   if (!s) return fail(nullptr, SDPLR_ERR_INVALID_ARG, "null handle");
   if (s->finalized) return fail(s, SDPLR_ERR_STATE, "add_symlowrank: already finalized");
   if (sc < 1 || !B || !D || gid - base < 0 || gid - base > s->m) return fail(s, SDPLR_ERR_INVALID_ARG, "add_symlowrank: bad args");
@@ -380,6 +399,7 @@ int32_t sdplr_hip_add_symlowrank(S* s, int64_t base, int64_t gid, int64_t sc, co
 }
 
 int32_t sdplr_hip_finalize(S* s) {
+  ApiShared api_guard;
   if (!s) return fail(nullptr, SDPLR_ERR_INVALID_ARG, "null handle");
   if (s->finalized) return fail(s, SDPLR_ERR_STATE, "finalize: already finalized");
   HIPCK(s, hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
@@ -475,8 +495,10 @@ int32_t sdplr_hip_finalize(S* s) {
   {  // all-equality defaults (src/structs.jl:266-268, :247)
     std::vector<double> inf(m, std::numeric_limits<double>::infinity()), ninf(m, -std::numeric_limits<double>::infinity());
     if (m > 0) {
-      HIPCK(s, hipMemcpy(s->lambda_ub, inf.data(), m * sizeof(double), hipMemcpyHostToDevice));
-      HIPCK(s, hipMemcpy(s->pv_lb, ninf.data(), m * sizeof(double), hipMemcpyHostToDevice));
+      // same stream as the zero-fills above, and drained before the host vectors go out of scope
+      HIPCK(s, hipMemcpyAsync(s->lambda_ub, inf.data(), m * sizeof(double), hipMemcpyHostToDevice, s->stream));
+      HIPCK(s, hipMemcpyAsync(s->pv_lb, ninf.data(), m * sizeof(double), hipMemcpyHostToDevice, s->stream));
+      HIPCK(s, hipStreamSynchronize(s->stream));
     }
   }
   if ((rc = dzero(s, &s->partials, (size_t)SDPLR_NSLOT * SDPLR_MAXNB))) return rc;
@@ -495,7 +517,8 @@ int32_t sdplr_hip_finalize(S* s) {
     s->hc->sigma = 2.0;             // config.σ_0 default, src/options.jl:5
     s->hc->alpha_max = 1.0;
     s->hc->latest = (int)s->h;      // src/lbfgs.jl:45
-    HIPCK(s, hipMemcpy(s->ctrl, s->hc, sizeof(DevCtrl), hipMemcpyHostToDevice));
+    HIPCK(s, hipMemcpyAsync(s->ctrl, s->hc, sizeof(DevCtrl), hipMemcpyHostToDevice, s->stream));
+    HIPCK(s, hipStreamSynchronize(s->stream));
     for (int k = 0; k < 2; k++) {
       HIPCK(s, hipHostMalloc((void**)&s->snap[k], sizeof(DevCtrl), hipHostMallocDefault));
       HIPCK(s, hipEventCreateWithFlags(&s->snap_ev[k], hipEventDisableTiming));
@@ -607,11 +630,13 @@ int32_t sdplr_hip_finalize(S* s) {
   std::vector<int>().swap(s->h_nzind); std::vector<int>().swap(s->h_trv); std::vector<int>().swap(s->h_frv);
   std::vector<int>().swap(s->h_mapped); std::vector<double>().swap(s->h_one); std::vector<double>().swap(s->h_two);
   for (auto& L : s->h_lr) { std::vector<double>().swap(L.B); }
+  HIPCK(s, hipStreamSynchronize(s->stream));
   s->finalized = true;
   return SDPLR_OK;
 }
 
 int32_t sdplr_hip_destroy(S* s) {
+  ApiShared api_guard;
   if (!s) return SDPLR_OK;
   if (s->stream) (void)hipStreamSynchronize(s->stream);
   for (auto& p : s->prof_pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
@@ -632,6 +657,7 @@ int32_t sdplr_hip_destroy(S* s) {
 }
 
 int32_t sdplr_hip_reset_rank(S* s, int64_t new_r) {
+  ApiShared api_guard;
   NEED_FINAL(s);
   if (new_r < 1 || s->n * new_r >= (1LL << 40)) return fail(s, SDPLR_ERR_INVALID_ARG, "reset_rank: bad rank");
   HIPCK(s, hipStreamSynchronize(s->stream));
@@ -643,9 +669,9 @@ int32_t sdplr_hip_reset_rank(S* s, int64_t new_r) {
   int rc = alloc_factors(s);
   if (rc) return rc;
   const int64_t m = s->m;
-  HIPCK(s, hipMemset(s->lambda, 0, std::max<int64_t>(m, 1) * sizeof(double)));
-  HIPCK(s, hipMemset(s->pv, 0, std::max<int64_t>(m, 1) * sizeof(double)));
-  for (double* p : {s->y, s->pv_raw, s->A_RD, s->A_DD}) HIPCK(s, hipMemset(p, 0, (m + 1) * sizeof(double)));
+  HIPCK(s, hipMemsetAsync(s->lambda, 0, std::max<int64_t>(m, 1) * sizeof(double), s->stream));
+  HIPCK(s, hipMemsetAsync(s->pv, 0, std::max<int64_t>(m, 1) * sizeof(double), s->stream));
+  for (double* p : {s->y, s->pv_raw, s->A_RD, s->A_DD}) HIPCK(s, hipMemsetAsync(p, 0, (m + 1) * sizeof(double), s->stream));
   if ((rc = dzero(s, &s->lr_part, (size_t)s->nb_lr * 2 * std::max(s->lr.ST, 1) * s->r))) return rc;
   if ((rc = dzero(s, &s->lr_W, (size_t)2 * std::max(s->lr.ST, 1) * s->r))) return rc;
   if ((rc = dzero(s, &s->lr_WS, (size_t)std::max(s->lr.ST, 1) * s->r))) return rc;
@@ -663,6 +689,7 @@ int32_t sdplr_hip_reset_rank(S* s, int64_t new_r) {
 // state transfer
 // ================================================================================================
 int32_t sdplr_hip_set_factor(S* s, int32_t slot, const double* h) {
+  ApiShared api_guard;
   NEED_FINAL(s);
   double* p = factor_ptr(s, slot);
   if (!p || !h) return fail(s, SDPLR_ERR_INVALID_ARG, "set_factor: bad slot");
@@ -672,6 +699,7 @@ int32_t sdplr_hip_set_factor(S* s, int32_t slot, const double* h) {
   return SDPLR_OK;
 }
 int32_t sdplr_hip_get_factor(S* s, int32_t slot, double* h) {
+  ApiShared api_guard;
   NEED_FINAL(s);
   double* p = factor_ptr(s, slot);
   if (!p || !h) return fail(s, SDPLR_ERR_INVALID_ARG, "get_factor: bad slot");
@@ -707,6 +735,7 @@ double* vec_ptr(S* s, int32_t which, int64_t* len, bool* in_ctrl) {
 
 extern "C" {
 int32_t sdplr_hip_set_vec(S* s, int32_t which, const double* h, int64_t len) {
+  ApiShared api_guard;
   NEED_FINAL(s);
   int64_t L; bool in_ctrl;
   double* p = vec_ptr(s, which, &L, &in_ctrl);
@@ -723,6 +752,7 @@ int32_t sdplr_hip_set_vec(S* s, int32_t which, const double* h, int64_t len) {
   return SDPLR_OK;
 }
 int32_t sdplr_hip_get_vec(S* s, int32_t which, double* h, int64_t len) {
+  ApiShared api_guard;
   NEED_FINAL(s);
   int64_t L; bool in_ctrl;
   double* p = vec_ptr(s, which, &L, &in_ctrl);
@@ -739,6 +769,7 @@ int32_t sdplr_hip_get_vec(S* s, int32_t which, double* h, int64_t len) {
   return SDPLR_OK;
 }
 int32_t sdplr_hip_set_scalar(S* s, int32_t which, double v) {
+  ApiShared api_guard;
   NEED_FINAL(s);
   int rc = pull(s);
   if (rc) return rc;
@@ -752,6 +783,7 @@ int32_t sdplr_hip_set_scalar(S* s, int32_t which, double v) {
   return push(s);
 }
 int32_t sdplr_hip_get_scalar(S* s, int32_t which, double* v) {
+  ApiShared api_guard;
   NEED_FINAL(s);
   if (!v) return fail(s, SDPLR_ERR_INVALID_ARG, "get_scalar: null");
   int rc = pull(s);
@@ -1145,6 +1177,7 @@ int run_lanczos(S* s, int64_t q, const double* v0, double* alpha, double* beta, 
 extern "C" {
 
 int32_t sdplr_hip_A(S* s, int32_t u_slot, int32_t v_slot, int32_t out_vec) {
+  ApiShared api_guard;
   NEED_FINAL(s);
   double* U = factor_ptr(s, u_slot);
   double* V = v_slot >= 0 ? factor_ptr(s, v_slot) : nullptr;
@@ -1155,11 +1188,13 @@ int32_t sdplr_hip_A(S* s, int32_t u_slot, int32_t v_slot, int32_t out_vec) {
   return sync_check(s);
 }
 int32_t sdplr_hip_At_preprocess(S* s) {
+  ApiShared api_guard;
   NEED_FINAL(s);
   enq_At_preprocess(s, 0);
   return sync_check(s);
 }
 int32_t sdplr_hip_At_left(S* s, int32_t ys, int32_t xs) {
+  ApiShared api_guard;
   NEED_FINAL(s);
   double *Y = factor_ptr(s, ys), *X = factor_ptr(s, xs);
   if (!Y || !X || Y == X) return fail(s, SDPLR_ERR_INVALID_ARG, "At_left: bad slots");
@@ -1168,6 +1203,7 @@ int32_t sdplr_hip_At_left(S* s, int32_t ys, int32_t xs) {
   return sync_check(s);
 }
 int32_t sdplr_hip_At_right(S* s, const double* x, double* yh, int64_t k) {
+  ApiShared api_guard;
   NEED_FINAL(s);
   if (!x || !yh || k < 1) return fail(s, SDPLR_ERR_INVALID_ARG, "At_right: bad args");
   const int64_t n = s->n;
@@ -1181,6 +1217,7 @@ int32_t sdplr_hip_At_right(S* s, const double* x, double* yh, int64_t k) {
 }
 
 int32_t sdplr_hip_f(S* s, double* L) {
+  ApiShared api_guard;
   NEED_FINAL(s);
   enq_f(s);
   int rc = pull(s);
@@ -1189,6 +1226,7 @@ int32_t sdplr_hip_f(S* s, double* L) {
   return sync_check(s);
 }
 int32_t sdplr_hip_g(S* s) {
+  ApiShared api_guard;
   NEED_FINAL(s);
   enq_g(s, 0, false);
   s->sg_stale = true;
@@ -1208,6 +1246,7 @@ int set_norm_params(S* s, double normC, double normb, int grel, int prel) {
 
 extern "C" {
 int32_t sdplr_hip_fg(S* s, double normC, double normb, int32_t grel, int32_t prel, double* L, double* gn, double* pn) {
+  ApiShared api_guard;
   NEED_FINAL(s);
   int rc = set_norm_params(s, normC, normb, grel, prel);
   if (rc) return rc;
@@ -1226,6 +1265,7 @@ int32_t sdplr_hip_fg(S* s, double normC, double normb, int32_t grel, int32_t pre
   return sync_check(s);
 }
 int32_t sdplr_hip_norms(S* s, double normC, double normb, int32_t grel, int32_t prel, double* gn, double* pn) {
+  ApiShared api_guard;
   NEED_FINAL(s);
   int rc = set_norm_params(s, normC, normb, grel, prel);
   if (rc) return rc;
@@ -1241,6 +1281,7 @@ int32_t sdplr_hip_norms(S* s, double normC, double normb, int32_t grel, int32_t 
   return sync_check(s);
 }
 int32_t sdplr_hip_axpy_R(S* s, double alpha) {
+  ApiShared api_guard;
   NEED_FINAL(s);
   int rc = pull(s);
   if (rc) return rc;
@@ -1250,6 +1291,7 @@ int32_t sdplr_hip_axpy_R(S* s, double alpha) {
   return sync_check(s);
 }
 int32_t sdplr_hip_update_lambda(S* s) {
+  ApiShared api_guard;
   NEED_FINAL(s);
   k_update_lambda<<<s->nb_m, SDPLR_NT, 0, s->stream>>>(s->ctrl, (int)s->m, s->lambda, s->lambda_ub, s->pv_raw);
   return sync_check(s);
@@ -1257,6 +1299,7 @@ int32_t sdplr_hip_update_lambda(S* s) {
 
 // ---- L-BFGS ------------------------------------------------------------------------------------------
 int32_t sdplr_hip_lbfgs_clear(S* s) {
+  ApiShared api_guard;
   NEED_FINAL(s);
   for (int j = 0; j < (int)s->h; j++) {
     HIPCK(s, hipMemsetAsync(aslot(s->arena, AS_S0 + j), 0, s->N * sizeof(double), s->stream));
@@ -1272,6 +1315,7 @@ int32_t sdplr_hip_lbfgs_clear(S* s) {
   return push(s);
 }
 int32_t sdplr_hip_lbfgs_dir(S* s, int32_t negate, double* descent) {
+  ApiShared api_guard;
   NEED_FINAL(s);
   ensure_gram(s);
   enq_lbfgs_dir(s, negate ? 1 : 0, 0, 0);
@@ -1282,12 +1326,14 @@ int32_t sdplr_hip_lbfgs_dir(S* s, int32_t negate, double* descent) {
   return sync_check(s);
 }
 int32_t sdplr_hip_descent_fallback(S* s) {
+  ApiShared api_guard;
   NEED_FINAL(s);
   k_neg_copy<<<s->nb_dense, SDPLR_NT, 0, s->stream>>>(aslot(s->arena, AS_G), aslot(s->arena, AS_D), s->N);
   s->sg_stale = true;
   return sync_check(s);
 }
 int32_t sdplr_hip_lbfgs_update(S* s, double stepsize) {
+  ApiShared api_guard;
   NEED_FINAL(s);
   if (s->h == 0) return SDPLR_OK;
   if (s->gram_dirty) {  // rows other than the updated one must be valid first
@@ -1325,10 +1371,12 @@ static int32_t linesearch_common(S* s, int armijo, double alpha_max, double* alp
   return sync_check(s);
 }
 int32_t sdplr_hip_linesearch(S* s, double alpha_max, double* alpha, double* L) {
+  ApiShared api_guard;
   NEED_FINAL(s);
   return linesearch_common(s, 0, alpha_max, alpha, L);
 }
 int32_t sdplr_hip_linesearch_armijo(S* s, double alpha_max, double* alpha, double* L) {
+  ApiShared api_guard;
   NEED_FINAL(s);
   return linesearch_common(s, 1, alpha_max, alpha, L);
 }
@@ -1338,6 +1386,7 @@ int32_t sdplr_hip_inner_loop(S* s, double normC, double normb, int32_t grel, int
                              double cur_gtol, double fprec_eps, int64_t max_local_iters, double time_budget_s,
                              double* Lio, double* gnio, double* pnio, double* last_alpha, int64_t* iters,
                              int32_t* exit_reason) {
+  std::shared_lock<std::shared_mutex> api_lock(g_api_rw);
   NEED_FINAL(s);
   if (!Lio || !gnio || !pnio || max_local_iters < 1) return fail(s, SDPLR_ERR_INVALID_ARG, "inner_loop: bad args");
   ensure_gram(s);
@@ -1365,15 +1414,32 @@ int32_t sdplr_hip_inner_loop(S* s, double normC, double normb, int32_t grel, int
     else enq_iteration(s, use_armijo);
   };
   if (fastp) enq_fast_refresh_P(s);
-  const bool use_graph = !s->prof_on && max_local_iters >= 4 && getenv("SDPLR_HIP_NO_GRAPH") == nullptr;
+  bool use_graph = !s->prof_on && !s->graph_disabled && max_local_iters >= 4 && getenv("SDPLR_HIP_NO_GRAPH") == nullptr;
   if (use_graph && !s->graph_exec[ar]) {
+    // Capture is fragile on ROCm 7.2 when OTHER host threads issue HIP calls meanwhile (observed: 8 handles
+    // driven by 8 threads → "operation failed due to a previous error during capture", any capture mode).
+    // So: one capture at a time, and a failed capture is not an error — this handle falls back to eager
+    // launches for good.
+    api_lock.unlock();
+    {
+    std::unique_lock<std::shared_mutex> excl(g_api_rw);
     hipGraph_t graph = nullptr;
-    HIPCK(s, hipStreamBeginCapture(s->stream, hipStreamCaptureModeThreadLocal));
-    for (int i = 0; i < s->graph_iters; i++) enq_iter();
-    HIPCK(s, hipStreamEndCapture(s->stream, &graph));
-    HIPCK(s, hipGraphInstantiate(&s->graph_exec[ar], graph, nullptr, nullptr, 0));
-    HIPCK(s, hipGraphDestroy(graph));
+    bool ok = hipStreamBeginCapture(s->stream, hipStreamCaptureModeRelaxed) == hipSuccess;
+    if (ok) {
+      for (int i = 0; i < s->graph_iters; i++) enq_iter();
+      ok = hipStreamEndCapture(s->stream, &graph) == hipSuccess && graph != nullptr;
+    }
+    if (ok) ok = hipGraphInstantiate(&s->graph_exec[ar], graph, nullptr, nullptr, 0) == hipSuccess;
+    if (graph) (void)hipGraphDestroy(graph);
+    if (!ok) {
+      (void)hipGetLastError();
+      s->graph_exec[ar] = nullptr;
+      s->graph_disabled = true;
+    }
+    }
+    api_lock.lock();
   }
+  if (s->graph_disabled) use_graph = false;
   const int64_t eager_batch = std::min<int64_t>(max_local_iters + 1, 8);
   const bool dbg = getenv("SDPLR_HIP_DEBUG") != nullptr;
   double t_enq = 0.0, t_wait = 0.0;
@@ -1457,6 +1523,7 @@ int32_t sdplr_hip_inner_loop(S* s, double normC, double normb, int32_t grel, int
 
 // ---- Lanczos / dual bound ------------------------------------------------------------------------------
 int32_t sdplr_hip_lanczos(S* s, int64_t q, const double* v0, double* alpha, double* beta, int64_t* steps) {
+  ApiShared api_guard;
   NEED_FINAL(s);
   if (!v0 || !alpha || !beta || !steps || q < 1) return fail(s, SDPLR_ERR_INVALID_ARG, "lanczos: bad args");
   return run_lanczos(s, q, v0, alpha, beta, steps);
@@ -1480,16 +1547,21 @@ int32_t sdplr_hip_tridiag_mineig(const double* alpha, const double* beta, int64_
   *out = 0.5 * (lo + hi) - 1;                                   // cancel the shift (:513)
   return SDPLR_OK;
 }
-int32_t sdplr_hip_approx_mineigval_lanczos(S* s, int64_t q, const double* v0, double* mineig) {
-  NEED_FINAL(s);
-  if (!v0 || !mineig || q < 1) return fail(s, SDPLR_ERR_INVALID_ARG, "approx_mineigval_lanczos: bad args");
+static int32_t approx_mineig_impl(S* s, int64_t q, const double* v0, double* mineig) {
   std::vector<double> al(q), be(q);
   int64_t steps = 0;
   int rc = run_lanczos(s, q, v0, al.data(), be.data(), &steps);
   if (rc) return rc;
   return sdplr_hip_tridiag_mineig(al.data(), be.data(), steps, mineig);
 }
+int32_t sdplr_hip_approx_mineigval_lanczos(S* s, int64_t q, const double* v0, double* mineig) {
+  ApiShared api_guard;
+  NEED_FINAL(s);
+  if (!v0 || !mineig || q < 1) return fail(s, SDPLR_ERR_INVALID_ARG, "approx_mineigval_lanczos: bad args");
+  return approx_mineig_impl(s, q, v0, mineig);
+}
 int32_t sdplr_hip_dual_obj(S* s, double trace_bound, int64_t iter, const double* v0, double* dual_value, double* mineig) {
+  ApiShared api_guard;
   NEED_FINAL(s);
   if (!v0) return fail(s, SDPLR_ERR_INVALID_ARG, "dual_obj: null v0");
   enq_copy2y(s, 0);              // src/coreop.jl:384
@@ -1497,7 +1569,7 @@ int32_t sdplr_hip_dual_obj(S* s, double trace_bound, int64_t iter, const double*
   const double it = (double)std::max<int64_t>(iter, 100);
   const int64_t eig_iter = (int64_t)(2 * std::ceil(std::pow(it, 0.5) * std::log((double)s->n)));  // :402
   double ev = 0.0;
-  int rc = sdplr_hip_approx_mineigval_lanczos(s, eig_iter, v0, &ev);
+  int rc = approx_mineig_impl(s, eig_iter, v0, &ev);
   if (rc) return rc;
   k_dot<<<s->nb_m, SDPLR_NT, 0, s->stream>>>((int)s->m, s->y, s->b, SLOT_DUALYB, s->partials);
   k_reduce_slot<<<1, SDPLR_NT, 0, s->stream>>>(&s->ctrl->descent, SLOT_DUALYB, s->nb_m, s->partials);
@@ -1510,6 +1582,7 @@ int32_t sdplr_hip_dual_obj(S* s, double trace_bound, int64_t iter, const double*
 
 // ---- profiling ---------------------------------------------------------------------------------------
 int32_t sdplr_hip_profile_enable(S* s, int32_t on) {
+  ApiShared api_guard;
   NEED_FINAL(s);
   prof_drain(s);
   for (auto& p : s->prof) p = ProfEntry();
@@ -1517,6 +1590,7 @@ int32_t sdplr_hip_profile_enable(S* s, int32_t on) {
   return SDPLR_OK;
 }
 int32_t sdplr_hip_profile_filter(S* s, const char* name) {
+  ApiShared api_guard;
   NEED_FINAL(s);
   s->prof_filter = name ? name : "";
   return SDPLR_OK;
@@ -1527,6 +1601,7 @@ int32_t sdplr_hip_profile_count(const S* s, int32_t* n_entries) {
   return SDPLR_OK;
 }
 int32_t sdplr_hip_profile_get(S* s, int32_t idx, char* name, int32_t cap, int64_t* launches, double* ms) {
+  ApiShared api_guard;
   NEED_FINAL(s);
   if (idx < 0 || idx >= (int32_t)s->prof_names.size()) return fail(s, SDPLR_ERR_INVALID_ARG, "profile_get: bad index");
   prof_drain(s);
