@@ -46,6 +46,9 @@ def algorithmic_bytes(d, h):
         "assemble_triu": 12 * nnzAgg + 8 * (m + 1) + 8 * nnzT,
         "assemble_full": 4 * nnzS + 8 * nnzT + 8 * nnzS,
         "spmm": 2 * N + 4 * (n + 1) + 12 * nnzS,
+        # structured fast path: W = A_g·D with the row dots riding along; the fused step
+        "spmm_W": 4 * N + 4 * (n + 1) + 12 * nnzS,    # D rows (once), R, P read; W written; A_g pattern+values
+        "fast_step": 7 * N,                            # R, D, P, W read; R, P, G written
     }
     b_iter = ((2 * h + 1) * N + 2 * N      # lbfgs_dir!
               + 2 * N                      # dot(dirt, Gt)

@@ -29,6 +29,9 @@ struct DevSparse {
   const int *short_ids, *chunk_beg, *chunk_end, *long_ids, *long_chunk_ptr;
   double *chunk_partial0, *chunk_partial1;
   double *UVt0, *UVt1;
+  // rows of the full pattern with more than long_thresh nonzeros (hub vertices): one block each (k_spmm_long)
+  int n_long_rows, long_thresh;
+  const int* long_rows;
 };
 
 struct DevLowRank {
@@ -207,6 +210,7 @@ k_spmm(DevSparse sp, const double* __restrict__ X, double* __restrict__ Y, int r
   double nrm = 0.0;
   for (long long j = (long long)blockIdx.x * G + threadIdx.x / LPR; j < sp.n; j += total) {
     const int beg = sp.colptr[j], end = sp.colptr[j + 1];
+    if (sp.n_long_rows > 0 && end - beg > sp.long_thresh) continue;  // hub row: k_spmm_long
     for (int ch = lane * VEC; ch < r; ch += LPR * VEC) {
       vecd<VEC> acc;
 #pragma unroll
@@ -272,6 +276,7 @@ k_spmv(DevSparse sp, const double* __restrict__ x, double* __restrict__ y, DevLo
   const long long total = (long long)gridDim.x * G;
   double dot = 0.0;
   for (long long j = (long long)blockIdx.x * G + threadIdx.x / LPR; j < sp.n; j += total) {
+    if (sp.n_long_rows > 0 && sp.colptr[j + 1] - sp.colptr[j] > sp.long_thresh) continue;  // k_spmv_long
     double t = 0.0;
     for (int p = sp.colptr[j] + lane; p < sp.colptr[j + 1]; p += LPR) t += sp.nzval[p] * x[sp.rowval[p]];
     t = group_sum<LPR>(t);
@@ -289,7 +294,8 @@ k_spmv(DevSparse sp, const double* __restrict__ x, double* __restrict__ y, DevLo
 
 // ---- low-rank projections W[f][c][k] = Σ_i B[c][i]·X_f[i][k] -------------------------------------------
 // `Ut * A.B` of tr_UtAU / tr_UtAV (src/coreop.jl:116,125-126) and `X * A.B` of mul! (src/structs.jl:142),
-// for up to two factors in one pass.  Per-block partials lr_part[((blk*F + f)*ST + c)*r + k].
+// for up to two factors in one pass.  Per-block partials lr_part[(((f*ST + c)*r + k)*gridDim.x + blk]
+// (block index fastest, so that the finalize kernel reads each output's partials contiguously).
 template <int LPR, int VEC, int F>
 __global__ void __launch_bounds__(SDPLR_NT)
 k_lr_project(DevLowRank lr, const double* __restrict__ X0, const double* __restrict__ X1, int n, int r,
@@ -334,7 +340,7 @@ k_lr_project(DevLowRank lr, const double* __restrict__ X0, const double* __restr
           if (chb + k < r) {
             double s = 0.0;
             for (int gg = 0; gg < G; gg++) s += sh[(gg * SDPLR_LRMAX + cc) * (LPR * VEC) + k];
-            lr_part[(((long long)blockIdx.x * F + f) * lr.ST + c0 + cc) * r + chb + k] = s;
+            lr_part[((((long long)f * lr.ST + c0 + cc) * r + chb + k)) * gridDim.x + blockIdx.x] = s;
           }
         }
       }
@@ -347,27 +353,32 @@ k_lr_project(DevLowRank lr, const double* __restrict__ X0, const double* __restr
 //  mode 1: out0[gid_t] = Σ_c D_c Σ_k W0·W1          tr_UtAV, src/coreop.jl:122-130   (F = 2)
 //  mode 2: out0[gid_t] = 2·Σ D W0·W1 ; out1[gid_t] = Σ D W1²   line search (src/linesearch.jl:10-16)
 //  mode 3: WS[c][k] = yvec[gid_c]·D_c·W0[c][k]      mul!(Y, X, A, α, β), src/structs.jl:142-144
-__global__ void __launch_bounds__(SDPLR_NT)
+__global__ void __launch_bounds__(1024)
 k_lr_finalize(DevLowRank lr, int r, int F, int nb, const double* __restrict__ lr_part, double* __restrict__ W,
               int mode, double* __restrict__ out0, double* __restrict__ out1, const double* __restrict__ yvec,
               double* __restrict__ WS, const DevCtrl* __restrict__ c, int check_done) {
   if (check_done && c->done) return;
   const int per = lr.ST * r;
-  for (int t = threadIdx.x; t < F * per; t += SDPLR_NT) {
-    const int f = t / per, ck = t % per;
-    double s = 0.0;
-    for (int b = 0; b < nb; b++) s += lr_part[((long long)b * F + f) * per + ck];
-    W[t] = s;
+  const int nout = F * per;
+  {  // one wave per output: lanes stride the nb contiguous per-block partials, fixed-order butterfly
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+    for (int t = wave; t < nout; t += nw) {
+      const double* p = lr_part + (long long)t * nb;
+      double s = 0.0;
+      for (int b = lane; b < nb; b += 64) s += p[b];
+      s = wave_sum(s);
+      if (lane == 0) W[t] = s;
+    }
   }
   __syncthreads();
   if (mode == 3) {
-    for (int t = threadIdx.x; t < per; t += SDPLR_NT) {
+    for (int t = threadIdx.x; t < per; t += blockDim.x) {
       const int cc = t / r;
       WS[t] = yvec[lr.col_gid[cc]] * lr.Dcat[cc] * W[t];
     }
     return;
   }
-  for (int t = threadIdx.x; t < lr.n_lr; t += SDPLR_NT) {
+  for (int t = threadIdx.x; t < lr.n_lr; t += blockDim.x) {
     double s0 = 0.0, s1 = 0.0;
     for (int cc = lr.mat_ptr[t]; cc < lr.mat_ptr[t + 1]; cc++) {
       double d0 = 0.0, d1 = 0.0;
@@ -939,4 +950,110 @@ k_fast_step_update(int n, int m, DevFast ff, FactorArena A, int slotP, int slotW
       c->nb_pvnorm = gridDim.x;
     }
   }
+}
+
+// ---- hub rows: one block per row of the full pattern with more than long_thresh nonzeros ------------------
+// Same result as k_spmm for those rows (which k_spmm skips): the row's nonzeros are dealt round-robin to the
+// block's sub-wave groups, the group partials are added in group order (deterministic).  Partials of the
+// norm / dot go to slot entries [pbase, pbase + n_long_rows).
+template <int LPR, int VEC>
+__global__ void __launch_bounds__(SDPLR_NT)
+k_spmm_long(DevSparse sp, const double* __restrict__ X, double* __restrict__ Y, int r, double scale,
+            DevLowRank lr, const double* __restrict__ WS, int slot, int pbase, double* __restrict__ partials,
+            const DevCtrl* __restrict__ c, int check_done, const double* __restrict__ Xdot) {
+  __shared__ double shg[SDPLR_NT * VEC];
+  __shared__ double sh[8];
+  if (check_done && c->done) return;
+  constexpr int G = SDPLR_NT / LPR;
+  const int lane = threadIdx.x % LPR, g = threadIdx.x / LPR;
+  double nrm = 0.0;
+  for (int lrow = blockIdx.x; lrow < sp.n_long_rows; lrow += gridDim.x) {
+  const long long j = sp.long_rows[lrow];
+  const int beg = sp.colptr[j], end = sp.colptr[j + 1];
+  for (int chb = 0; chb < r; chb += LPR * VEC) {
+    const int ch = chb + lane * VEC;
+    vecd<VEC> acc;
+#pragma unroll
+    for (int k = 0; k < VEC; k++) acc.v[k] = 0.0;
+    if (ch < r) {
+      int p = beg + g;
+      for (; p + 3 * G < end; p += 4 * G) {  // four independent row gathers in flight per group
+        const long long i0 = sp.rowval[p], i1 = sp.rowval[p + G], i2 = sp.rowval[p + 2 * G], i3 = sp.rowval[p + 3 * G];
+        const double v0 = sp.nzval[p], v1 = sp.nzval[p + G], v2 = sp.nzval[p + 2 * G], v3 = sp.nzval[p + 3 * G];
+        const vecd<VEC> x0 = ldrow<VEC>(X + i0 * r + ch), x1 = ldrow<VEC>(X + i1 * r + ch);
+        const vecd<VEC> x2 = ldrow<VEC>(X + i2 * r + ch), x3 = ldrow<VEC>(X + i3 * r + ch);
+#pragma unroll
+        for (int k = 0; k < VEC; k++) {
+          acc.v[k] += x0.v[k] * v0;
+          acc.v[k] += x1.v[k] * v1;
+          acc.v[k] += x2.v[k] * v2;
+          acc.v[k] += x3.v[k] * v3;
+        }
+      }
+      for (; p < end; p += G) {
+        const long long i = sp.rowval[p];
+        const double v = sp.nzval[p];
+        const vecd<VEC> x = ldrow<VEC>(X + i * r + ch);
+#pragma unroll
+        for (int k = 0; k < VEC; k++) acc.v[k] += x.v[k] * v;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < VEC; k++) shg[(g * LPR + lane) * VEC + k] = acc.v[k];
+    __syncthreads();
+    if (g == 0 && ch < r) {
+      vecd<VEC> tot;
+#pragma unroll
+      for (int k = 0; k < VEC; k++) tot.v[k] = 0.0;
+      for (int gg = 0; gg < G; gg++)
+#pragma unroll
+        for (int k = 0; k < VEC; k++) tot.v[k] += shg[(gg * LPR + lane) * VEC + k];
+      for (int cc = 0; cc < lr.ST; cc++) {
+        const double b = lr.Bcat[(long long)cc * sp.n + j];
+        const vecd<VEC> w = ldrow<VEC>(WS + (long long)cc * r + ch);
+#pragma unroll
+        for (int k = 0; k < VEC; k++) tot.v[k] += w.v[k] * b;
+      }
+#pragma unroll
+      for (int k = 0; k < VEC; k++) tot.v[k] *= scale;
+      if (Xdot) {
+        const vecd<VEC> xd = ldrow<VEC>(Xdot + j * r + ch);
+#pragma unroll
+        for (int k = 0; k < VEC; k++) nrm += tot.v[k] * xd.v[k];
+      } else {
+#pragma unroll
+        for (int k = 0; k < VEC; k++) nrm += tot.v[k] * tot.v[k];
+      }
+      strow<VEC>(Y + j * r + ch, tot);
+    }
+  }
+  }
+  if (slot >= 0) {
+    nrm = block_sum1(nrm, sh);
+    if (threadIdx.x == 0) slot_partials(partials, slot)[pbase + blockIdx.x] = nrm;
+  }
+}
+
+// hub rows of the SpMV: one block per row, 256 lanes stride the row
+__global__ void __launch_bounds__(SDPLR_NT)
+k_spmv_long(DevSparse sp, const double* __restrict__ x, double* __restrict__ y, DevLowRank lr,
+            const double* __restrict__ coef, int slot, int pbase, double* __restrict__ partials,
+            const int* __restrict__ stop_flag) {
+  __shared__ double sh[8];
+  if (stop_flag && *stop_flag) return;
+  double dot = 0.0;
+  for (int lrow = blockIdx.x; lrow < sp.n_long_rows; lrow += gridDim.x) {
+    const long long j = sp.long_rows[lrow];
+    double t = 0.0;
+    for (int p = sp.colptr[j] + threadIdx.x; p < sp.colptr[j + 1]; p += SDPLR_NT) t += sp.nzval[p] * x[sp.rowval[p]];
+    __syncthreads();
+    t = block_sum1(t, sh);
+    if (threadIdx.x == 0) {
+      for (int cc = 0; cc < lr.ST; cc++) t += coef[cc] * lr.Bcat[(long long)cc * sp.n + j];
+      y[j] = t;
+      dot += x[j] * t;
+    }
+  }
+  if (slot >= 0 && threadIdx.x == 0) slot_partials(partials, slot)[pbase + blockIdx.x] = dot;
 }

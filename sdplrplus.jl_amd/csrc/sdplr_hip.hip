@@ -279,7 +279,7 @@ int alloc_factors(S* s) {
   s->nb_upd = std::min(s->nb_dense, 512);
   if (const char* e = getenv("SDPLR_HIP_NB_UPD")) s->nb_upd = std::max(1, std::min(atoi(e), SDPLR_MAXNB));
   s->nb_sddmm = blocks_for(s->nnzT, G, 8192);
-  s->nb_spmm = blocks_for(s->n, G, SDPLR_MAXNB);
+  s->nb_spmm = blocks_for(s->n, G, SDPLR_MAXNB - 256);  // + up to 256 hub-row blocks share the partial slot
   return SDPLR_OK;
 }
 
@@ -456,6 +456,19 @@ int32_t sdplr_hip_finalize(S* s) {
   UP(short_ids, short_ids); UP(chunk_beg, chunk_beg); UP(chunk_end, chunk_end);
   UP(long_ids, long_ids); UP(long_chunk_ptr, long_chunk_ptr);
 #undef UP
+  // hub rows (power-law graphs): rows of the full pattern far longer than the rest get a block each
+  auto plan_long = [&](const std::vector<int>& ptr, DevSparse& dst) -> int {
+    std::vector<int> deg(n);
+    for (int64_t j = 0; j < n; j++) deg[j] = ptr[j + 1] - ptr[j];
+    const int thresh = 64;   // ≈ 3× the mean degree of the G(n,p) configurations: none of their rows qualify
+    std::vector<int> rows;
+    for (int64_t j = 0; j < n; j++)
+      if (deg[j] > thresh) rows.push_back((int)j);
+    dst.n_long_rows = (int)rows.size();
+    dst.long_thresh = thresh;
+    return upload(s, &dst.long_rows, rows);
+  };
+  if ((rc = plan_long(s->h_fcp, sp))) return rc;
   if ((rc = dzero(s, &sp.nzval, s->nnzS))) return rc;
   if ((rc = dzero(s, &sp.triu_nzval, s->nnzT))) return rc;
   if ((rc = dzero(s, &sp.UVt0, s->nnzT))) return rc;
@@ -597,6 +610,7 @@ int32_t sdplr_hip_finalize(S* s) {
       DevSparse& sg = s->spg;
       sg = DevSparse{};
       sg.n = (int)n; sg.nnzS = (int)g_col.size();
+      if ((rc = plan_long(g_ptr, sg))) return rc;
       if ((rc = upload(s, &sg.colptr, g_ptr))) return rc;
       if ((rc = upload(s, &sg.rowval, g_col))) return rc;
       { const double* gv = nullptr; if ((rc = upload(s, &gv, g_val))) return rc; sg.nzval = const_cast<double*>(gv); }
@@ -613,12 +627,12 @@ int32_t sdplr_hip_finalize(S* s) {
       for (auto& L : s->h_lr) extra.push_back((int)L.gid);
       if ((rc = upload(s, &s->extra_slots, extra))) return rc;
       s->n_extra = (int)extra.size();
-      s->fast_singleton = single && getenv("SDPLR_HIP_NO_FAST2") == nullptr;
+      s->fast_singleton = single && s->spg.n_long_rows == 0 && getenv("SDPLR_HIP_NO_FAST2") == nullptr;
     }
   }
   if ((rc = alloc_factors(s))) return rc;
   s->nb_m = blocks_for(m + 1, SDPLR_NT, 256);
-  s->nb_spmv = blocks_for(n, SDPLR_NT / 8, SDPLR_MAXNB);
+  s->nb_spmv = blocks_for(n, SDPLR_NT / 8, SDPLR_MAXNB - 256);
   s->nb_nnzT = blocks_for(s->nnzT, SDPLR_NT, 4096);
   s->nb_nnzS = blocks_for(s->nnzS, SDPLR_NT, 4096);
   s->nb_n = blocks_for(n, SDPLR_NT, SDPLR_MAXNB);
@@ -832,7 +846,7 @@ void enq_lowrank(S* s, const double* X0, const double* X1, int F, int mode, doub
     else { LV_DISPATCH((k_lr_project<LPR, VEC, 2><<<s->nb_lr, SDPLR_NT, 0, s->stream>>>(s->lr, X0, X1, (int)s->n, (int)s->r, s->lr_part, s->ctrl, chk))) }
   }
   ProfScope ps(s, "lr_finalize");
-  k_lr_finalize<<<1, SDPLR_NT, 0, s->stream>>>(s->lr, (int)s->r, F, s->nb_lr, s->lr_part, s->lr_W, mode, out0, out1, s->y, s->lr_WS, s->ctrl, chk);
+  k_lr_finalize<<<1, 1024, 0, s->stream>>>(s->lr, (int)s->r, F, s->nb_lr, s->lr_part, s->lr_W, mode, out0, out1, s->y, s->lr_WS, s->ctrl, chk);
 }
 
 // mode 0: out0 = 𝒜(UUᵀ); mode 1: out0 = 𝒜((UVᵀ+VUᵀ)/2); mode 2: out0 = 2·𝒜((UVᵀ+VUᵀ)/2), out1 = 𝒜(VVᵀ)
@@ -880,6 +894,9 @@ void enq_At_left(S* s, double* Y, const double* X, double scale, int slot, int c
   enq_lowrank(s, X, X, 1, 3, nullptr, nullptr, chk);
   ProfScope ps(s, "spmm");
   LV_DISPATCH((k_spmm<LPR, VEC><<<s->nb_spmm, SDPLR_NT, 0, s->stream>>>(s->sp, X, Y, (int)s->r, scale, s->lr, s->lr_WS, slot, s->partials, s->ctrl, chk)))
+  if (s->sp.n_long_rows > 0) {
+    LV_DISPATCH((k_spmm_long<LPR, VEC><<<std::min(s->sp.n_long_rows, 256), SDPLR_NT, 0, s->stream>>>(s->sp, X, Y, (int)s->r, scale, s->lr, s->lr_WS, slot, s->nb_spmm, s->partials, s->ctrl, chk, nullptr)))
+  }
 }
 
 void enq_copy2y(S* s, int chk) {
@@ -969,7 +986,7 @@ void enq_linesearch(S* s, int armijo, int chk, int fuse_y) {
     k_ls_solve<<<1, SDPLR_NT, 0, s->stream>>>(s->ctrl, (int)s->m, s->nb_m, s->A_RD, s->A_DD, s->partials, chk, fuse_y);
   }
   ProfScope ps(s, "ls_commit");
-  k_ls_commit<<<s->nb_m, SDPLR_NT, 0, s->stream>>>(s->ctrl, (int)s->m, s->pv_raw, s->A_RD, s->A_DD, s->pv_lb, s->pv, fuse_y, s->y, s->lambda, s->lambda_ub, s->partials, chk, fuse_y, s->nb_spmm);
+  k_ls_commit<<<s->nb_m, SDPLR_NT, 0, s->stream>>>(s->ctrl, (int)s->m, s->pv_raw, s->A_RD, s->A_DD, s->pv_lb, s->pv, fuse_y, s->y, s->lambda, s->lambda_ub, s->partials, chk, fuse_y, s->nb_spmm + std::min(s->sp.n_long_rows, 256));
 }
 
 void enq_axpy_R(S* s, int chk) {
@@ -996,6 +1013,9 @@ void enq_fast_refresh_P(S* s) {
   ProfScope ps(s, "spmm_P");
   DevLowRank none{};
   LV_DISPATCH((k_spmm<LPR, VEC><<<s->nb_spmm, SDPLR_NT, 0, s->stream>>>(s->spg, aslot(s->arena, AS_R), fast_P(s), (int)s->r, 1.0, none, nullptr, -1, s->partials, s->ctrl, 0)))
+  if (s->spg.n_long_rows > 0) {
+    LV_DISPATCH((k_spmm_long<LPR, VEC><<<std::min(s->spg.n_long_rows, 256), SDPLR_NT, 0, s->stream>>>(s->spg, aslot(s->arena, AS_R), fast_P(s), (int)s->r, 1.0, none, nullptr, -1, 0, s->partials, s->ctrl, 0, nullptr)))
+  }
 }
 
 // one pass of the while body, src/sdplr.jl:190-278, with ONE gather pass (W = A_g·D)
@@ -1016,6 +1036,9 @@ void enq_iteration_fast(S* s, int armijo) {
     ProfScope ps(s, "spmm_W");
     DevLowRank none{};
     LV_DISPATCH((k_spmm<LPR, VEC><<<s->nb_spmm, SDPLR_NT, 0, s->stream>>>(s->spg, D, W, (int)s->r, 1.0, none, nullptr, SLOT_DW, s->partials, s->ctrl, 1, D)))
+    if (s->spg.n_long_rows > 0) {
+      LV_DISPATCH((k_spmm_long<LPR, VEC><<<std::min(s->spg.n_long_rows, 256), SDPLR_NT, 0, s->stream>>>(s->spg, D, W, (int)s->r, 1.0, none, nullptr, SLOT_DW, s->nb_spmm, s->partials, s->ctrl, 1, D)))
+    }
   }
   {
     const int nb = s->sp_fast.n_short_blocks + s->sp_fast.n_chunks;
@@ -1031,7 +1054,7 @@ void enq_iteration_fast(S* s, int armijo) {
   }
   {
     ProfScope ps(s, "fast_fill");
-    k_fast_fill<<<1, SDPLR_NT, 0, s->stream>>>(s->ff, s->A_RD, s->A_DD, SLOT_PD, s->nb_spmm, SLOT_DW, s->nb_spmm, s->partials, s->ctrl, 1);
+    k_fast_fill<<<1, SDPLR_NT, 0, s->stream>>>(s->ff, s->A_RD, s->A_DD, SLOT_PD, s->nb_spmm, SLOT_DW, s->nb_spmm + std::min(s->spg.n_long_rows, 256), s->partials, s->ctrl, 1);
   }
   enq_lowrank(s, R, D, 2, 2, s->A_RD, s->A_DD, 1);
   // ---- scalar stage + commit (with y of the following g!) ----
@@ -1129,6 +1152,8 @@ void enq_spmv(S* s, const double* x, double* yv, int slot, const int* stop_flag)
   }
   ProfScope ps(s, "spmv");
   k_spmv<<<s->nb_spmv, SDPLR_NT, 0, s->stream>>>(s->sp, x, yv, s->lr, s->lr_coef, slot, s->partials, stop_flag);
+  if (s->sp.n_long_rows > 0)
+    k_spmv_long<<<std::min(s->sp.n_long_rows, 256), SDPLR_NT, 0, s->stream>>>(s->sp, x, yv, s->lr, s->lr_coef, slot, s->nb_spmv, s->partials, stop_flag);
 }
 
 int run_lanczos(S* s, int64_t q, const double* v0, double* alpha, double* beta, int64_t* steps) {
@@ -1155,7 +1180,7 @@ int run_lanczos(S* s, int64_t q, const double* v0, double* alpha, double* beta, 
     enq_spmv(s, v, Av, SLOT_LZ_A, stop);                                  // :483
     {
       ProfScope ps(s, "lanczos_update");
-      k_lz_update1<<<s->nb_n, SDPLR_NT, 0, s->stream>>>(s->ctrl, (int)n, (int)i, v, Av, vpre, s->lz_alpha, s->nb_spmv, s->partials);
+      k_lz_update1<<<s->nb_n, SDPLR_NT, 0, s->stream>>>(s->ctrl, (int)n, (int)i, v, Av, vpre, s->lz_alpha, s->nb_spmv + std::min(s->sp.n_long_rows, 256), s->partials);
       k_lz_update2<<<s->nb_n, SDPLR_NT, 0, s->stream>>>(s->ctrl, (int)n, (int)i, Av, s->lz_beta, s->nb_n, s->partials);
     }
     double* t = vpre;  // copyto!(v_pre, v); copyto!(v, Av)  (:498-499) as a pointer rotation
@@ -1255,7 +1280,7 @@ int32_t sdplr_hip_fg(S* s, double normC, double normb, int32_t grel, int32_t pre
   {
     ProfScope ps(s, "pv_norm");  // src/coreop.jl:340-347
     k_pv_norm<<<s->nb_m, SDPLR_NT, 0, s->stream>>>((int)s->m, s->pv_raw, s->pv_lb, s->pv, 1, s->partials);
-    k_norms<<<1, SDPLR_NT, 0, s->stream>>>(s->ctrl, s->nb_spmm, s->nb_m, 0, 0, s->partials);
+    k_norms<<<1, SDPLR_NT, 0, s->stream>>>(s->ctrl, s->nb_spmm + std::min(s->sp.n_long_rows, 256), s->nb_m, 0, 0, s->partials);
   }
   s->sg_stale = true;
   if ((rc = pull(s))) return rc;

@@ -367,3 +367,23 @@ def test_config5_gset_batch_slice(hip_abi):
         assert dual <= obj + 1e-6 * abs(obj)
         # best known cuts of G1/G2 are 11624/11620 and the SDP bound is ≈ 12083/12089: −obj lies in between ±1 %
         assert 11600 * 0.99 <= -obj <= 12100 * 1.01
+
+
+def test_concurrent_handles_match_serial(hip_abi):
+    """Different handles driven from different host threads (SURVEY §8b 'Threading'): 24 full MaxCut solves,
+    8 in flight, must reproduce the serial results bit for bit (regression: a legacy-stream zero-fill used to
+    race with the factor upload on the solver's own stream; hipGraph capture used to break other threads)."""
+    from concurrent.futures import ThreadPoolExecutor
+    datas = [problems.maxcut_data(problems.gnp_graph(300, 0.1, 200 + k)) for k in range(24)]
+
+    def one(k):
+        res = sj.sdplr(data=datas[k], r=8, printlevel=0, ptol=0.01, objtol=0.01, seed=0,
+                       prior_trace_bound=300.0, maxmajoriter=60)
+        return res["obj"], res["iter"], res["majoriter"]
+
+    serial = [one(k) for k in range(24)]
+    with ThreadPoolExecutor(max_workers=8) as ex:
+        threaded = list(ex.map(one, range(24)))
+    assert all(o < -100 for o, _, _ in serial)
+    # Lanczos start vectors are drawn per solve from the same seed ⇒ identical trajectories
+    assert threaded == serial
