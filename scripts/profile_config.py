@@ -25,7 +25,8 @@ for k, (c, ms) in sorted(p.items(), key=lambda kv: -kv[1][1]):
     print(f"{k:20s} {1e3*ms/40:8.1f} us/iter  ({c/40:.2f} launches/iter)")
     tot += 1e3 * ms / 40
 print("sum", tot, "dims", var.dims())
-if which == "minbis":
+if which in ("minbis", "maxcut", "lovasz"):
+    var.dual_obj(float(data.n), 0, np.ones(data.n))
     var.profile_enable(True)
     v0 = np.random.Generator(np.random.PCG64(5)).standard_normal(data.n)
     var.lanczos(232, v0)

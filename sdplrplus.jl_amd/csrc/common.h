@@ -16,7 +16,7 @@
 
 #define SDPLR_HMAX 16          // largest numlbfgsvecs supported by the fused L-BFGS kernels
 #define SDPLR_NT 256           // threads per block for every kernel (4 waves)
-#define SDPLR_MAXNB 1024       // largest grid of a partial-producing kernel
+#define SDPLR_MAXNB 4096       // largest grid of a partial-producing kernel (width of a partial slot)
 #define SDPLR_NSLOT 160        // reduction slots in the partials buffer
 #define SDPLR_LRMAX 8          // low-rank columns handled per register pass
 
@@ -50,6 +50,8 @@ struct DevCtrl {
   int lz_done;
   long long lz_steps;
   double lz_beta_prev;
+  double lz_gamma_cur, lz_gamma_prev;  // norms of the current / previous unnormalised Lanczos vectors
+  long long lz_qmax;
   // ---- L-BFGS (src/lbfgs.jl:4-28) ----
   int latest;          // 1-based, as in the reference
   int gram_pending;    // set by k_lbfgs_update, consumed by k_lbfgs_boundary
@@ -126,6 +128,7 @@ enum {
   SLOT_LZ_B = 10,     // Lanczos ‖Av‖²
   SLOT_V0 = 11,       // ‖v0‖²
   SLOT_DUALYB = 12,   // ⟨y[1:m], b⟩
+  SLOT_LZ_N = 15,     // Lanczos ‖u‖² of the vector about to be multiplied
   SLOT_PD = 13,       // ⟨P, D⟩ (structured fast path)
   SLOT_DW = 14,       // ⟨D, W⟩
   SLOT_GRAM = 16,     // 16 .. 16+5*HMAX-1: partials of lbfgs_update (see k_dense.h)

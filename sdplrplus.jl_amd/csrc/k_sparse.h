@@ -1057,3 +1057,103 @@ k_spmv_long(DevSparse sp, const double* __restrict__ x, double* __restrict__ y, 
   }
   if (slot >= 0 && threadIdx.x == 0) slot_partials(partials, slot)[pbase + blockIdx.x] = dot;
 }
+
+// ================================================================================================
+// Lanczos recurrence (src/coreop.jl:481-500) on UNNORMALISED vectors, two kernels per step.
+//   u_1 = v0, γ_1 = ‖v0‖;  u_{i+1} = r_i = S·v_i − α_i v_i − β_{i−1} v_{i−1},  γ_{i+1} = β_i = ‖r_i‖,  v_i = u_i/γ_i.
+//   K1 k_lz_spmv: t = S·u_i (+ low-rank), partials of u_i·t;  its block 0 first closes the previous step:
+//      γ_i from the ‖u_i‖² partials, beta[i−1] = γ_i, the break test |β| < √n·eps (:494-496), the q-step cap.
+//   K2 k_lz_step: α_i = (u_i·t)/γ_i², r_i = t/γ_i − (α_i·u_i/γ_i + β_{i−1}·u_{i−1}/γ_{i−1}) written over t,
+//      partials of ‖r_i‖² and of ⟨B_c, r_i⟩ for the next K1's low-rank term.
+// Normalising lazily removes one grid-wide dependency per step (three kernels → two) and the kernels carry
+// no step index, so three steps (one rotation of the three vector buffers) replay as a hipGraph.
+// ================================================================================================
+template <int LPR>
+__global__ void __launch_bounds__(SDPLR_NT)
+k_lz_spmv(DevSparse sp, DevCtrl* __restrict__ c, const double* __restrict__ u, double* __restrict__ t,
+          DevLowRank lr, const double* __restrict__ yvec, const double* __restrict__ btx_part, int nb_prev,
+          double* __restrict__ coef_out, double* __restrict__ beta_out, double* __restrict__ partials) {
+  __shared__ double sh[8];
+  __shared__ double coef[SDPLR_LRMAX * 8];
+  if (c->lz_done) return;
+  for (int cc = 0; cc < lr.ST; cc++) {  // low-rank coefficients y[gid]·D_c·⟨B_c, u⟩ (src/structs.jl:117-127)
+    const double sidx = reduce_partials(btx_part + (long long)cc * nb_prev, nb_prev, sh);
+    if (threadIdx.x == 0) {
+      const double cf = yvec[lr.col_gid[cc]] * lr.Dcat[cc] * sidx;
+      if (cc < SDPLR_LRMAX * 8) coef[cc] = cf;
+      if (blockIdx.x == 0) coef_out[cc] = cf;
+    }
+    __syncthreads();
+  }
+  if (blockIdx.x == 0) {  // close the previous step (see header)
+    const double nn = reduce_partials(slot_partials(partials, SLOT_LZ_N), nb_prev, sh);
+    if (threadIdx.x == 0) {
+      const double g = sqrt(nn);
+      const long long st = c->lz_steps;
+      if (st > 0) {
+        beta_out[st - 1] = g;                                                  // beta[i] = ‖Av‖  (:492)
+        if (fabs(g) < sqrt((double)sp.n) * 2.220446049250313e-16) c->lz_done = 1;   // (:494-496)
+      }
+      if (st >= c->lz_qmax) c->lz_done = 1;
+      c->lz_gamma_prev = c->lz_gamma_cur;
+      c->lz_gamma_cur = g;
+      c->lz_beta_prev = (st > 0) ? g : 0.0;
+    }
+  }
+  constexpr int G = SDPLR_NT / LPR;
+  const int lane = threadIdx.x % LPR;
+  const long long total = (long long)gridDim.x * G;
+  double dot = 0.0;
+  for (long long j = (long long)blockIdx.x * G + threadIdx.x / LPR; j < sp.n; j += total) {
+    if (sp.n_long_rows > 0 && sp.colptr[j + 1] - sp.colptr[j] > sp.long_thresh) continue;
+    double tj = 0.0;
+    for (int p = sp.colptr[j] + lane; p < sp.colptr[j + 1]; p += LPR) tj += sp.nzval[p] * u[sp.rowval[p]];
+    tj = group_sum<LPR>(tj);
+    if (lane == 0) {
+      for (int cc = 0; cc < lr.ST; cc++) tj += coef[cc] * lr.Bcat[(long long)cc * sp.n + j];
+      t[j] = tj;
+      dot += u[j] * tj;
+    }
+  }
+  dot = block_sum1(dot, sh);
+  if (threadIdx.x == 0) slot_partials(partials, SLOT_LZ_A)[blockIdx.x] = dot;
+}
+
+__global__ void __launch_bounds__(SDPLR_NT)
+k_lz_step(int n, DevCtrl* __restrict__ c, const double* __restrict__ uprev, const double* __restrict__ u,
+          double* __restrict__ t, DevLowRank lr, double* __restrict__ btx_part, int nb_a,
+          double* __restrict__ alpha_out, double* __restrict__ partials) {
+  __shared__ double sh[8];
+  if (c->lz_done) return;
+  const double gi = c->lz_gamma_cur, gp = c->lz_gamma_prev, be = c->lz_beta_prev;
+  const double al = reduce_partials(slot_partials(partials, SLOT_LZ_A), nb_a, sh) / (gi * gi);  // v'·Av (:484)
+  double nrm = 0.0;
+  double bt[SDPLR_LRMAX];
+#pragma unroll
+  for (int cc = 0; cc < SDPLR_LRMAX; cc++) bt[cc] = 0.0;
+  const int stride = gridDim.x * SDPLR_NT;
+  for (int k = blockIdx.x * SDPLR_NT + threadIdx.x; k < n; k += stride) {
+    const double vi = u[k] / gi, avk = t[k] / gi, vp = uprev[k] / gp;
+    const double r = avk - (al * vi + be * vp);                 // (:486-490)
+    t[k] = r;
+    nrm += r * r;
+#pragma unroll
+    for (int cc = 0; cc < SDPLR_LRMAX; cc++)
+      if (cc < lr.ST) bt[cc] += lr.Bcat[(long long)cc * n + k] * r;
+  }
+  __syncthreads();
+  nrm = block_sum1(nrm, sh);
+  if (threadIdx.x == 0) slot_partials(partials, SLOT_LZ_N)[blockIdx.x] = nrm;
+#pragma unroll
+  for (int cc = 0; cc < SDPLR_LRMAX; cc++)
+    if (cc < lr.ST) {
+      __syncthreads();
+      const double v = block_sum1(bt[cc], sh);
+      if (threadIdx.x == 0) btx_part[(long long)cc * gridDim.x + blockIdx.x] = v;
+    }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    const long long st = c->lz_steps;
+    alpha_out[st] = al;
+    c->lz_steps = st + 1;                                       // iter += 1 (:482)
+  }
+}

@@ -89,6 +89,7 @@ struct sdplr_hip_solver {
 
   // kernel shapes
   int LPR = 1, VEC = 1, HM = 4;
+  int nb_lzv = 1;  // grid of k_lz_spmv
   int nb_upd = 1;  // grid of k_lbfgs_update (its per-block partials are folded by one block)
   int nb_dense = 1, nb_m = 1, nb_sddmm = 1, nb_spmm = 1, nb_spmv = 1, nb_nnzT = 1, nb_nnzS = 1, nb_n = 1;
 
@@ -96,6 +97,7 @@ struct sdplr_hip_solver {
   hipGraphExec_t graph_exec[2] = {nullptr, nullptr};
   int graph_iters = 8;
   bool graph_disabled = false;
+  hipGraphExec_t lz_graph = nullptr;   // three Lanczos steps (one rotation of the vector buffers)
 
   // Gram bookkeeping (see k_dense.h)
   bool gram_dirty = false, sg_stale = false, ynext_pending = false;
@@ -274,12 +276,12 @@ int alloc_factors(S* s) {
   s->arena.base = base;
   choose_shape(s);
   const int G = SDPLR_NT / s->LPR;
-  s->nb_dense = blocks_for((s->N + 1) / 2, SDPLR_NT, SDPLR_MAXNB);
+  s->nb_dense = blocks_for((s->N + 1) / 2, SDPLR_NT, 1024);
   if (const char* e = getenv("SDPLR_HIP_NB_DENSE")) s->nb_dense = std::max(1, std::min(atoi(e), SDPLR_MAXNB));
   s->nb_upd = std::min(s->nb_dense, 512);
   if (const char* e = getenv("SDPLR_HIP_NB_UPD")) s->nb_upd = std::max(1, std::min(atoi(e), SDPLR_MAXNB));
   s->nb_sddmm = blocks_for(s->nnzT, G, 8192);
-  s->nb_spmm = blocks_for(s->n, G, SDPLR_MAXNB - 256);  // + up to 256 hub-row blocks share the partial slot
+  s->nb_spmm = blocks_for(s->n, G, 768);  // + up to 256 hub-row blocks share the partial slot
   return SDPLR_OK;
 }
 
@@ -519,7 +521,7 @@ int32_t sdplr_hip_finalize(S* s) {
     if ((rc = dzero(s, &s->lz_buf[k], n))) return rc;
   if ((rc = dzero(s, &s->lz_v0, n))) return rc;
   s->nb_lr = 256;
-  if ((rc = dzero(s, &s->lr_btx_part, (size_t)std::max(lr.ST, 1) * 64))) return rc;
+  if ((rc = dzero(s, &s->lr_btx_part, (size_t)std::max(lr.ST, 1) * SDPLR_MAXNB))) return rc;
   if ((rc = dzero(s, &s->lr_coef, std::max(lr.ST, 1)))) return rc;
   {
     DevCtrl* d = nullptr;
@@ -632,10 +634,10 @@ int32_t sdplr_hip_finalize(S* s) {
   }
   if ((rc = alloc_factors(s))) return rc;
   s->nb_m = blocks_for(m + 1, SDPLR_NT, 256);
-  s->nb_spmv = blocks_for(n, SDPLR_NT / 8, SDPLR_MAXNB - 256);
+  s->nb_spmv = blocks_for(n, SDPLR_NT / 8, 768);
   s->nb_nnzT = blocks_for(s->nnzT, SDPLR_NT, 4096);
   s->nb_nnzS = blocks_for(s->nnzS, SDPLR_NT, 4096);
-  s->nb_n = blocks_for(n, SDPLR_NT, SDPLR_MAXNB);
+  s->nb_n = blocks_for(n, SDPLR_NT, 1024);
   // low-rank scratch depends on r: allocated for the largest rank seen (reset_rank re-allocates)
   if ((rc = dzero(s, &s->lr_part, (size_t)s->nb_lr * 2 * std::max(lr.ST, 1) * s->r))) return rc;
   if ((rc = dzero(s, &s->lr_W, (size_t)2 * std::max(lr.ST, 1) * s->r))) return rc;
@@ -660,6 +662,7 @@ int32_t sdplr_hip_destroy(S* s) {
   if (s->lz_alpha) (void)hipFree(s->lz_alpha);
   if (s->lz_beta) (void)hipFree(s->lz_beta);
   if (s->hc) (void)hipHostFree(s->hc);
+  if (s->lz_graph) (void)hipGraphExecDestroy(s->lz_graph);
   for (int k = 0; k < 2; k++) {
     if (s->snap[k]) (void)hipHostFree(s->snap[k]);
     if (s->snap_ev[k]) (void)hipEventDestroy(s->snap_ev[k]);
@@ -1137,6 +1140,8 @@ int ensure_lz_capacity(S* s, int64_t q) {
   HIPCK(s, hipStreamSynchronize(s->stream));
   if (s->lz_alpha) (void)hipFree(s->lz_alpha);
   if (s->lz_beta) (void)hipFree(s->lz_beta);
+  if (s->lz_graph) { (void)hipGraphExecDestroy(s->lz_graph); s->lz_graph = nullptr; }
+  q = std::max<int64_t>(q, 4096);
   HIPCK(s, hipMalloc((void**)&s->lz_alpha, q * sizeof(double)));
   HIPCK(s, hipMalloc((void**)&s->lz_beta, q * sizeof(double)));
   s->lz_cap = q;
@@ -1156,7 +1161,7 @@ void enq_spmv(S* s, const double* x, double* yv, int slot, const int* stop_flag)
     k_spmv_long<<<std::min(s->sp.n_long_rows, 256), SDPLR_NT, 0, s->stream>>>(s->sp, x, yv, s->lr, s->lr_coef, slot, s->nb_spmv, s->partials, stop_flag);
 }
 
-int run_lanczos(S* s, int64_t q, const double* v0, double* alpha, double* beta, int64_t* steps) {
+int run_lanczos_classic(S* s, int64_t q, const double* v0, double* alpha, double* beta, int64_t* steps) {
   const int64_t n = s->n;
   if (q > n - 1) q = n - 1;  // src/coreop.jl:465
   if (q < 1) return fail(s, SDPLR_ERR_INVALID_ARG, "lanczos: q < 1 (needs n ≥ 2)");
@@ -1185,6 +1190,91 @@ int run_lanczos(S* s, int64_t q, const double* v0, double* alpha, double* beta, 
     }
     double* t = vpre;  // copyto!(v_pre, v); copyto!(v, Av)  (:498-499) as a pointer rotation
     vpre = v; v = Av; Av = t;
+  }
+  HIPCK(s, hipGetLastError());
+  HIPCK(s, hipMemcpyAsync(alpha, s->lz_alpha, q * sizeof(double), hipMemcpyDeviceToHost, s->stream));
+  HIPCK(s, hipMemcpyAsync(beta, s->lz_beta, q * sizeof(double), hipMemcpyDeviceToHost, s->stream));
+  if ((rc = pull(s))) return rc;
+  *steps = s->hc->lz_steps;
+  return SDPLR_OK;
+}
+
+// one Lanczos step = k_lz_spmv (+ hub rows) + k_lz_step on the buffer triple (uprev, u, t)
+void enq_lz_step(S* s, double* uprev, double* u, double* t) {
+  const int* stop = &s->ctrl->lz_done;
+  {
+    ProfScope ps(s, "lz_spmv");
+    static const int lz_lpr = getenv("SDPLR_HIP_LZ_LPR") ? atoi(getenv("SDPLR_HIP_LZ_LPR")) : 8;
+    const int nbv = blocks_for(s->n, SDPLR_NT / lz_lpr, 768);  // more blocks only lengthen the consumer-side reductions
+    s->nb_lzv = nbv;
+    if (lz_lpr == 4) k_lz_spmv<4><<<nbv, SDPLR_NT, 0, s->stream>>>(s->sp, s->ctrl, u, t, s->lr, s->y, s->lr_btx_part, s->nb_n, s->lr_coef, s->lz_beta, s->partials);
+    else if (lz_lpr == 16) k_lz_spmv<16><<<nbv, SDPLR_NT, 0, s->stream>>>(s->sp, s->ctrl, u, t, s->lr, s->y, s->lr_btx_part, s->nb_n, s->lr_coef, s->lz_beta, s->partials);
+    else if (lz_lpr == 32) k_lz_spmv<32><<<nbv, SDPLR_NT, 0, s->stream>>>(s->sp, s->ctrl, u, t, s->lr, s->y, s->lr_btx_part, s->nb_n, s->lr_coef, s->lz_beta, s->partials);
+    else k_lz_spmv<8><<<nbv, SDPLR_NT, 0, s->stream>>>(s->sp, s->ctrl, u, t, s->lr, s->y, s->lr_btx_part, s->nb_n, s->lr_coef, s->lz_beta, s->partials);
+    if (s->sp.n_long_rows > 0)
+      k_spmv_long<<<std::min(s->sp.n_long_rows, 256), SDPLR_NT, 0, s->stream>>>(s->sp, u, t, s->lr, s->lr_coef, SLOT_LZ_A, s->nb_lzv, s->partials, stop);
+  }
+  ProfScope ps(s, "lz_step");
+  k_lz_step<<<s->nb_n, SDPLR_NT, 0, s->stream>>>((int)s->n, s->ctrl, uprev, u, t, s->lr, s->lr_btx_part, s->nb_lzv + std::min(s->sp.n_long_rows, 256), s->lz_alpha, s->partials);
+}
+
+// approx_mineigval_lanczos's recurrence, src/coreop.jl:461-500 (see k_sparse.h "Lanczos recurrence")
+int run_lanczos(S* s, int64_t q, const double* v0, double* alpha, double* beta, int64_t* steps,
+                std::shared_lock<std::shared_mutex>* api_lock) {
+  const int64_t n = s->n;
+  if (s->lr.ST > SDPLR_LRMAX || getenv("SDPLR_HIP_CLASSIC_LANCZOS") != nullptr)
+    return run_lanczos_classic(s, q, v0, alpha, beta, steps);
+  if (q > n - 1) q = n - 1;  // src/coreop.jl:465
+  if (q < 1) return fail(s, SDPLR_ERR_INVALID_ARG, "lanczos: q < 1 (needs n ≥ 2)");
+  int rc = ensure_lz_capacity(s, q);
+  if (rc) return rc;
+  if ((rc = pull(s))) return rc;
+  DevCtrl* c = s->hc;
+  c->lz_done = 0; c->lz_steps = 0; c->lz_beta_prev = 0.0; c->lz_gamma_cur = 1.0; c->lz_gamma_prev = 1.0; c->lz_qmax = q;
+  if ((rc = push(s))) return rc;
+  double *b0 = s->lz_buf[0], *b1 = s->lz_buf[1], *b2 = s->lz_buf[2];
+  HIPCK(s, hipMemcpyAsync(b1, v0, n * sizeof(double), hipMemcpyHostToDevice, s->stream));   // u_1 = v0
+  HIPCK(s, hipMemsetAsync(b0, 0, n * sizeof(double), s->stream));                            // u_0 = 0
+  HIPCK(s, hipMemsetAsync(s->lz_alpha, 0, q * sizeof(double), s->stream));
+  HIPCK(s, hipMemsetAsync(s->lz_beta, 0, q * sizeof(double), s->stream));
+  {
+    ProfScope ps(s, "lanczos_init");
+    k_sumsq<<<s->nb_n, SDPLR_NT, 0, s->stream>>>(b1, n, SLOT_LZ_N, s->partials);                // ‖v0‖² (:474)
+    if (s->lr.ST > 0)
+      k_lr_btx<<<dim3(s->nb_n, s->lr.ST), SDPLR_NT, 0, s->stream>>>(s->lr, b1, (int)n, s->lr_btx_part, nullptr);
+  }
+  // three steps = one rotation of (uprev, u, t): (b0,b1,b2) → (b1,b2,b0) → (b2,b0,b1)
+  auto three = [&]() {
+    enq_lz_step(s, b0, b1, b2);
+    enq_lz_step(s, b1, b2, b0);
+    enq_lz_step(s, b2, b0, b1);
+  };
+  const int64_t rounds = (q + 1 + 2) / 3;   // q steps + the closing k_lz_spmv of step q+1
+  bool use_graph = !s->prof_on && !s->graph_disabled && getenv("SDPLR_HIP_NO_GRAPH") == nullptr;
+  if (use_graph && !s->lz_graph && api_lock) {
+    api_lock->unlock();
+    {
+      std::unique_lock<std::shared_mutex> excl(g_api_rw);
+      hipGraph_t graph = nullptr;
+      bool ok = hipStreamBeginCapture(s->stream, hipStreamCaptureModeRelaxed) == hipSuccess;
+      if (ok) {
+        three();
+        ok = hipStreamEndCapture(s->stream, &graph) == hipSuccess && graph != nullptr;
+      }
+      if (ok) ok = hipGraphInstantiate(&s->lz_graph, graph, nullptr, nullptr, 0) == hipSuccess;
+      if (graph) (void)hipGraphDestroy(graph);
+      if (!ok) {
+        (void)hipGetLastError();
+        s->lz_graph = nullptr;
+        s->graph_disabled = true;
+      }
+    }
+    api_lock->lock();
+  }
+  if (!s->lz_graph) use_graph = false;
+  for (int64_t k = 0; k < rounds; k++) {
+    if (use_graph) HIPCK(s, hipGraphLaunch(s->lz_graph, s->stream));
+    else three();
   }
   HIPCK(s, hipGetLastError());
   HIPCK(s, hipMemcpyAsync(alpha, s->lz_alpha, q * sizeof(double), hipMemcpyDeviceToHost, s->stream));
@@ -1551,7 +1641,7 @@ int32_t sdplr_hip_lanczos(S* s, int64_t q, const double* v0, double* alpha, doub
   ApiShared api_guard;
   NEED_FINAL(s);
   if (!v0 || !alpha || !beta || !steps || q < 1) return fail(s, SDPLR_ERR_INVALID_ARG, "lanczos: bad args");
-  return run_lanczos(s, q, v0, alpha, beta, steps);
+  return run_lanczos(s, q, v0, alpha, beta, steps, &api_guard.l);
 }
 int32_t sdplr_hip_tridiag_mineig(const double* alpha, const double* beta, int64_t k, double* out) {
   if (!alpha || !out || k < 1 || (k > 1 && !beta)) return SDPLR_ERR_INVALID_ARG;
@@ -1572,10 +1662,11 @@ int32_t sdplr_hip_tridiag_mineig(const double* alpha, const double* beta, int64_
   *out = 0.5 * (lo + hi) - 1;                                   // cancel the shift (:513)
   return SDPLR_OK;
 }
-static int32_t approx_mineig_impl(S* s, int64_t q, const double* v0, double* mineig) {
+static int32_t approx_mineig_impl(S* s, int64_t q, const double* v0, double* mineig,
+                                  std::shared_lock<std::shared_mutex>* api_lock) {
   std::vector<double> al(q), be(q);
   int64_t steps = 0;
-  int rc = run_lanczos(s, q, v0, al.data(), be.data(), &steps);
+  int rc = run_lanczos(s, q, v0, al.data(), be.data(), &steps, api_lock);
   if (rc) return rc;
   return sdplr_hip_tridiag_mineig(al.data(), be.data(), steps, mineig);
 }
@@ -1583,7 +1674,7 @@ int32_t sdplr_hip_approx_mineigval_lanczos(S* s, int64_t q, const double* v0, do
   ApiShared api_guard;
   NEED_FINAL(s);
   if (!v0 || !mineig || q < 1) return fail(s, SDPLR_ERR_INVALID_ARG, "approx_mineigval_lanczos: bad args");
-  return approx_mineig_impl(s, q, v0, mineig);
+  return approx_mineig_impl(s, q, v0, mineig, &api_guard.l);
 }
 int32_t sdplr_hip_dual_obj(S* s, double trace_bound, int64_t iter, const double* v0, double* dual_value, double* mineig) {
   ApiShared api_guard;
@@ -1594,7 +1685,7 @@ int32_t sdplr_hip_dual_obj(S* s, double trace_bound, int64_t iter, const double*
   const double it = (double)std::max<int64_t>(iter, 100);
   const int64_t eig_iter = (int64_t)(2 * std::ceil(std::pow(it, 0.5) * std::log((double)s->n)));  // :402
   double ev = 0.0;
-  int rc = approx_mineig_impl(s, eig_iter, v0, &ev);
+  int rc = approx_mineig_impl(s, eig_iter, v0, &ev, &api_guard.l);
   if (rc) return rc;
   k_dot<<<s->nb_m, SDPLR_NT, 0, s->stream>>>((int)s->m, s->y, s->b, SLOT_DUALYB, s->partials);
   k_reduce_slot<<<1, SDPLR_NT, 0, s->stream>>>(&s->ctrl->descent, SLOT_DUALYB, s->nb_m, s->partials);
