@@ -163,17 +163,7 @@ def main():
     dominant = max(per_kernel_bytes, key=lambda k: prof_all.get(k, (0, 0.0))[1])
     launches, dom_ms = prof_all.get(dominant, (0, 0.0))
 
-    dt_max = dt
-    objs = [obj]
-    if dist is not None:
-        import torch
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt_max = float(t.item())
-        o = torch.tensor([obj], dtype=torch.float64, device="cuda")
-        gathered = [torch.zeros_like(o) for _ in range(world)]
-        dist.all_gather(gathered, o)          # RCCL: the only collective of the workload (objectives)
-        objs = [float(x.item()) for x in gathered]
+    dt_max, objs = reduce_over_ranks(dist, dt, obj, "cuda" if dist is not None else None)
 
     if rank == 0:
         its = world * K / dt_max
@@ -214,6 +204,21 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def reduce_over_ranks(dist, dt, obj, device):
+    """max-over-ranks of the timed region and the per-rank objectives — the only collectives of the
+    workload (RCCL over xGMI on the GPU node; gloo in tests/test_batch_gloo.py)."""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return dt, [obj]
+    import torch
+    world = dist.get_world_size()
+    t = torch.tensor([dt], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    o = torch.tensor([obj], dtype=torch.float64, device=device)
+    gathered = [torch.zeros_like(o) for _ in range(world)]
+    dist.all_gather(gathered, o)
+    return float(t.item()), [float(x.item()) for x in gathered]
 
 
 def load_traffic(kernel):

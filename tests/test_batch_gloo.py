@@ -55,3 +55,32 @@ def test_two_rank_gloo_gather_matches_serial(oracle_abi):
     assert got.shape == serial.shape == (5, batch.N_FIELDS)
     assert np.array_equal(got[:, 0], np.arange(5.0))
     assert np.allclose(got[:, 1:4], serial[:, 1:4], rtol=1e-12)   # same seeds ⇒ same solves, any sharding
+
+
+def _bench_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import bench
+    dt_max, objs = bench.reduce_over_ranks(dist, 0.25 * (rank + 1), -100.0 - rank, None)
+    q.put((rank, dt_max, objs))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bench_rank_reduction_gloo():
+    """bench.py's N > 1 reduction: MAX of the timed region over ranks + all_gather of the objectives."""
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_bench_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=300) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, dt_max, objs in got:
+        assert dt_max == 0.5 and objs == [-100.0, -101.0]
