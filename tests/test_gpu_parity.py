@@ -405,7 +405,7 @@ def test_code_paths_agree(hip_abi, oracle_abi, family, toggles, monkeypatch):
     armijo = data.has_inequalities
 
     iters = 6 if armijo else 25     # see the note on the μ-conductance-ineq start below
-    tolR = 1e-6 if armijo else 1e-9
+    tolR = 1e-4 if armijo else 1e-9
     st0 = []
 
     def run(abi):
