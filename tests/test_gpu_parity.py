@@ -446,3 +446,77 @@ def test_lanczos_paths_agree(hip_abi, monkeypatch):
     assert np.allclose(a1[:4], a2[:4], rtol=1e-8) and np.allclose(b1[:4], b2[:4], rtol=1e-8)
     assert g.tridiag_mineig(a1, b1) == pytest.approx(g.tridiag_mineig(a2, b2), abs=1e-8)
     g.close()
+
+
+def _random_problem(kind: str, n: int, rng):
+    """Hand-made constraint structures that hit the classification edges of the device layout."""
+    def sym_sparse(density, with_diag=True):
+        M = sp.random(n, n, density=density, random_state=np.random.RandomState(int(rng.integers(1 << 30))), format="csr")
+        M = sp.triu(M, k=1)
+        M = M + M.T
+        if with_diag:
+            M = M + sp.diags(rng.standard_normal(n))
+        return sp.csc_matrix(M)
+
+    def coo_sym(pairs, vals):
+        I, J, V = [], [], []
+        for (i, j), v in zip(pairs, vals):
+            I.append(i); J.append(j); V.append(v)
+            if i != j:
+                I.append(j); J.append(i); V.append(v)
+        return sj.SparseMatrixCOO(I, J, V, n, n)
+
+    lowrank = lambda s: sj.SymLowRankMatrix(rng.standard_normal(s), rng.standard_normal((n, s)))
+    if kind == "general_constraint_diag_cost":       # the one off-diagonal matrix is a constraint, C is diagonal
+        C = sj.Diagonal(rng.standard_normal(n))
+        As = [sym_sparse(0.2)] + [coo_sym([(i, i)], [1.0 + i]) for i in range(n)]
+    elif kind == "two_general":                       # two off-diagonal matrices ⇒ generic path
+        C = sym_sparse(0.2)
+        As = [sym_sparse(0.1), sj.Diagonal(np.ones(n))] + [coo_sym([(i, i)], [1.0]) for i in range(0, n, 2)]
+    elif kind == "duplicates_and_missing_diag":       # duplicate COO entries; rows without any diagonal entry
+        C = sym_sparse(0.15, with_diag=False)
+        As = [sj.SparseMatrixCOO([0, 0, 2], [0, 0, 2], [0.5, 0.25, -1.0], n, n),
+              coo_sym([(1, 1), (3, 3), (5, 5)], [1.0, 2.0, 3.0]), lowrank(2)]
+    elif kind == "all_lowrank":                       # no sparse matrix at all
+        C = lowrank(1)
+        As = [lowrank(2), lowrank(1)]
+    elif kind == "lowrank_cost_multi_column":         # s > 1 columns, several low-rank matrices + general constraint
+        C = lowrank(3)
+        As = [sym_sparse(0.2), lowrank(2)] + [coo_sym([(i, i)], [1.0]) for i in range(n)]
+    elif kind == "edge_constraints_sparse_cost":      # Lovász-like edge rows AND a sparse cost ⇒ generic path
+        C = sym_sparse(0.1)
+        As = [coo_sym([(i, (i + 1) % n)], [1.0]) for i in range(n)] + [sp.identity(n, format="csc")]
+    else:
+        raise KeyError(kind)
+    bs = rng.standard_normal(len(As))
+    return C, As, bs
+
+
+@pytest.mark.parametrize("kind", ["general_constraint_diag_cost", "two_general", "duplicates_and_missing_diag",
+                                  "all_lowrank", "lowrank_cost_multi_column", "edge_constraints_sparse_cost"])
+@pytest.mark.parametrize("r", [2, 5, 32])
+def test_unusual_structures(hip_abi, oracle_abi, kind, r):
+    rng = np.random.Generator(np.random.PCG64(77))
+    n = 14
+    C, As, bs = _random_problem(kind, n, rng)
+    data = sj.SDPData(C, As, bs)
+    g, o = pair(hip_abi, oracle_abi, data, r, 9)
+    normC, normb = 3.0, 2.0
+    sg, so = g.fg(normC, normb), o.fg(normC, normb)
+    assert np.allclose(sg, so, rtol=1e-11)
+    R = g.Rt
+    assert np.max(np.abs(g.primal_vio_raw - primal_vio_dense(C, As, bs, R))) < 1e-9 * (1 + np.max(np.abs(g.primal_vio_raw)))
+    assert rel(g.Gt, o.Gt) < 1e-12
+    assert np.max(np.abs(g.Gt - 2 * S_dense(C, As, g.y) @ R)) < 1e-10 * (1 + np.max(np.abs(g.Gt)))
+    for it in range(6):
+        rg = g.inner_loop(normC, normb, True, True, False, 0.0, -1e300, 1, 0.0, *sg)
+        ro = o.inner_loop(normC, normb, True, True, False, 0.0, -1e300, 1, 0.0, *so)
+        scale = np.maximum(np.abs(so), np.abs(ro[:3]))
+        assert np.all(np.abs(np.array(rg[:3]) - np.array(ro[:3])) <= 1e-8 * scale), (kind, it, rg, ro)
+        sg, so = rg[:3], ro[:3]
+    assert rel(g.Rt, o.Rt) < 1e-8
+    assert np.max(np.abs(g.primal_vio_raw - primal_vio_dense(C, As, bs, g.Rt))) < 1e-8 * (1 + np.max(np.abs(g.primal_vio_raw)))
+    v0 = rng.standard_normal(n)
+    (dg, eg), (do, eo) = g.dual_obj(5.0, 0, v0), o.dual_obj(5.0, 0, v0)
+    assert eg == pytest.approx(eo, rel=1e-7, abs=1e-9) and dg == pytest.approx(do, rel=1e-7, abs=1e-9)
+    g.close(); o.close()
