@@ -39,7 +39,8 @@ def main():
     assert abi.set_device(local_rank) == 0
     graphs = instances()
     t0 = time.perf_counter()
-    local = batch.solve_local(graphs, rank, world, 10, concurrency=8, make_data=problems.maxcut_data,
+    conc = int(os.environ.get("SDPLR_BATCH_CONCURRENCY", "8"))
+    local = batch.solve_local(graphs, rank, world, 10, concurrency=conc, make_data=problems.maxcut_data,
                               ptol=0.01, objtol=0.01, seed=0, prior_trace_bound=800.0)
     res = batch.gather(local, len(graphs), dist, device)
     dt = time.perf_counter() - t0

@@ -1100,19 +1100,56 @@ k_lz_spmv(DevSparse sp, DevCtrl* __restrict__ c, const double* __restrict__ u, d
       c->lz_beta_prev = (st > 0) ? g : 0.0;
     }
   }
-  constexpr int G = SDPLR_NT / LPR;
+  // Four rows per sub-wave group in flight: the row pointers, then the first (index, value) pair of every
+  // row, then the four gathers are issued back to back — the kernel is bound by the chain
+  // colptr → rowval → x[rowval] of each row, not by bandwidth (18 → see DESIGN.md for the measured effect).
+  constexpr int G = SDPLR_NT / LPR, RIF = 4;
   const int lane = threadIdx.x % LPR;
   const long long total = (long long)gridDim.x * G;
   double dot = 0.0;
-  for (long long j = (long long)blockIdx.x * G + threadIdx.x / LPR; j < sp.n; j += total) {
-    if (sp.n_long_rows > 0 && sp.colptr[j + 1] - sp.colptr[j] > sp.long_thresh) continue;
-    double tj = 0.0;
-    for (int p = sp.colptr[j] + lane; p < sp.colptr[j + 1]; p += LPR) tj += sp.nzval[p] * u[sp.rowval[p]];
-    tj = group_sum<LPR>(tj);
-    if (lane == 0) {
-      for (int cc = 0; cc < lr.ST; cc++) tj += coef[cc] * lr.Bcat[(long long)cc * sp.n + j];
-      t[j] = tj;
-      dot += u[j] * tj;
+  for (long long j0 = (long long)blockIdx.x * G + threadIdx.x / LPR; j0 < sp.n; j0 += RIF * total) {
+    int beg[RIF], end[RIF];
+#pragma unroll
+    for (int k = 0; k < RIF; k++) {
+      const long long j = j0 + k * total;
+      if (j < sp.n) {
+        beg[k] = sp.colptr[j];
+        end[k] = sp.colptr[j + 1];
+        if (sp.n_long_rows > 0 && end[k] - beg[k] > sp.long_thresh) end[k] = beg[k];  // hub row: k_spmv_long
+      } else {
+        beg[k] = end[k] = 0;
+      }
+    }
+    double tj[RIF];
+#pragma unroll
+    for (int k = 0; k < RIF; k++) tj[k] = 0.0;
+    int maxlen = 0;
+#pragma unroll
+    for (int k = 0; k < RIF; k++) maxlen = max(maxlen, end[k] - beg[k]);
+    maxlen = max(maxlen, __shfl_xor(maxlen, 32, 64));  // wave-uniform trip count is not required; group-uniform is
+    for (int off = lane; off < ((maxlen + LPR - 1) / LPR) * LPR; off += LPR) {
+      int rv[RIF];
+      double nv[RIF];
+#pragma unroll
+      for (int k = 0; k < RIF; k++) {
+        const int p = beg[k] + off;
+        const bool ok = p < end[k];
+        rv[k] = ok ? sp.rowval[p] : 0;
+        nv[k] = ok ? sp.nzval[p] : 0.0;
+      }
+#pragma unroll
+      for (int k = 0; k < RIF; k++) tj[k] += nv[k] * u[rv[k]];
+    }
+#pragma unroll
+    for (int k = 0; k < RIF; k++) {
+      const long long j = j0 + k * total;
+      const double v = group_sum<LPR>(tj[k]);
+      if (lane == 0 && j < sp.n && !(sp.n_long_rows > 0 && sp.colptr[j + 1] - sp.colptr[j] > sp.long_thresh)) {
+        double tv = v;
+        for (int cc = 0; cc < lr.ST; cc++) tv += coef[cc] * lr.Bcat[(long long)cc * sp.n + j];
+        t[j] = tv;
+        dot += u[j] * tv;
+      }
     }
   }
   dot = block_sum1(dot, sh);
