@@ -11,7 +11,7 @@ host layout, ``problems.py`` SDP builders, ``sdplr.py`` host control flow, ``bui
 from . import batch, cabi, preprocess, problems, structs  # noqa: F401
 from .cabi import CABI, DeviceSolver, SdplrError, load_hip, hip_library_path  # noqa: F401
 from .preprocess import AggregatedLayout, preprocess_sparsecons  # noqa: F401
-from .sdplr import _sdplr, build_solver, initial_point, sdplr  # noqa: F401
+from .sdplr import DIMACS_errors, SDP_S_eigval, _sdplr, build_solver, initial_point, sdplr  # noqa: F401
 from .structs import (BurerMonteiroConfig, Diagonal, SDPData, SparseBatch, SparseMatrixCOO,  # noqa: F401
                       SymLowRankMatrix, barvinok_pataki)
 

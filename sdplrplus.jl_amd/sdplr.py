@@ -73,6 +73,52 @@ def _load_point(s: DeviceSolver, data: SDPData, r: int, config: BurerMonteiroCon
     s.Rt0, s.λ0 = Rt0, λ0
 
 
+
+def SDP_S_eigval(var: DeviceSolver, nevs: int = 1, preprocessed: bool = False, *, which: str = "SA",
+                 ncv: Optional[int] = None, tol: float = 0.0, maxiter: int = 1000000, v0=None) -> np.ndarray:
+    """``SDP_S_eigval`` (src/coreop.jl:351-374): smallest eigenvalues of S through ARPACK on the shifted
+    operator x ↦ S·x + x.  The reference calls GenericArpack.symeigs (a Julia port of ARPACK); here the
+    same implicitly restarted Lanczos runs in scipy's ARPACK binding on the host, with the operator
+    applied on the device (``𝒜t!(y, aux, x, var)``, src/coreop.jl:281-300).  ``preprocessed=False``
+    refreshes S from the current y first (the reference's branch :358-360 calls 𝒜t_preprocess! with
+    swapped arguments and has no method; every caller passes ``true``)."""
+    from scipy.sparse.linalg import LinearOperator, eigsh
+    if not preprocessed:
+        var.At_preprocess()
+    n = var.n
+    op = LinearOperator((n, n), matvec=lambda x: var.At_right(np.asarray(x, dtype=np.float64).ravel()) + x.ravel(),
+                        dtype=np.float64)            # shift the matrix by I (:365-366)
+    if n <= max(nevs + 1, 3):                         # ARPACK needs k < n − 1: tiny problems go dense
+        S = np.column_stack([op.matvec(e) for e in np.eye(n)])
+        return np.sort(np.linalg.eigvalsh((S + S.T) / 2))[:nevs] - 1.0
+    ncv = min(ncv if ncv is not None else min(100, n), n)
+    ncv = max(ncv, min(n, 2 * nevs + 1))
+    vals = eigsh(op, k=nevs, which=which, ncv=ncv, tol=tol, maxiter=maxiter, v0=v0, return_eigenvectors=False)
+    return np.sort(np.real(vals)) - 1.0               # cancel the shift (:372)
+
+
+def DIMACS_errors(data: SDPData, var: DeviceSolver) -> np.ndarray:
+    """The six DIMACS errors (src/coreop.jl:417-453) with X = RRᵀ, Z = C − 𝒜*(λ)."""
+    m = data.m
+    pv_raw = var.primal_vio_raw
+    normb = float(np.linalg.norm(data.b))
+    err1 = float(np.linalg.norm(pv_raw[:m])) / (1.0 + normb)
+    err2 = err3 = 0.0                                  # X = YYᵀ ⪰ 0, Z = C − 𝒜*(y) by construction (:433)
+    λ = var.λ
+    var.y = np.concatenate([-λ, [1.0]])                # copy2y_λ! (:238-246)
+    var.At_preprocess()                                # (:436)
+    ev = SDP_S_eigval(var, 1, True, which="SA", ncv=min(100, data.n), maxiter=1000000)
+    normC = data.normC()
+    err4 = max(0.0, -float(ev[0])) / (1.0 + normC)
+    obj = var.obj
+    λb = float(λ @ data.b)
+    err5 = (obj - λb) / (1.0 + abs(obj) + abs(λb))
+    Rt = var.Rt
+    var.At_left(cabi.F_GT, cabi.F_RT)                  # Rt·S (:449); Gt is recomputed by the next g!
+    err6 = float(np.sum(Rt * var.Gt)) / (1.0 + abs(obj) + abs(λb))
+    return np.array([err1, err2, err3, err4, err5, err6])
+
+
 def _print_row(config, majoriter, localiter, iter_, L, obj, σ, gtol, ptol, gnorm, pnorm, gap, dobj):
     """printintermediate (src/myprint.jl:17-58), one plain line."""
     if config.printlevel > 0:
@@ -166,11 +212,15 @@ def _sdplr(data: SDPData, var: DeviceSolver, config: BurerMonteiroConfig,
         σ = var.σ
         if primal_vio_norm <= cur_ptol:                         # :310
             t0 = time.time()
-            if config.eigval_highprecision:
-                raise NotImplementedError("eigval_highprecision (GenericArpack path, "
-                                          "src/coreop.jl:351-374) is out of scope of the hot path")
             v0 = rng.standard_normal(n)                         # replaces randn, coreop.jl:473
-            dual_value, _ = var.dual_obj(config.prior_trace_bound, iter_, v0)     # :314
+            if config.eigval_highprecision:                     # coreop.jl:389-400
+                var.y = np.concatenate([-np.minimum(var.λ_ub, var.λ - var.σ * var.primal_vio_raw[:m]), [1.0]])
+                var.At_preprocess()
+                ev = SDP_S_eigval(var, 1, True, which="SA", ncv=min(100, n), tol=1e-6, maxiter=1000000,
+                                  v0=v0)[0]
+                dual_value = float(-(var.y[:m] @ data.b) + config.prior_trace_bound * min(ev, 0.0))
+            else:
+                dual_value, _ = var.dual_obj(config.prior_trace_bound, iter_, v0)     # :314
             obj = var.obj
             if dual_value > max_dual_value:                     # :324-327
                 best_λ = -var.y
@@ -231,15 +281,14 @@ def _sdplr(data: SDPData, var: DeviceSolver, config: BurerMonteiroConfig,
     _print_row(config, majoriter, -1, iter_, L_val, var.obj, var.σ, cur_gtol, cur_ptol, grad_norm,
                primal_vio_norm, min_duality_gap, max_dual_value)
     totaltime = time.time() - starttime
-    if config.eval_DIMACS_errs:
-        raise NotImplementedError("DIMACS_errors (src/coreop.jl:426-453) is out of scope of the hot path")
+    DIMACS_errs = DIMACS_errors(data, var) if config.eval_DIMACS_errs else np.zeros(6)   # :419-425
     Rt = var.Rt
     return {                                                    # :426-448
         "Rt": Rt, "lambda": best_λ, "Rt0": Rt0, "lambda0": λ0, "sigma": var.σ,
         "grad_norm": grad_norm, "primal_vio": primal_vio_norm, "obj": var.obj,
         "max_dual_value": max_dual_value, "min_duality_gap": min_duality_gap,
         "totaltime": totaltime, "dual_time": dual_time, "primaltime": totaltime - dual_time,
-        "iter": iter_, "majoriter": majoriter, "DIMACS_errs": np.zeros(6), "ptol": config.ptol,
+        "iter": iter_, "majoriter": majoriter, "DIMACS_errs": DIMACS_errs, "ptol": config.ptol,
         "objtol": config.objtol, "fprec": config.fprec, "rankupd_tol": config.rankupd_tol,
         "r": Rt.shape[1],
     }

@@ -520,3 +520,8 @@ def test_unusual_structures(hip_abi, oracle_abi, kind, r):
     (dg, eg), (do, eo) = g.dual_obj(5.0, 0, v0), o.dual_obj(5.0, 0, v0)
     assert eg == pytest.approx(eo, rel=1e-7, abs=1e-9) and dg == pytest.approx(do, rel=1e-7, abs=1e-9)
     g.close(); o.close()
+
+
+def test_eigval_and_dimacs_on_gpu(hip_abi):
+    from test_oracle_endtoend import _check_eigval_and_dimacs
+    _check_eigval_and_dimacs(hip_abi)

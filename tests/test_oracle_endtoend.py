@@ -191,3 +191,48 @@ def test_quartic_argmin_is_global_min_on_grid():
         assert f == pytest.approx(np.polyval(bq[::-1], a), rel=1e-12, abs=1e-12)
     rc, _, _ = oracle.quartic_argmin(np.array([0.0, 1.0, 1.0, 0.0, 1.0]), 1.0)
     assert rc == cabi.ERR_NOT_DESCENT
+
+
+def _check_eigval_and_dimacs(abi):
+    """SDP_S_eigval (src/coreop.jl:351-374) and DIMACS_errors (:426-453) against dense recomputation."""
+    for family in ["maxcut", "minimum_bisection", "lovasz_theta"]:
+        data, C, As, bs = make_data(family, 4, 30, 0.3)
+        var, _ = make_solver(abi, data, 4, seed=1)
+        n, m = data.n, data.m
+        normC, normb = data.normC(), float(np.linalg.norm(data.b))
+        st = var.fg(normC, normb)
+        var.inner_loop(normC, normb, True, True, False, 0.0, -1e300, 5, 0.0, *st)
+        rng = np.random.Generator(np.random.PCG64(3))
+        var.λ = rng.standard_normal(m)
+        var.f()
+        R, λ = var.Rt, var.λ
+        S = S_dense(C, As, np.concatenate([-λ, [1.0]]))
+        w = np.linalg.eigvalsh(S)
+        errs = sj.DIMACS_errors(data, var)
+        pv = var.primal_vio_raw
+        obj = float(np.sum((C.toarray() @ R) * R))
+        λb = float(λ @ bs)
+        ref = [np.linalg.norm(pv[:m]) / (1 + normb), 0.0, 0.0, max(0.0, -w[0]) / (1 + normC),
+               (obj - λb) / (1 + abs(obj) + abs(λb)), float(np.sum(R * (S @ R))) / (1 + abs(obj) + abs(λb))]
+        assert np.allclose(errs, ref, rtol=1e-7, atol=1e-10), (family, errs, ref)
+        ev = sj.SDP_S_eigval(var, 2, True, which="SA", ncv=min(20, n), tol=1e-10)
+        assert np.allclose(ev, w[:2], rtol=1e-8, atol=1e-9)
+        var.close()
+
+
+def test_eigval_and_dimacs_on_oracle(oracle_abi):
+    _check_eigval_and_dimacs(oracle_abi)
+
+
+def test_highprecision_and_dimacs_options(oracle_abi):
+    """config.eigval_highprecision / eval_DIMACS_errs (src/options.jl:17-18) through the driver."""
+    A = problems.gnp_graph(40, 0.2, 5)
+    C, As, bs = problems.maxcut(A)
+    res = sj.sdplr(C, As, bs, 6, abi=oracle_abi, printlevel=0, seed=2, prior_trace_bound=40.0,
+                   ptol=1e-3, objtol=1e-3, eigval_highprecision=True, eval_DIMACS_errs=True)
+    assert res["primal_vio"] <= 1e-3 and res["min_duality_gap"] <= 1e-3
+    e = res["DIMACS_errs"]
+    assert e.shape == (6,) and e[1] == 0 and e[2] == 0
+    assert abs(e[0]) < 1e-2 and e[3] < 1e-2 and abs(e[4]) < 1e-2 and abs(e[5]) < 1e-2
+    # the dual bound from the ARPACK eigenvalue is a valid lower bound on the SDP value
+    assert res["max_dual_value"] <= res["obj"] + 1e-6 * abs(res["obj"])
