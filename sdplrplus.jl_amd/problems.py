@@ -216,6 +216,65 @@ def mu_conductance_ineq(A, mu: float):
     return L, As, np.asarray(bs), np.asarray(ct, dtype=bool)
 
 
+def _pad3(M, n):
+    M = sp.coo_matrix(M)
+    out = sp.csc_matrix((M.data, (M.row, M.col)), shape=(3 * n, 3 * n))
+    out.sort_indices()
+    return out
+
+
+def relaxed_maxcut(A):
+    """−¼⟨L,X⟩ with 0.99 ≤ Diag(X) ≤ 1 through slack diagonals (exps/problems.jl:188-216)."""
+    A = _check_undirected(A)
+    n = A.shape[0]
+    N = 3 * n
+    L = _pad3(_laplacian(A, -0.25), n)
+    As, bs = [], []
+    for i in range(n):
+        As.append(SparseMatrixCOO([i, i + n], [i, i + n], [1.0, 1.0], N, N)); bs.append(1.0)
+    for i in range(n):
+        As.append(SparseMatrixCOO([i, i + 2 * n], [i, i + 2 * n], [1.0, -1.0], N, N)); bs.append(0.99)
+    return L, As, np.asarray(bs)
+
+
+def mu_conductance_reformulated(A, mu: float):
+    """exps/problems.jl:233-281: the second slack block bounds the first slack (ub − lb)."""
+    A = _check_undirected(A)
+    n = A.shape[0]
+    N = 3 * n
+    d = np.asarray(A.sum(axis=1)).ravel()
+    volG = d.sum()
+    L = sp.csc_matrix(sp.diags(d) - A)
+    ub, lb = _mu_bounds(volG, mu)
+    As = [_pad3(sp.diags(d), n), SymLowRankMatrix(np.ones(1), np.concatenate([d, np.zeros(2 * n)]).reshape(-1, 1))]
+    bs = [1.0, 0.0]
+    for i in range(n):
+        As.append(SparseMatrixCOO([i, i + n], [i, i + n], [1.0, 1.0], N, N)); bs.append(ub)
+    for i in range(n):
+        As.append(SparseMatrixCOO([i + n, i + 2 * n], [i + n, i + 2 * n], [1.0, 1.0], N, N)); bs.append(ub - lb)
+    return _pad3(L, n), As, np.asarray(bs)
+
+
+def mu_conductance_native(A, mu: float):
+    """exps/problems.jl:295-341: n×n, inequality rows scaled by ‖D‖_F, rank-1 row scaled by ‖D‖_F/‖d‖²."""
+    A = _check_undirected(A)
+    n = A.shape[0]
+    d = np.asarray(A.sum(axis=1)).ravel()
+    volG = d.sum()
+    L = sp.csc_matrix(sp.diags(d) - A)
+    L.sort_indices()
+    D_norm = float(np.linalg.norm(d))          # norm(D, 2) of the diagonal matrix = ‖d‖₂
+    dd_norm = float(np.linalg.norm(d) ** 2)
+    ub, lb = _mu_bounds(volG, mu)
+    As = [sp.csc_matrix(sp.diags(d)), SymLowRankMatrix(np.array([D_norm / dd_norm]), d.reshape(-1, 1))]
+    bs, ct = [1.0, 0.0], [False, False]
+    for i in range(n):
+        As.append(SparseMatrixCOO([i], [i], [D_norm], n, n)); bs.append(ub * D_norm); ct.append(True)
+    for i in range(n):
+        As.append(SparseMatrixCOO([i], [i], [-D_norm], n, n)); bs.append(-lb * D_norm); ct.append(True)
+    return L, As, np.asarray(bs), np.asarray(ct, dtype=bool)
+
+
 # ------------------------------------------------------------------------------------------------
 # batched builders (same matrices, no per-constraint objects)
 # ------------------------------------------------------------------------------------------------

@@ -236,3 +236,24 @@ def test_highprecision_and_dimacs_options(oracle_abi):
     assert abs(e[0]) < 1e-2 and e[3] < 1e-2 and abs(e[4]) < 1e-2 and abs(e[5]) < 1e-2
     # the dual bound from the ARPACK eigenvalue is a valid lower bound on the SDP value
     assert res["max_dual_value"] <= res["obj"] + 1e-6 * abs(res["obj"])
+
+
+@pytest.mark.parametrize("name", ["relaxed_maxcut", "mu_conductance_reformulated", "mu_conductance_native"])
+def test_experiment_builders(oracle_abi, name):
+    """the remaining builders of exps/problems.jl (:188-341): the operator identities hold on them too."""
+    from helpers import primal_vio_dense
+    A = problems.gnp_graph(9, 0.5, 3)
+    ct = None
+    if name == "relaxed_maxcut":
+        C, As, bs = problems.relaxed_maxcut(A)
+    elif name == "mu_conductance_reformulated":
+        C, As, bs = problems.mu_conductance_reformulated(A, 0.05)
+    else:
+        C, As, bs, ct = problems.mu_conductance_native(A, 0.05)
+    data = sj.SDPData(C, As, bs, ct)
+    var, _ = make_solver(oracle_abi, data, 3, seed=4)
+    var.f()
+    assert np.max(np.abs(var.primal_vio_raw - primal_vio_dense(C, As, bs, var.Rt))) < 1e-10
+    var.g()
+    assert np.max(np.abs(var.Gt - 2 * S_dense(C, As, var.y) @ var.Rt)) < 1e-10 * (1 + np.max(np.abs(var.Gt)))
+    var.close()
