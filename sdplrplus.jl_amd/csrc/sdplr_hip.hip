@@ -1106,15 +1106,8 @@ void enq_iteration_fast2(S* s) {
     ProfScope ps(s, "ls_solve_fast");
     k_ls_solve_fast<<<1, SDPLR_NT, 0, s->stream>>>(s->ctrl, (int)s->m, s->ff.gid_g, s->n_extra, s->extra_slots, s->nb_spmm, s->A_RD, s->A_DD, s->lambda, s->lambda_ub, s->pv_raw, s->pv_lb, s->pv, s->y, s->lr.ST, (int)s->r, s->lr.col_gid, s->lr.Dcat, s->lr_W, s->lr_WS, s->partials, 1);
   }
-  // opt-in: measured 111 µs against 41 + 65 µs for the two separate kernels at the north-star size (register
-  // pressure: 166 VGPRs + scratch), so the separate kernels stay the default
-  if (s->h >= 1 && s->h <= 8 && getenv("SDPLR_HIP_FUSED_UPDATE") != nullptr) {
-    ProfScope ps(s, "fast_step_update");                                              // :219-246
-    const int sP = 3 + 2 * (int)s->h, sW = sP + 1;
-    if (s->HM == 4) { LV_DISPATCH((k_fast_step_update<LPR, VEC, 4><<<s->nb_upd, SDPLR_NT, 0, s->stream>>>((int)s->n, (int)s->m, s->ff, s->arena, sP, sW, (int)s->r, (int)s->h, s->y, s->lambda, s->lambda_ub, s->pv_raw, s->pv_lb, s->pv, s->A_RD, s->A_DD, s->lr, s->lr_WS, s->partials, s->ctrl, 1))) }
-    else { LV_DISPATCH((k_fast_step_update<LPR, VEC, 8><<<s->nb_upd, SDPLR_NT, 0, s->stream>>>((int)s->n, (int)s->m, s->ff, s->arena, sP, sW, (int)s->r, (int)s->h, s->y, s->lambda, s->lambda_ub, s->pv_raw, s->pv_lb, s->pv, s->A_RD, s->A_DD, s->lr, s->lr_WS, s->partials, s->ctrl, 1))) }
-    return;
-  }
+  // (a variant fusing this step kernel with lbfgs_update! was measured at 111 µs against 38 + 59 µs for the
+  // two kernels — 166 VGPRs and scratch — and dropped)
   {
     ProfScope ps(s, "fast_step");                                                     // :219-234
     LV_DISPATCH((k_fast_step2<LPR, VEC><<<s->nb_spmm, SDPLR_NT, 0, s->stream>>>((int)s->n, (int)s->m, s->ff, R, D, P, W, G, (int)s->r, s->y, s->lambda, s->lambda_ub, s->pv_raw, s->pv_lb, s->pv, s->A_RD, s->A_DD, s->lr, s->lr_WS, s->partials, s->ctrl, 1)))

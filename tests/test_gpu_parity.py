@@ -391,7 +391,7 @@ def test_concurrent_handles_match_serial(hip_abi):
 
 @pytest.mark.parametrize("family,toggles", [
     ("maxcut", ["SDPLR_HIP_NO_FAST"]), ("maxcut", ["SDPLR_HIP_NO_FAST2"]), ("maxcut", ["SDPLR_HIP_NO_GRAPH"]),
-    ("maxcut", ["SDPLR_HIP_FUSED_UPDATE"]), ("minimum_bisection", ["SDPLR_HIP_NO_FAST"]),
+    ("minimum_bisection", ["SDPLR_HIP_NO_FAST"]),
     ("minimum_bisection", ["SDPLR_HIP_NO_FAST2"]), ("cutnorm", ["SDPLR_HIP_NO_FAST"]),
     ("mu_conductance_0.05", ["SDPLR_HIP_NO_FAST"]), ("ineq_0.05", ["SDPLR_HIP_NO_FAST"]),
 ])
