@@ -814,3 +814,246 @@ k_spmm_fast(DevSparse sg, int m, DevFast ff, const double* __restrict__ R, const
     slot_partials(partials, SLOT_DW)[blockIdx.x] = acc[9];
   }
 }
+
+// ---- hub rows: one block per row of the full pattern with more than long_thresh nonzeros ------------------
+// Same result as k_spmm for those rows (which k_spmm skips): the row's nonzeros are dealt round-robin to the
+// block's sub-wave groups, the group partials are added in group order (deterministic).  Partials of the
+// norm / dot go to slot entries [pbase, pbase + n_long_rows).
+template <int LPR, int VEC>
+__global__ void __launch_bounds__(SDPLR_NT)
+k_spmm_long(DevSparse sp, const double* __restrict__ X, double* __restrict__ Y, int r, double scale,
+            DevLowRank lr, const double* __restrict__ WS, int slot, int pbase, double* __restrict__ partials,
+            const DevCtrl* __restrict__ c, int check_done, const double* __restrict__ Xdot) {
+  __shared__ double shg[SDPLR_NT * VEC];
+  __shared__ double sh[8];
+  if (check_done && c->done) return;
+  constexpr int G = SDPLR_NT / LPR;
+  const int lane = threadIdx.x % LPR, g = threadIdx.x / LPR;
+  double nrm = 0.0;
+  for (int lrow = blockIdx.x; lrow < sp.n_long_rows; lrow += gridDim.x) {
+  const long long j = sp.long_rows[lrow];
+  const int beg = sp.colptr[j], end = sp.colptr[j + 1];
+  for (int chb = 0; chb < r; chb += LPR * VEC) {
+    const int ch = chb + lane * VEC;
+    vecd<VEC> acc;
+#pragma unroll
+    for (int k = 0; k < VEC; k++) acc.v[k] = 0.0;
+    if (ch < r) {
+      int p = beg + g;
+      for (; p + 3 * G < end; p += 4 * G) {  // four independent row gathers in flight per group
+        const long long i0 = sp.rowval[p], i1 = sp.rowval[p + G], i2 = sp.rowval[p + 2 * G], i3 = sp.rowval[p + 3 * G];
+        const double v0 = sp.nzval[p], v1 = sp.nzval[p + G], v2 = sp.nzval[p + 2 * G], v3 = sp.nzval[p + 3 * G];
+        const vecd<VEC> x0 = ldrow<VEC>(X + i0 * r + ch), x1 = ldrow<VEC>(X + i1 * r + ch);
+        const vecd<VEC> x2 = ldrow<VEC>(X + i2 * r + ch), x3 = ldrow<VEC>(X + i3 * r + ch);
+#pragma unroll
+        for (int k = 0; k < VEC; k++) {
+          acc.v[k] += x0.v[k] * v0;
+          acc.v[k] += x1.v[k] * v1;
+          acc.v[k] += x2.v[k] * v2;
+          acc.v[k] += x3.v[k] * v3;
+        }
+      }
+      for (; p < end; p += G) {
+        const long long i = sp.rowval[p];
+        const double v = sp.nzval[p];
+        const vecd<VEC> x = ldrow<VEC>(X + i * r + ch);
+#pragma unroll
+        for (int k = 0; k < VEC; k++) acc.v[k] += x.v[k] * v;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < VEC; k++) shg[(g * LPR + lane) * VEC + k] = acc.v[k];
+    __syncthreads();
+    if (g == 0 && ch < r) {
+      vecd<VEC> tot;
+#pragma unroll
+      for (int k = 0; k < VEC; k++) tot.v[k] = 0.0;
+      for (int gg = 0; gg < G; gg++)
+#pragma unroll
+        for (int k = 0; k < VEC; k++) tot.v[k] += shg[(gg * LPR + lane) * VEC + k];
+      for (int cc = 0; cc < lr.ST; cc++) {
+        const double b = lr.Bcat[(long long)cc * sp.n + j];
+        const vecd<VEC> w = ldrow<VEC>(WS + (long long)cc * r + ch);
+#pragma unroll
+        for (int k = 0; k < VEC; k++) tot.v[k] += w.v[k] * b;
+      }
+#pragma unroll
+      for (int k = 0; k < VEC; k++) tot.v[k] *= scale;
+      if (Xdot) {
+        const vecd<VEC> xd = ldrow<VEC>(Xdot + j * r + ch);
+#pragma unroll
+        for (int k = 0; k < VEC; k++) nrm += tot.v[k] * xd.v[k];
+      } else {
+#pragma unroll
+        for (int k = 0; k < VEC; k++) nrm += tot.v[k] * tot.v[k];
+      }
+      strow<VEC>(Y + j * r + ch, tot);
+    }
+  }
+  }
+  if (slot >= 0) {
+    nrm = block_sum1(nrm, sh);
+    if (threadIdx.x == 0) slot_partials(partials, slot)[pbase + blockIdx.x] = nrm;
+  }
+}
+
+// hub rows of the SpMV: one block per row, 256 lanes stride the row
+__global__ void __launch_bounds__(SDPLR_NT)
+k_spmv_long(DevSparse sp, const double* __restrict__ x, double* __restrict__ y, DevLowRank lr,
+            const double* __restrict__ coef, int slot, int pbase, double* __restrict__ partials,
+            const int* __restrict__ stop_flag) {
+  __shared__ double sh[8];
+  if (stop_flag && *stop_flag) return;
+  double dot = 0.0;
+  for (int lrow = blockIdx.x; lrow < sp.n_long_rows; lrow += gridDim.x) {
+    const long long j = sp.long_rows[lrow];
+    double t = 0.0;
+    for (int p = sp.colptr[j] + threadIdx.x; p < sp.colptr[j + 1]; p += SDPLR_NT) t += sp.nzval[p] * x[sp.rowval[p]];
+    __syncthreads();
+    t = block_sum1(t, sh);
+    if (threadIdx.x == 0) {
+      for (int cc = 0; cc < lr.ST; cc++) t += coef[cc] * lr.Bcat[(long long)cc * sp.n + j];
+      y[j] = t;
+      dot += x[j] * t;
+    }
+  }
+  if (slot >= 0 && threadIdx.x == 0) slot_partials(partials, slot)[pbase + blockIdx.x] = dot;
+}
+
+// ================================================================================================
+// Lanczos recurrence (src/coreop.jl:481-500) on UNNORMALISED vectors, two kernels per step.
+//   u_1 = v0, γ_1 = ‖v0‖;  u_{i+1} = r_i = S·v_i − α_i v_i − β_{i−1} v_{i−1},  γ_{i+1} = β_i = ‖r_i‖,  v_i = u_i/γ_i.
+//   K1 k_lz_spmv: t = S·u_i (+ low-rank), partials of u_i·t;  its block 0 first closes the previous step:
+//      γ_i from the ‖u_i‖² partials, beta[i−1] = γ_i, the break test |β| < √n·eps (:494-496), the q-step cap.
+//   K2 k_lz_step: α_i = (u_i·t)/γ_i², r_i = t/γ_i − (α_i·u_i/γ_i + β_{i−1}·u_{i−1}/γ_{i−1}) written over t,
+//      partials of ‖r_i‖² and of ⟨B_c, r_i⟩ for the next K1's low-rank term.
+// Normalising lazily removes one grid-wide dependency per step (three kernels → two) and the kernels carry
+// no step index, so three steps (one rotation of the three vector buffers) replay as a hipGraph.
+// ================================================================================================
+template <int LPR>
+__global__ void __launch_bounds__(SDPLR_NT)
+k_lz_spmv(DevSparse sp, DevCtrl* __restrict__ c, const double* __restrict__ u, double* __restrict__ t,
+          DevLowRank lr, const double* __restrict__ yvec, const double* __restrict__ btx_part, int nb_prev,
+          double* __restrict__ coef_out, double* __restrict__ beta_out, double* __restrict__ partials) {
+  __shared__ double sh[8];
+  __shared__ double coef[SDPLR_LRMAX * 8];
+  if (c->lz_done) return;
+  for (int cc = 0; cc < lr.ST; cc++) {  // low-rank coefficients y[gid]·D_c·⟨B_c, u⟩ (src/structs.jl:117-127)
+    const double sidx = reduce_partials(btx_part + (long long)cc * nb_prev, nb_prev, sh);
+    if (threadIdx.x == 0) {
+      const double cf = yvec[lr.col_gid[cc]] * lr.Dcat[cc] * sidx;
+      if (cc < SDPLR_LRMAX * 8) coef[cc] = cf;
+      if (blockIdx.x == 0) coef_out[cc] = cf;
+    }
+    __syncthreads();
+  }
+  if (blockIdx.x == 0) {  // close the previous step (see header)
+    const double nn = reduce_partials(slot_partials(partials, SLOT_LZ_N), nb_prev, sh);
+    if (threadIdx.x == 0) {
+      const double g = sqrt(nn);
+      const long long st = c->lz_steps;
+      if (st > 0) {
+        beta_out[st - 1] = g;                                                  // beta[i] = ‖Av‖  (:492)
+        if (fabs(g) < sqrt((double)sp.n) * 2.220446049250313e-16) c->lz_done = 1;   // (:494-496)
+      }
+      if (st >= c->lz_qmax) c->lz_done = 1;
+      c->lz_gamma_prev = c->lz_gamma_cur;
+      c->lz_gamma_cur = g;
+      c->lz_beta_prev = (st > 0) ? g : 0.0;
+    }
+  }
+  // Four rows per sub-wave group in flight: the row pointers, then the first (index, value) pair of every
+  // row, then the four gathers are issued back to back — the kernel is bound by the chain
+  // colptr → rowval → x[rowval] of each row, not by bandwidth (18 → see DESIGN.md for the measured effect).
+  constexpr int G = SDPLR_NT / LPR, RIF = 4;
+  const int lane = threadIdx.x % LPR;
+  const long long total = (long long)gridDim.x * G;
+  double dot = 0.0;
+  for (long long j0 = (long long)blockIdx.x * G + threadIdx.x / LPR; j0 < sp.n; j0 += RIF * total) {
+    int beg[RIF], end[RIF];
+#pragma unroll
+    for (int k = 0; k < RIF; k++) {
+      const long long j = j0 + k * total;
+      if (j < sp.n) {
+        beg[k] = sp.colptr[j];
+        end[k] = sp.colptr[j + 1];
+        if (sp.n_long_rows > 0 && end[k] - beg[k] > sp.long_thresh) end[k] = beg[k];  // hub row: k_spmv_long
+      } else {
+        beg[k] = end[k] = 0;
+      }
+    }
+    double tj[RIF];
+#pragma unroll
+    for (int k = 0; k < RIF; k++) tj[k] = 0.0;
+    int maxlen = 0;
+#pragma unroll
+    for (int k = 0; k < RIF; k++) maxlen = max(maxlen, end[k] - beg[k]);
+    maxlen = max(maxlen, __shfl_xor(maxlen, 32, 64));  // wave-uniform trip count is not required; group-uniform is
+    for (int off = lane; off < ((maxlen + LPR - 1) / LPR) * LPR; off += LPR) {
+      int rv[RIF];
+      double nv[RIF];
+#pragma unroll
+      for (int k = 0; k < RIF; k++) {
+        const int p = beg[k] + off;
+        const bool ok = p < end[k];
+        rv[k] = ok ? sp.rowval[p] : 0;
+        nv[k] = ok ? sp.nzval[p] : 0.0;
+      }
+#pragma unroll
+      for (int k = 0; k < RIF; k++) tj[k] += nv[k] * u[rv[k]];
+    }
+#pragma unroll
+    for (int k = 0; k < RIF; k++) {
+      const long long j = j0 + k * total;
+      const double v = group_sum<LPR>(tj[k]);
+      if (lane == 0 && j < sp.n && !(sp.n_long_rows > 0 && sp.colptr[j + 1] - sp.colptr[j] > sp.long_thresh)) {
+        double tv = v;
+        for (int cc = 0; cc < lr.ST; cc++) tv += coef[cc] * lr.Bcat[(long long)cc * sp.n + j];
+        t[j] = tv;
+        dot += u[j] * tv;
+      }
+    }
+  }
+  dot = block_sum1(dot, sh);
+  if (threadIdx.x == 0) slot_partials(partials, SLOT_LZ_A)[blockIdx.x] = dot;
+}
+
+__global__ void __launch_bounds__(SDPLR_NT)
+k_lz_step(int n, DevCtrl* __restrict__ c, const double* __restrict__ uprev, const double* __restrict__ u,
+          double* __restrict__ t, DevLowRank lr, double* __restrict__ btx_part, int nb_a,
+          double* __restrict__ alpha_out, double* __restrict__ partials) {
+  __shared__ double sh[8];
+  if (c->lz_done) return;
+  const double gi = c->lz_gamma_cur, gp = c->lz_gamma_prev, be = c->lz_beta_prev;
+  const double al = reduce_partials(slot_partials(partials, SLOT_LZ_A), nb_a, sh) / (gi * gi);  // v'·Av (:484)
+  double nrm = 0.0;
+  double bt[SDPLR_LRMAX];
+#pragma unroll
+  for (int cc = 0; cc < SDPLR_LRMAX; cc++) bt[cc] = 0.0;
+  const int stride = gridDim.x * SDPLR_NT;
+  for (int k = blockIdx.x * SDPLR_NT + threadIdx.x; k < n; k += stride) {
+    const double vi = u[k] / gi, avk = t[k] / gi, vp = uprev[k] / gp;
+    const double r = avk - (al * vi + be * vp);                 // (:486-490)
+    t[k] = r;
+    nrm += r * r;
+#pragma unroll
+    for (int cc = 0; cc < SDPLR_LRMAX; cc++)
+      if (cc < lr.ST) bt[cc] += lr.Bcat[(long long)cc * n + k] * r;
+  }
+  __syncthreads();
+  nrm = block_sum1(nrm, sh);
+  if (threadIdx.x == 0) slot_partials(partials, SLOT_LZ_N)[blockIdx.x] = nrm;
+#pragma unroll
+  for (int cc = 0; cc < SDPLR_LRMAX; cc++)
+    if (cc < lr.ST) {
+      __syncthreads();
+      const double v = block_sum1(bt[cc], sh);
+      if (threadIdx.x == 0) btx_part[(long long)cc * gridDim.x + blockIdx.x] = v;
+    }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    const long long st = c->lz_steps;
+    alpha_out[st] = al;
+    c->lz_steps = st + 1;                                       // iter += 1 (:482)
+  }
+}
