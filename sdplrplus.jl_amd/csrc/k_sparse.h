@@ -211,31 +211,41 @@ k_spmm(DevSparse sp, const double* __restrict__ X, double* __restrict__ Y, int r
   for (long long j = (long long)blockIdx.x * G + threadIdx.x / LPR; j < sp.n; j += total) {
     const int beg = sp.colptr[j], end = sp.colptr[j + 1];
     if (sp.n_long_rows > 0 && end - beg > sp.long_thresh) continue;  // hub row: k_spmm_long
-    for (int ch = lane * VEC; ch < r; ch += LPR * VEC) {
+    for (int chb = 0; chb < r; chb += LPR * VEC) {
+      // all lanes of the group run the loop: the (index, value) pairs of the row are fetched LPR at a time and
+      // handed round with shuffles, eight row gathers in flight per lane (see k_spmm_fast)
+      const int ch = chb + lane * VEC;
+      const bool act = ch < r;
       vecd<VEC> acc;
 #pragma unroll
       for (int k = 0; k < VEC; k++) acc.v[k] = 0.0;
-      int p = beg;
-      for (; p + 4 <= end; p += 4) {  // four independent row gathers in flight
-        const long long i0 = sp.rowval[p], i1 = sp.rowval[p + 1], i2 = sp.rowval[p + 2], i3 = sp.rowval[p + 3];
-        const double v0 = sp.nzval[p], v1 = sp.nzval[p + 1], v2 = sp.nzval[p + 2], v3 = sp.nzval[p + 3];
-        const vecd<VEC> x0 = ldrow<VEC>(X + i0 * r + ch), x1 = ldrow<VEC>(X + i1 * r + ch);
-        const vecd<VEC> x2 = ldrow<VEC>(X + i2 * r + ch), x3 = ldrow<VEC>(X + i3 * r + ch);
+      for (int base = beg; base < end; base += LPR) {
+        const int cnt = min(LPR, end - base);
+        const int my_i = (lane < cnt) ? sp.rowval[base + lane] : 0;
+        const double my_v = (lane < cnt) ? sp.nzval[base + lane] : 0.0;
+        for (int k0 = 0; k0 < cnt; k0 += 8) {
+          vecd<VEC> x[8];
+          double v[8];
 #pragma unroll
-        for (int k = 0; k < VEC; k++) {
-          acc.v[k] += x0.v[k] * v0;
-          acc.v[k] += x1.v[k] * v1;
-          acc.v[k] += x2.v[k] * v2;
-          acc.v[k] += x3.v[k] * v3;
+          for (int q = 0; q < 8; q++) {
+            const int src = min(k0 + q, LPR - 1);
+            const long long i = __shfl(my_i, src, LPR);
+            v[q] = __shfl(my_v, src, LPR);
+            if (act && k0 + q < cnt) {
+              x[q] = ldrow<VEC>(X + i * r + ch);
+            } else {
+#pragma unroll
+              for (int k = 0; k < VEC; k++) x[q].v[k] = 0.0;
+              v[q] = 0.0;
+            }
+          }
+#pragma unroll
+          for (int q = 0; q < 8; q++)
+#pragma unroll
+            for (int k = 0; k < VEC; k++) acc.v[k] += x[q].v[k] * v[q];
         }
       }
-      for (; p < end; p++) {
-        const long long i = sp.rowval[p];
-        const double v = sp.nzval[p];
-        const vecd<VEC> x = ldrow<VEC>(X + i * r + ch);
-#pragma unroll
-        for (int k = 0; k < VEC; k++) acc.v[k] += x.v[k] * v;
-      }
+      if (!act) continue;
       for (int cc = 0; cc < lr.ST; cc++) {
         const double b = lr.Bcat[(long long)cc * sp.n + j];
         const vecd<VEC> w = ldrow<VEC>(WS + (long long)cc * r + ch);
@@ -749,31 +759,47 @@ k_spmm_fast(DevSparse sg, int m, DevFast ff, const double* __restrict__ R, const
   for (long long j = (long long)blockIdx.x * G + threadIdx.x / LPR; j < sg.n; j += total) {
     const int beg = sg.colptr[j], end = sg.colptr[j + 1];
     double rd = 0.0, dd = 0.0;
-    for (int ch = lane * VEC; ch < r; ch += LPR * VEC) {
-      const vecd<VEC> xr = ldrow<VEC>(R + j * r + ch), xd = ldrow<VEC>(D + j * r + ch), xp = ldrow<VEC>(P + j * r + ch);
-      vecd<VEC> w;
+    for (int chb = 0; chb < r; chb += LPR * VEC) {
+      // every lane of the group runs the loop (the index hand-off below is a shuffle); lanes past the row's
+      // end (r not a multiple of LPR·VEC) just do not touch memory
+      const int ch = chb + lane * VEC;
+      const bool act = ch < r;
+      vecd<VEC> xr, xd, xp, w;
 #pragma unroll
-      for (int k = 0; k < VEC; k++) w.v[k] = 0.0;
-      int p = beg;
-      for (; p + 4 <= end; p += 4) {
-        const long long i0 = sg.rowval[p], i1 = sg.rowval[p + 1], i2 = sg.rowval[p + 2], i3 = sg.rowval[p + 3];
-        const double v0 = sg.nzval[p], v1 = sg.nzval[p + 1], v2 = sg.nzval[p + 2], v3 = sg.nzval[p + 3];
-        const vecd<VEC> x0 = ldrow<VEC>(D + i0 * r + ch), x1 = ldrow<VEC>(D + i1 * r + ch);
-        const vecd<VEC> x2 = ldrow<VEC>(D + i2 * r + ch), x3 = ldrow<VEC>(D + i3 * r + ch);
-#pragma unroll
-        for (int k = 0; k < VEC; k++) {
-          w.v[k] += x0.v[k] * v0;
-          w.v[k] += x1.v[k] * v1;
-          w.v[k] += x2.v[k] * v2;
-          w.v[k] += x3.v[k] * v3;
-        }
+      for (int k = 0; k < VEC; k++) xr.v[k] = xd.v[k] = xp.v[k] = w.v[k] = 0.0;
+      if (act) {
+        xr = ldrow<VEC>(R + j * r + ch);
+        xd = ldrow<VEC>(D + j * r + ch);
+        xp = ldrow<VEC>(P + j * r + ch);
       }
-      for (; p < end; p++) {
-        const long long i = sg.rowval[p];
-        const double v = sg.nzval[p];
-        const vecd<VEC> x = ldrow<VEC>(D + i * r + ch);
+      // The row's (index, value) pairs are fetched LPR at a time by the group's lanes and handed round with
+      // shuffles, so the gathers — eight in flight per lane — never wait on an index load: per row the chain is
+      // one index fetch + ⌈len/8⌉ gather rounds instead of ⌈len/4⌉ × (index fetch → gather).
+      for (int base = beg; base < end; base += LPR) {
+        const int cnt = min(LPR, end - base);
+        const int my_i = (lane < cnt) ? sg.rowval[base + lane] : 0;
+        const double my_v = (lane < cnt) ? sg.nzval[base + lane] : 0.0;
+        for (int k0 = 0; k0 < cnt; k0 += 8) {
+          vecd<VEC> x[8];
+          double v[8];
 #pragma unroll
-        for (int k = 0; k < VEC; k++) w.v[k] += x.v[k] * v;
+          for (int q = 0; q < 8; q++) {
+            const int src = min(k0 + q, LPR - 1);
+            const long long i = __shfl(my_i, src, LPR);
+            v[q] = __shfl(my_v, src, LPR);
+            if (act && k0 + q < cnt) {
+              x[q] = ldrow<VEC>(D + i * r + ch);
+            } else {
+#pragma unroll
+              for (int k = 0; k < VEC; k++) x[q].v[k] = 0.0;
+              v[q] = 0.0;
+            }
+          }
+#pragma unroll
+          for (int q = 0; q < 8; q++)
+#pragma unroll
+            for (int k = 0; k < VEC; k++) w.v[k] += x[q].v[k] * v[q];
+        }
       }
 #pragma unroll
       for (int k = 0; k < VEC; k++) {
@@ -782,7 +808,7 @@ k_spmm_fast(DevSparse sg, int m, DevFast ff, const double* __restrict__ R, const
         acc[8] += xp.v[k] * xd.v[k];
         acc[9] += xd.v[k] * w.v[k];
       }
-      strow<VEC>(W + j * r + ch, w);
+      if (act) strow<VEC>(W + j * r + ch, w);
     }
     rd = group_sum<LPR>(rd);
     dd = group_sum<LPR>(dd);
