@@ -111,14 +111,16 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     K, W = max(args.steps, 1), max(args.warmup, 1)
 
-    abi = sj.load_hip()  # no fallback: raises if the HIP library is missing
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("SDPLR_BENCH_FORCE_DIST"):
+        # torch first: its wheel bundles a HIP runtime with the same SONAME as /opt/rocm's, and whichever is
+        # loaded first serves both torch and libsdplr_hip.so — one runtime per process either way
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    abi = sj.load_hip()  # no fallback: raises if the HIP library is missing
     if abi.set_device(local_rank) != 0:
         raise RuntimeError((abi.last_error(None) or b"set_device failed").decode())
 
@@ -209,7 +211,8 @@ def main():
 def reduce_over_ranks(dist, dt, obj, device):
     """max-over-ranks of the timed region and the per-rank objectives — the only collectives of the
     workload (RCCL over xGMI on the GPU node; gloo in tests/test_batch_gloo.py)."""
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+    if dist is None or not dist.is_initialized() or (
+            dist.get_world_size() == 1 and not os.environ.get("SDPLR_BENCH_FORCE_DIST")):
         return dt, [obj]
     import torch
     world = dist.get_world_size()
