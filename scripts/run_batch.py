@@ -28,14 +28,14 @@ def instances():
 
 def main():
     rank, local_rank, world = (int(os.environ.get(k, d)) for k, d in (("RANK", 0), ("LOCAL_RANK", 0), ("WORLD_SIZE", 1)))
-    abi = sj.load_hip()
     dist, device = None, None
-    if world > 1:
+    if world > 1:   # torch before the HIP library: one HIP runtime per process (same SONAME in the torch wheel)
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
         device = torch.device("cuda", local_rank)
         dist.init_process_group("nccl", device_id=device)
+    abi = sj.load_hip()
     assert abi.set_device(local_rank) == 0
     graphs = instances()
     t0 = time.perf_counter()
