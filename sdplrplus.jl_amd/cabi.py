@@ -113,7 +113,10 @@ _HIP: Optional[CABI] = None
 
 
 def hip_library_path() -> str:
-    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libsdplr_hip.so")
+    """lib/libsdplr_hip.so of this package; SDPLR_HIP_LIBRARY names another build of the same HIP library
+    (kernel experiments) — there is no non-HIP backend to point it at."""
+    return os.environ.get("SDPLR_HIP_LIBRARY") or os.path.join(
+        os.path.dirname(os.path.abspath(__file__)), "lib", "libsdplr_hip.so")
 
 
 def load_hip() -> CABI:

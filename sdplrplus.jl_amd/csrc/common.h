@@ -72,9 +72,21 @@ __device__ __forceinline__ double wave_sum(double v) {
 // sum over a sub-wave group of G lanes (G power of two ≤ 64); every lane of the group gets it
 template <int G>
 __device__ __forceinline__ double group_sum(double v) {
+  if constexpr (G == 16) {
+    // a 16-lane group is one DPP row: rotate by 8, 4, 2, 1 (v_mov_b32_dpp row_ror, VALU only).  Lane i adds
+    // the same partners in the same order as the xor butterfly below (after the step of width o the partial
+    // sums have period o), so the result is bit-identical to it — without four trips over the LDS crossbar.
+#define SDPLR_ROR(n)                                                                              \
+    v += __hiloint2double(__builtin_amdgcn_mov_dpp(__double2hiint(v), 0x120 + n, 0xf, 0xf, true),   \
+                          __builtin_amdgcn_mov_dpp(__double2loint(v), 0x120 + n, 0xf, 0xf, true));
+    SDPLR_ROR(8) SDPLR_ROR(4) SDPLR_ROR(2) SDPLR_ROR(1)
+#undef SDPLR_ROR
+    return v;
+  } else {
 #pragma unroll
-  for (int o = G / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+    for (int o = G / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+  }
 }
 
 // block-wide sums of K values; result valid in every thread.  sh must hold K*(NT/64) doubles.

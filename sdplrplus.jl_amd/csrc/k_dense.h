@@ -230,23 +230,37 @@ k_lbfgs_dir(const DevCtrl* __restrict__ c, FactorArena A, long long N, int h, in
   double desc = 0.0;
   const long long N2 = N >> 1;
   const long long stride = (long long)gridDim.x * SDPLR_NT;
+  // Slot pointers for the HM unrolled positions: positions k ≥ h reuse a valid slot with a zero coefficient,
+  // so that every load of a trip is unconditional and the compiler issues all 2·HM + 1 of them back to back
+  // (with `if (k < h)` around the loads hipcc waited for each pair before issuing the next: a chain of memory
+  // round trips per trip instead of one).
+  const double* yp[HM];
+  const double* sp_[HM];
+#pragma unroll
+  for (int k = 0; k < HM; k++) {
+    const int slot = (k < h) ? order[k] : 0;
+    yp[k] = (h > 0) ? aslot(A, as_y0(A) + slot) : G;
+    sp_[k] = (h > 0) ? aslot(A, AS_S0 + slot) : G;
+  }
   for (long long i = (long long)blockIdx.x * SDPLR_NT + threadIdx.x; i < N2; i += stride) {
     const double2 g = ldnt2(G, i);
+    double2 yv[HM], sv[HM];
+#pragma unroll
+    for (int k = 0; k < HM; k++) {
+      yv[k] = ldnt2(yp[k], i);
+      sv[k] = ldnt2(sp_[k], i);
+    }
     double2 r = g;
 #pragma unroll
-    for (int k = 0; k < HM; k++)  // newest → oldest: q −= α y   (:94-102)
-      if (k < h) {
-        const double2 y = ldnt2(aslot(A, as_y0(A) + order[k]), i);
-        r.x -= ca[k] * y.x;
-        r.y -= ca[k] * y.y;
-      }
+    for (int k = 0; k < HM; k++) {  // newest → oldest: q −= α y   (:94-102); ca = 0 beyond h
+      r.x -= ca[k] * yv[k].x;
+      r.y -= ca[k] * yv[k].y;
+    }
 #pragma unroll
-    for (int k = HM - 1; k >= 0; k--)  // oldest → newest: r += γ s  (:104-113)
-      if (k < h) {
-        const double2 s = ldnt2(aslot(A, AS_S0 + order[k]), i);
-        r.x += cg[k] * s.x;
-        r.y += cg[k] * s.y;
-      }
+    for (int k = HM - 1; k >= 0; k--) {  // oldest → newest: r += γ s  (:104-113); cg = 0 beyond h
+      r.x += cg[k] * sv[k].x;
+      r.y += cg[k] * sv[k].y;
+    }
     double2 d;
     d.x = sgn * r.x;
     d.y = sgn * r.y;
@@ -332,34 +346,47 @@ k_lbfgs_update(const DevCtrl* __restrict__ c, FactorArena A, long long N, int h,
   for (int k = 0; k < 5 * HM; k++) acc[k] = 0.0;
   const long long N2 = N >> 1;
   const long long stride = (long long)gridDim.x * SDPLR_NT;
+  // all 2·HM + 2 loads of a trip are unconditional (slots l ≥ h alias slot 0 and are masked out of the sums):
+  // see k_lbfgs_dir
+  const double* slp[HM];
+  const double* ylp[HM];
+#pragma unroll
+  for (int l = 0; l < HM; l++) {
+    const int slot = (l < h) ? l : 0;
+    slp[l] = aslot(A, AS_S0 + slot);
+    ylp[l] = aslot(A, as_y0(A) + slot);
+  }
   for (long long i = (long long)blockIdx.x * SDPLR_NT + threadIdx.x; i < N2; i += stride) {
     const double2 g = ldnt2(G, i);
+    const double2 d = ldnt2(dir, i);
+    double2 sv[HM], yv[HM];
+#pragma unroll
+    for (int l = 0; l < HM; l++) {
+      sv[l] = ldnt2(slp[l], i);
+      yv[l] = ldnt2(ylp[l], i);
+    }
     double2 sn, yn;
+    sn.x = sn.y = yn.x = yn.y = 0.0;
+#pragma unroll
+    for (int l = 0; l < HM; l++)   // the stored s_j, y_j (y_j holds −G_old, written by lbfgs_dir!)
+      if (l == j) {
+        sn = sv[l];
+        yn = yv[l];
+      }
     if (UPDATE) {
-      const double2 d = ldnt2(dir, i);
       sn.x = alpha * d.x;  // BLAS.scal!(stepsize, dir)  (:142)
       sn.y = alpha * d.y;
+      yn.x += g.x;         // axpy!(1, grad, y_j)  (:145)
+      yn.y += g.y;
       reinterpret_cast<double2*>(dir)[i] = sn;
       reinterpret_cast<double2*>(Sj)[i] = sn;  // copy!(s_j, dir)  (:143)
-      const double2 yo = ldnt2(Yj, i);
-      yn.x = yo.x + g.x;  // axpy!(1, grad, y_j)  (:145)
-      yn.y = yo.y + g.y;
       reinterpret_cast<double2*>(Yj)[i] = yn;
-    } else {
-      sn = ldnt2(Sj, i);
-      yn = ldnt2(Yj, i);
     }
 #pragma unroll
     for (int l = 0; l < HM; l++)
       if (l < h) {
-        double2 sl, yl;
-        if (l == j) {
-          sl = sn;
-          yl = yn;
-        } else {
-          sl = ldnt2(aslot(A, AS_S0 + l), i);
-          yl = ldnt2(aslot(A, as_y0(A) + l), i);
-        }
+        const double2 sl = (l == j) ? sn : sv[l];
+        const double2 yl = (l == j) ? yn : yv[l];
         acc[0 * HM + l] += sn.x * yl.x + sn.y * yl.y;
         acc[1 * HM + l] += sl.x * yn.x + sl.y * yn.y;
         acc[2 * HM + l] += yn.x * yl.x + yn.y * yl.y;

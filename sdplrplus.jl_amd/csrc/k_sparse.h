@@ -841,6 +841,263 @@ k_spmm_fast(DevSparse sg, int m, DevFast ff, const double* __restrict__ R, const
   }
 }
 
+// ---- column-sweep form of k_spmm_fast --------------------------------------------------------------------
+// A sub-wave group owns a tile of K consecutive rows.  The tile's nonzeros are stored sorted by COLUMN
+// (entry = local row << 27 | column, value), so every group walks its list from column 0 to column n−1, and
+// since the lists are equally long on average all the groups resident on the chip read the same narrow band
+// of D at the same time: the band lives in the XCD's 4 MiB L2 instead of each row gather going out to the
+// Infinity Cache (a uniformly random gather keeps only 4 MiB / |D| of its rows in L2).  The K partial rows
+// live in LDS (private to the group, read-modify-write in list order, so the sums are formed in the same
+// order as in k_spmm_fast — per row by increasing column — and W is bit-identical).  One list per group
+// also removes the per-row pointer → index → gather dependency chain: the next index chunk is fetched
+// while the current gathers are in flight.
+#define SDPLR_TILE_COLBITS 24
+#ifndef SDPLR_TILE_WIN
+#define SDPLR_TILE_WIN 4
+#endif
+#ifndef SDPLR_TILE_EXP
+#define SDPLR_TILE_EXP 0
+#endif
+struct DevTile {
+  int K, n_tiles;        // K = most rows in any tile
+  const int* row0;       // [n_tiles + 1] first row of each tile
+  const int* ptr;        // [n_tiles + 1]
+  const int* ent;        // local row << 27 | column
+  const double* val;
+};
+
+// value held by lane `src` (0 ≤ src < LPR, constant after unrolling) of the caller's LPR-lane group
+template <int LPR>
+__device__ __forceinline__ int group_bcast(int v, int src) {
+  if constexpr (LPR == 16) {  // the group is one DPP row: v_mov_b32_dpp row_newbcast, no LDS crossbar
+    switch (src) {
+#define SDPLR_BC(i) case i: return __builtin_amdgcn_mov_dpp(v, 0x150 + i, 0xf, 0xf, true);
+      SDPLR_BC(0) SDPLR_BC(1) SDPLR_BC(2) SDPLR_BC(3) SDPLR_BC(4) SDPLR_BC(5) SDPLR_BC(6) SDPLR_BC(7)
+      SDPLR_BC(8) SDPLR_BC(9) SDPLR_BC(10) SDPLR_BC(11) SDPLR_BC(12) SDPLR_BC(13) SDPLR_BC(14)
+#undef SDPLR_BC
+      default: return __builtin_amdgcn_mov_dpp(v, 0x150 + 15, 0xf, 0xf, true);
+    }
+  } else {
+    return __shfl(v, src, LPR);
+  }
+}
+template <int LPR>
+__device__ __forceinline__ double group_bcast(double v, int src) {
+  return __hiloint2double(group_bcast<LPR>(__double2hiint(v), src), group_bcast<LPR>(__double2loint(v), src));
+}
+
+template <int LPR, int VEC>
+__global__ void __launch_bounds__(SDPLR_NT, 4)
+k_spmm_tile(DevTile tl, int n, int m, DevFast ff, const double* __restrict__ R, const double* __restrict__ D,
+            const double* __restrict__ P, double* __restrict__ W, int r, const double* __restrict__ lam,
+            const double* __restrict__ pv_raw, double* __restrict__ A_RD, double* __restrict__ A_DD,
+            double* __restrict__ partials, const DevCtrl* __restrict__ c, int check_done) {
+  // [G][K+1][LPR·VEC] partial rows, [G][K][2] row dots, [G][8] line-search sums
+  extern __shared__ double tile_lds[];
+  __shared__ double sh[10 * (SDPLR_NT / 64)];
+  if (check_done && c->done) return;
+  constexpr int G = SDPLR_NT / LPR;
+  constexpr int RW = LPR * VEC;
+  const int lane = threadIdx.x % LPR, grp = threadIdx.x / LPR;
+  const int K = tl.K;
+  // row k of this group: rows + k·RW; row K is a dump for the ring slots past the end of the list
+  double* rows = tile_lds + (size_t)grp * (K + 1) * RW + lane * VEC;
+  double* dots = tile_lds + (size_t)G * (K + 1) * RW + (size_t)grp * K * 2;
+  double* ls = tile_lds + (size_t)G * (K + 1) * RW + (size_t)G * K * 2 + (size_t)grp * 8;  // per group
+  const double sigma = c->sigma;
+  double pd = 0.0, dw = 0.0;  // ⟨P,D⟩, ⟨D,W⟩
+  for (int k = lane; k < 8; k += LPR) ls[k] = 0.0;
+  for (long long tile = (long long)blockIdx.x * G + grp; tile < tl.n_tiles; tile += (long long)gridDim.x * G) {
+    const int beg = tl.ptr[tile], end = tl.ptr[tile + 1];
+    const long long j0 = tl.row0[tile];
+    const int nrows = tl.row0[tile + 1] - (int)j0;
+    for (int k = lane; k < K; k += LPR) dots[2 * k] = dots[2 * k + 1] = 0.0;
+    __builtin_amdgcn_wave_barrier();
+    for (int chb = 0; chb < r; chb += RW) {
+      const int ch = chb + lane * VEC;
+      const bool act = ch < r;
+      for (int k = 0; k < K; k++)
+#pragma unroll
+        for (int q = 0; q < VEC; q++) rows[k * RW + q] = 0.0;
+      // (ce, cv): the list chunk being consumed, one entry per lane; (ne, nv): the chunk after it.  A ring of
+      // WIN row gathers stays in flight: as soon as entry t has been folded into its LDS row, the gather of
+      // entry t + WIN takes its slot, so the memory pipe never drains between batches.
+      // The loop body is branch-free and as short as it can be made — at four entries per wave instruction
+      // its VALU issue, not memory, was the limit: the host pads every list to a multiple of LPR with dump
+      // entries (so no validity tests), the column sits in the low 24 bits of the entry (v_mad_u32_u24 reads
+      // just those: byte offset = column·row bytes + channel bytes, 32 bits, added to the uniform base by
+      // the load itself), and for LPR = 16 the hand-offs are DPP row broadcasts, not LDS-crossbar shuffles.
+      constexpr int WIN = LPR < SDPLR_TILE_WIN ? LPR : SDPLR_TILE_WIN;
+      const unsigned rowb = (unsigned)r * 8u, chb8 = (unsigned)(act ? ch : 0) * 8u;
+      const char* Db = reinterpret_cast<const char*>(D);
+      const int dump = (K << SDPLR_TILE_COLBITS) | (int)j0;  // row K of the group's LDS rows is a dump
+      int ce = tl.ent[beg + lane], ne = tl.ent[beg + LPR + lane];
+      double cv = tl.val[beg + lane], nv = tl.val[beg + LPR + lane];
+      vecd<VEC> x[WIN];
+      double* fold[WIN];  // LDS row the slot's gather will be added to
+#pragma unroll
+      for (int q = 0; q < WIN; q++) {
+        int e = group_bcast<LPR>(ce, q);
+        e = (beg < end) ? e : dump;
+        fold[q] = rows + ((unsigned)e >> SDPLR_TILE_COLBITS) * (unsigned)RW;
+        x[q] = ldrow<VEC>(reinterpret_cast<const double*>(Db + (__umul24((unsigned)e, rowb) + chb8)));
+      }
+      // enter the loop with nothing but the ring outstanding: the compiler's wait-count merge at the loop
+      // header is then exact instead of falling back to vmcnt(0) on every trip
+      __builtin_amdgcn_sched_barrier(0);
+#if SDPLR_TILE_EXP == 3   /* experiment: no main loop */
+      for (int base = beg; base < beg; base += LPR) {
+#else
+      for (int base = beg; base < end; base += LPR) {
+#endif
+        const bool more = base + LPR < end;
+        // the chunk after next, fetched first so that by the time it is rotated in (a register copy, which
+        // must wait for the load) a whole chunk of gathers has been issued behind it and nothing drains
+        // (the arrays carry 2·64 entries of tail padding, so this never reads past their end)
+        const int fe = tl.ent[base + 2 * LPR + lane];
+        const double fv = tl.val[base + 2 * LPR + lane];
+#pragma unroll
+        for (int k0 = 0; k0 < LPR; k0 += WIN) {
+#pragma unroll
+          for (int q = 0; q < WIN; q++) {
+            // fold one …  (an LDS atomic add without return, ds_add_f64: the LDS unit applies a wave's adds in
+            // issue order and each lane owns its addresses, so the sum is formed in list order exactly as a
+            // read-add-write would form it, but the wave never waits for it)
+            const double v = group_bcast<LPR>(cv, k0 + q);
+#if SDPLR_TILE_EXP == 1   /* experiment: no LDS fold */
+#pragma unroll
+            for (int k = 0; k < VEC; k++) pd += x[q].v[k] * v;
+#else
+#pragma unroll
+            for (int k = 0; k < VEC; k++)
+              (void)__hip_atomic_fetch_add(fold[q] + k, x[q].v[k] * v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#endif
+            // … refill one
+            int e2;
+            if (k0 + WIN < LPR) {
+              e2 = group_bcast<LPR>(ce, (k0 + WIN + q) % LPR);
+            } else {
+              e2 = group_bcast<LPR>(ne, q);
+              e2 = more ? e2 : dump;   // past the end of the list: nothing to gather
+            }
+            fold[q] = rows + ((unsigned)e2 >> SDPLR_TILE_COLBITS) * (unsigned)RW;
+#if SDPLR_TILE_EXP == 2   /* experiment: no gathers */
+#pragma unroll
+            for (int k = 0; k < VEC; k++) x[q].v[k] = (double)e2;
+#else
+            x[q] = ldrow<VEC>(reinterpret_cast<const double*>(Db + (__umul24((unsigned)e2, rowb) + chb8)));
+#endif
+            __builtin_amdgcn_sched_barrier(0);  // no clustering of the refills behind the folds
+          }
+        }
+        ce = ne;
+        cv = nv;
+        ne = fe;
+        nv = fv;
+      }
+      // the tile's rows, four at a time (one memory round trip for twelve row loads, eight interleaved group
+      // sums): W out, row dots, ⟨P,D⟩ and ⟨D,W⟩ partials.  Loads are clamped, not predicated.
+#if SDPLR_TILE_EXP == 4   /* experiment: no epilogue */
+      for (int k = 0; k < 0; k += 4) {
+#else
+      for (int k = 0; k < nrows; k += 4) {
+#endif
+        vecd<VEC> xr[4], xd[4], xp[4], w[4];
+        const long long chs = act ? ch : 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          const long long j = j0 + min(k + i, nrows - 1);
+          xr[i] = ldrow<VEC>(R + j * r + chs);
+          xd[i] = ldrow<VEC>(D + j * r + chs);
+          xp[i] = ldrow<VEC>(P + j * r + chs);
+#pragma unroll
+          for (int q = 0; q < VEC; q++) w[i].v[q] = rows[min(k + i, nrows - 1) * RW + q];
+        }
+        double rd[4], dd[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          const bool ok = act && k + i < nrows;
+          if (ok) strow<VEC>(W + (j0 + k + i) * r + ch, w[i]);
+          rd[i] = dd[i] = 0.0;
+          double tp = 0.0, tw = 0.0;
+#pragma unroll
+          for (int q = 0; q < VEC; q++) {
+            rd[i] += xr[i].v[q] * xd[i].v[q];
+            dd[i] += xd[i].v[q] * xd[i].v[q];
+            tp += xp[i].v[q] * xd[i].v[q];
+            tw += xd[i].v[q] * w[i].v[q];
+          }
+          rd[i] = ok ? rd[i] : 0.0;
+          dd[i] = ok ? dd[i] : 0.0;
+          pd += ok ? tp : 0.0;
+          dw += ok ? tw : 0.0;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          rd[i] = group_sum<LPR>(rd[i]);
+          dd[i] = group_sum<LPR>(dd[i]);
+        }
+        if (lane == 0) {
+#pragma unroll
+          for (int i = 0; i < 4; i++)
+            if (k + i < nrows) {
+              dots[2 * (k + i)] += rd[i];
+              dots[2 * (k + i) + 1] += dd[i];
+            }
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+    // the constraints attached to the tile's rows, one lane per row; their line-search sums are reduced over
+    // the group and kept in LDS (8 doubles per group), not in registers the gather ring needs
+    double t8[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) t8[k] = 0.0;
+    for (int k = lane; k < nrows; k += LPR) {
+      const long long j = j0 + k;
+      const double rd = dots[2 * k], dd = dots[2 * k + 1];
+      const int e0 = ff.drow_ptr[j], e1 = ff.drow_ptr[j + 1];
+      for (int e = e0; e < e1; e++) {
+        const int gid = ff.drow_gid[e];
+        const double v = ff.drow_val[e];
+        const double q1 = v * (rd + rd), q2 = v * dd;
+        A_RD[gid] = q1;
+        A_DD[gid] = q2;
+        if (gid < m) {
+          const double l = lam[gid], nq0 = pv_raw[gid];
+          t8[0] += l * nq0;
+          t8[1] += nq0 * nq0;
+          t8[2] += l * q1;
+          t8[3] += nq0 * q1;
+          t8[4] += (l - sigma * nq0) * q2;
+          t8[5] += q1 * q1;
+          t8[6] += q1 * q2;
+          t8[7] += q2 * q2;
+        }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 8; k++) t8[k] = group_sum<LPR>(t8[k]);
+    if (lane == 0) {
+#pragma unroll
+      for (int k = 0; k < 8; k++) ls[k] += t8[k];
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  double acc[10];
+#pragma unroll
+  for (int k = 0; k < 8; k++) acc[k] = (lane == 0) ? ls[k] : 0.0;
+  acc[8] = pd;
+  acc[9] = dw;
+  block_sum<10>(acc, sh);
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int k = 0; k < 8; k++) slot_partials(partials, SLOT_LS + k)[blockIdx.x] = acc[k];
+    slot_partials(partials, SLOT_PD)[blockIdx.x] = acc[8];
+    slot_partials(partials, SLOT_DW)[blockIdx.x] = acc[9];
+  }
+}
+
 // ---- hub rows: one block per row of the full pattern with more than long_thresh nonzeros ------------------
 // Same result as k_spmm for those rows (which k_spmm skips): the row's nonzeros are dealt round-robin to the
 // block's sub-wave groups, the group partials are added in group order (deterministic).  Partials of the

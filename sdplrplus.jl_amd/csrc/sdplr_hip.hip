@@ -70,6 +70,10 @@ struct sdplr_hip_solver {
   DevFast ff{};
   DevSparse sp_fast{};       // sp with the segmented-reduction plan restricted to the diagonal-only matrices
   DevSparse spg{};           // the general matrix A_g alone, as a symmetric CSR with fixed values
+  DevTile tile{};            // the same matrix as column-sorted K-row tiles (k_spmm_tile)
+  int nb_tile = 0;
+  bool use_tile = false;
+  int tile_lpr = 0;          // the lists are padded to multiples of this sub-wave width
   bool fast_singleton = false;   // every diagonal-only matrix has exactly one entry (k_sparse.h, singleton form)
   const int* extra_slots = nullptr;  // slots not attached to a row: A_g and the low-rank matrices
   int n_extra = 0;
@@ -282,6 +286,7 @@ int alloc_factors(S* s) {
   if (const char* e = getenv("SDPLR_HIP_NB_UPD")) s->nb_upd = std::max(1, std::min(atoi(e), SDPLR_MAXNB));
   s->nb_sddmm = blocks_for(s->nnzT, G, 8192);
   s->nb_spmm = blocks_for(s->n, G, 768);  // + up to 256 hub-row blocks share the partial slot
+  s->nb_tile = blocks_for(s->tile.n_tiles, G, 1024);
   return SDPLR_OK;
 }
 
@@ -616,6 +621,54 @@ int32_t sdplr_hip_finalize(S* s) {
       if ((rc = upload(s, &sg.colptr, g_ptr))) return rc;
       if ((rc = upload(s, &sg.rowval, g_col))) return rc;
       { const double* gv = nullptr; if ((rc = upload(s, &gv, g_val))) return rc; sg.nzval = const_cast<double*>(gv); }
+      // column-sorted K-row tiles of A_g for k_spmm_tile; K is chosen so that one tile per sub-wave group
+      // fills the chip once (≈1024 resident blocks), which keeps every group's sweep in phase
+      if (n < (1LL << SDPLR_TILE_COLBITS) && getenv("SDPLR_HIP_NO_TILE") == nullptr) {
+        choose_shape(s);
+        const int G = SDPLR_NT / s->LPR;
+        // tiles of ⌊n/T⌋ or ⌈n/T⌉ consecutive rows; T fills 1024 blocks (4 per CU) exactly when that keeps a
+        // tile within 8 rows, so every CU carries the same number of equally long lists
+        int64_t nt = std::min<int64_t>(n, 1024LL * G);
+        if ((n + nt - 1) / nt > 8) nt = (n + 7) / 8;
+        if (const char* e = getenv("SDPLR_HIP_TILE_K")) { const int kk = std::max(1, std::min(atoi(e), 8)); nt = (n + kk - 1) / kk; }
+        std::vector<int> t_row(nt + 1), t_ptr(nt + 1, 0), t_ent;
+        for (int64_t t = 0; t <= nt; t++) t_row[t] = (int)((t * n) / nt);
+        int K = 1;
+        for (int64_t t = 0; t < nt; t++) K = std::max(K, t_row[t + 1] - t_row[t]);
+        // every list is padded to a multiple of LPR with (dump row K, column = the tile's first row, value 0)
+        // entries, and the arrays end with 2·64 more entries so that the kernel's look-ahead stays in bounds
+        const int L = s->LPR;
+        std::vector<double> t_val;
+        t_ent.reserve(g_col.size() + (size_t)nt * L / 2 + 128);
+        t_val.reserve(g_col.size() + (size_t)nt * L / 2 + 128);
+        std::vector<std::pair<int, int>> tmp;  // (column, position in the CSR)
+        std::vector<int> rowof;
+        for (int64_t t = 0; t < nt; t++) {
+          const int64_t r0 = t_row[t], r1 = t_row[t + 1];
+          const int b = g_ptr[r0], e = g_ptr[r1];
+          tmp.clear();
+          for (int q = b; q < e; q++) tmp.push_back({g_col[q], q});
+          std::sort(tmp.begin(), tmp.end());  // by column, then by CSR position (= by row)
+          int64_t row = r0;
+          rowof.assign(e - b, 0);
+          for (int q = b; q < e; q++) { while (q >= g_ptr[row + 1]) row++; rowof[q - b] = (int)(row - r0); }
+          for (int q = 0; q < e - b; q++) {
+            t_ent.push_back((rowof[tmp[q].second - b] << SDPLR_TILE_COLBITS) | tmp[q].first);
+            t_val.push_back(g_val[tmp[q].second]);
+          }
+          while (t_ent.size() % L) { t_ent.push_back((K << SDPLR_TILE_COLBITS) | (int)r0); t_val.push_back(0.0); }
+          t_ptr[t + 1] = (int)t_ent.size();
+        }
+        for (int q = 0; q < 128; q++) { t_ent.push_back(0); t_val.push_back(0.0); }
+        s->tile_lpr = L;
+        if ((rc = upload(s, &s->tile.row0, t_row))) return rc;
+        s->tile.K = K;
+        s->tile.n_tiles = (int)nt;
+        if ((rc = upload(s, &s->tile.ptr, t_ptr))) return rc;
+        if ((rc = upload(s, &s->tile.ent, t_ent))) return rc;
+        if ((rc = upload(s, &s->tile.val, t_val))) return rc;
+        s->use_tile = true;
+      }
       s->ff.gid_g = s->h_gids[kg];
       if ((rc = upload(s, &s->ff.diagpos, diagpos))) return rc;
       if ((rc = upload(s, &s->ff.drow_ptr, d_ptr))) return rc;
@@ -1099,12 +1152,17 @@ void enq_iteration_fast2(S* s) {
   enq_lbfgs_dir(s, 1, 1, 1);                                                          // :197-205
   {
     ProfScope ps(s, "spmm_W");   // W = A_g·D + row dots + line-search sums of the row-attached constraints
-    LV_DISPATCH((k_spmm_fast<LPR, VEC><<<s->nb_spmm, SDPLR_NT, 0, s->stream>>>(s->spg, (int)s->m, s->ff, R, D, P, W, (int)s->r, s->lambda, s->pv_raw, s->A_RD, s->A_DD, s->partials, s->ctrl, 1)))
+    if (s->use_tile && s->tile_lpr == s->LPR && s->n * s->r * 8 < (1LL << 32)) {
+      const size_t lds = ((size_t)SDPLR_NT * s->VEC * (s->tile.K + 1) + (size_t)(SDPLR_NT / s->LPR) * (2 * s->tile.K + 8)) * sizeof(double);
+      LV_DISPATCH((k_spmm_tile<LPR, VEC><<<s->nb_tile, SDPLR_NT, lds, s->stream>>>(s->tile, (int)s->n, (int)s->m, s->ff, R, D, P, W, (int)s->r, s->lambda, s->pv_raw, s->A_RD, s->A_DD, s->partials, s->ctrl, 1)))
+    } else {
+      LV_DISPATCH((k_spmm_fast<LPR, VEC><<<s->nb_spmm, SDPLR_NT, 0, s->stream>>>(s->spg, (int)s->m, s->ff, R, D, P, W, (int)s->r, s->lambda, s->pv_raw, s->A_RD, s->A_DD, s->partials, s->ctrl, 1)))
+    }
   }
   enq_lowrank(s, R, D, 2, 2, s->A_RD, s->A_DD, 1);
   {
     ProfScope ps(s, "ls_solve_fast");
-    k_ls_solve_fast<<<1, SDPLR_NT, 0, s->stream>>>(s->ctrl, (int)s->m, s->ff.gid_g, s->n_extra, s->extra_slots, s->nb_spmm, s->A_RD, s->A_DD, s->lambda, s->lambda_ub, s->pv_raw, s->pv_lb, s->pv, s->y, s->lr.ST, (int)s->r, s->lr.col_gid, s->lr.Dcat, s->lr_W, s->lr_WS, s->partials, 1);
+    k_ls_solve_fast<<<1, SDPLR_NT, 0, s->stream>>>(s->ctrl, (int)s->m, s->ff.gid_g, s->n_extra, s->extra_slots, (s->use_tile && s->tile_lpr == s->LPR && s->n * s->r * 8 < (1LL << 32)) ? s->nb_tile : s->nb_spmm, s->A_RD, s->A_DD, s->lambda, s->lambda_ub, s->pv_raw, s->pv_lb, s->pv, s->y, s->lr.ST, (int)s->r, s->lr.col_gid, s->lr.Dcat, s->lr_W, s->lr_WS, s->partials, 1);
   }
   // (a variant fusing this step kernel with lbfgs_update! was measured at 111 µs against 38 + 59 µs for the
   // two kernels — 166 VGPRs and scratch — and dropped)
