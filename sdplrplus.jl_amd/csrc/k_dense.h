@@ -50,18 +50,19 @@ __device__ __forceinline__ void stnt2(double* p, long long i, double2 v) {
 __host__ __device__ __forceinline__ double* aslot(const FactorArena& A, int k) { return A.base + (long long)k * A.stride; }
 __host__ __device__ __forceinline__ int as_y0(const FactorArena& A) { return AS_S0 + A.h; }  // y_j at as_y0(A) + j
 
-// ---- two-loop coefficients from the Gram data (one thread, Gram data staged in LDS) -----------------
+// ---- two-loop coefficients from the Gram data (one thread, control block staged in LDS) -------------
 // Mirrors src/lbfgs.jl:93-113 step by step; j runs newest → oldest, then oldest → newest.
-struct GramLds {
-  double SY[SDPLR_HMAX * SDPLR_HMAX], YY[SDPLR_HMAX * SDPLR_HMAX];
-  double Sg[SDPLR_HMAX], Yg[SDPLR_HMAX], rho[SDPLR_HMAX];
+struct SeamLds {
+  DevCtrl c;                              // the whole control block: one coalesced load, one coalesced store
   double red[5 * SDPLR_HMAX];
   double nrm[2];                          // Σ‖G‖² partials, Σ‖pv‖² partials
   double al[SDPLR_HMAX], ga[SDPLR_HMAX];  // two-loop work arrays: in LDS so that dynamic indexing
   int order[SDPLR_HMAX];                  // does not fall back to scratch memory
 };
-__device__ inline void lbfgs_coefficients(DevCtrl* c, GramLds& gd, int h, int latest) {
+static_assert(sizeof(DevCtrl) % 8 == 0, "DevCtrl is copied as 8-byte words");
+__device__ inline void lbfgs_coefficients(SeamLds& gd, int h, int latest) {
   if (h == 0) return;
+  DevCtrl& c = gd.c;
   int* order = gd.order;
   double *al = gd.al, *ga = gd.ga;
   int j = latest - 1;  // 0-based newest
@@ -71,23 +72,75 @@ __device__ inline void lbfgs_coefficients(DevCtrl* c, GramLds& gd, int h, int la
   }
   for (int i = 0; i < h; i++) {  // α_j = ρ_j ⟨s_j, q⟩,  q = G − Σ_{newer l} α_l y_l
     const int jj = order[i];
-    double sq = gd.Sg[jj];
-    for (int k = 0; k < i; k++) sq -= al[order[k]] * gd.SY[jj * SDPLR_HMAX + order[k]];
-    al[jj] = gd.rho[jj] * sq;
+    double sq = c.Sg[jj];
+    for (int k = 0; k < i; k++) sq -= al[order[k]] * c.SY[jj * SDPLR_HMAX + order[k]];
+    al[jj] = c.rho[jj] * sq;
   }
   for (int i = h - 1; i >= 0; i--) {  // β_j = ρ_j ⟨y_j, r⟩,  r = q + Σ_{older l} γ_l s_l
     const int jj = order[i];
-    double yr = gd.Yg[jj];
-    for (int k = 0; k < h; k++) yr -= al[order[k]] * gd.YY[jj * SDPLR_HMAX + order[k]];
-    for (int k = h - 1; k > i; k--) yr += ga[order[k]] * gd.SY[order[k] * SDPLR_HMAX + jj];
-    const double beta = gd.rho[jj] * yr;
+    double yr = c.Yg[jj];
+    for (int k = 0; k < h; k++) yr -= al[order[k]] * c.YY[jj * SDPLR_HMAX + order[k]];
+    for (int k = h - 1; k > i; k--) yr += ga[order[k]] * c.SY[order[k] * SDPLR_HMAX + jj];
+    const double beta = c.rho[jj] * yr;
     ga[jj] = al[jj] - beta;      // γ = a − β  (:107)
   }
   for (int l = 0; l < h; l++) {
-    c->a[l] = al[l];             // lbfgshis.vecs[j].a[] = α  (:97)
-    c->c_alpha[l] = al[l];
-    c->c_gamma[l] = ga[l];
+    c.a[l] = al[l];              // lbfgshis.vecs[j].a[] = α  (:97)
+    c.c_alpha[l] = al[l];
+    c.c_gamma[l] = ga[l];
   }
+}
+
+// the serial part of the seam, on the LDS copy of the control block (thread 0)
+__device__ inline void seam_serial(SeamLds& gd, int h, int jfixed, int fin_mode, int do_loop, int do_coeff,
+                                   bool fin, bool norms) {
+  DevCtrl& c = gd.c;
+  int latest = c.latest;
+  if (fin) {
+    const int j = (fin_mode == 1) ? (latest % h) : jfixed;
+    for (int l = 0; l < h; l++) {
+      c.SY[j * SDPLR_HMAX + l] = gd.red[0 * SDPLR_HMAX + l];
+      if (l != j) c.SY[l * SDPLR_HMAX + j] = gd.red[1 * SDPLR_HMAX + l];
+      c.YY[j * SDPLR_HMAX + l] = gd.red[2 * SDPLR_HMAX + l];
+      c.YY[l * SDPLR_HMAX + j] = gd.red[2 * SDPLR_HMAX + l];
+      c.Sg[l] = gd.red[3 * SDPLR_HMAX + l];
+      c.Yg[l] = gd.red[4 * SDPLR_HMAX + l];
+    }
+    if (fin_mode == 1) {
+      c.rho[j] = 1.0 / c.SY[j * SDPLR_HMAX + j];
+      latest = j + 1;
+      c.latest = latest;
+      c.gram_pending = 0;
+    }
+  }
+  if (norms) {
+    const double g = sqrt(gd.nrm[0]), pn = sqrt(gd.nrm[1] + c.pv2_extra);
+    c.gnorm = c.grel ? g / c.normC : g;
+    c.pvnorm = c.prel ? pn / c.normb : pn;
+    c.norms_pending = 0;
+  }
+  if (do_loop) {
+    if (c.done) return;
+    if (c.reldelta_exit) {                            // :238-241 (after g! and the norms)
+      c.reldelta_exit = 0;
+      c.done = 1;
+      c.exit_reason = EXIT_RELDELTA;
+      return;
+    }
+    if (c.iters > 0 && c.iters >= c.max_iters) {      // :272-277 (checked after the update)
+      c.done = 1;
+      c.exit_reason = EXIT_ITERS;
+      return;
+    }
+    if (!(c.gnorm > c.cur_gtol)) {                    // :190
+      c.done = 1;
+      c.exit_reason = EXIT_GTOL;
+      return;
+    }
+    c.iters += 1;
+    c.lastval = c.L;
+  }
+  if (do_coeff) lbfgs_coefficients(gd, h, latest);
 }
 
 // The seam between two inner iterations, one block of 1024 threads:
@@ -97,103 +150,66 @@ __device__ inline void lbfgs_coefficients(DevCtrl* c, GramLds& gd, int h, int la
 //  2. do_loop: the loop tests of src/sdplr.jl:272-277 and :190, localiter += 1, lastval = ℒ (:207);
 //  3. do_coeff: the two-loop coefficients of the next direction.
 // Each of the 5h sums is reduced by one wave (lanes stride the per-block partials, fixed order).
+// The control block is staged through LDS whole (one coalesced load while the partials are being summed,
+// one coalesced store at the end): the serial part then runs on LDS latencies, not on a dozen dependent
+// global round trips.
 __global__ void __launch_bounds__(1024)
 k_lbfgs_boundary(DevCtrl* __restrict__ c, int h, int jfixed, int fin_mode, int do_loop, int do_coeff,
                  int nb_partials, const double* __restrict__ partials) {
-  __shared__ GramLds gd;
+  __shared__ SeamLds gd;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const bool fin = (fin_mode == 2) || (fin_mode == 1 && c->gram_pending);
-  const bool norms = c->norms_pending != 0;
+  // Everything this kernel reads from global memory is requested in one go — the flags, the control block
+  // and the partials (summed whether or not the flags will want them) — so the kernel pays one memory round
+  // trip, not flag → count → partials.
+  const int gp = c->gram_pending, np = c->norms_pending;
+  {
+    const unsigned long long* src = reinterpret_cast<const unsigned long long*>(c);
+    unsigned long long* dst = reinterpret_cast<unsigned long long*>(&gd.c);
+    for (int t = tid; t < (int)(sizeof(DevCtrl) / 8); t += 1024) dst[t] = src[t];
+  }
+  if (wave >= 14) {  // ‖G‖², ‖pv‖² of the iteration that just ended (src/sdplr.jl:224-234): waves 14 and 15
+    const int nbp = (wave == 14) ? c->nb_gnorm : c->nb_pvnorm;   // ≤ 1024 on every path
+    const double* p = slot_partials(partials, wave == 14 ? SLOT_GNORM2 : SLOT_PVNORM2);
+    double v[16];
+#pragma unroll
+    for (int u = 0; u < 16; u++) v[u] = p[lane + 64 * u];        // the slot arrays hold SDPLR_MAXNB entries
+    double t = 0.0;
+#pragma unroll
+    for (int u = 0; u < 16; u++) t += (lane + 64 * u < nbp) ? v[u] : 0.0;
+    for (int i = lane + 1024; i < nbp; i += 64) t += p[i];
+    t = wave_sum(t);
+    if (lane == 0) gd.nrm[wave - 14] = t;
+  } else if (fin_mode != 0) {  // the 5h Gram sums, two per wave and trip
+    for (int s0 = wave; s0 < 5 * h; s0 += 28) {
+      const int s1 = s0 + 14;
+      const bool two = s1 < 5 * h;
+      const double* pa = slot_partials(partials, SLOT_GRAM + (s0 / h) * SDPLR_HMAX + s0 % h);
+      const double* pb = two ? slot_partials(partials, SLOT_GRAM + (s1 / h) * SDPLR_HMAX + s1 % h) : pa;
+      double ta = 0.0, tb = 0.0;
+#pragma unroll 8
+      for (int i = lane; i < nb_partials; i += 64) {
+        ta += pa[i];
+        tb += pb[i];
+      }
+      ta = wave_sum(ta);
+      tb = wave_sum(tb);
+      if (lane == 0) {
+        gd.red[(s0 / h) * SDPLR_HMAX + s0 % h] = ta;
+        if (two) gd.red[(s1 / h) * SDPLR_HMAX + s1 % h] = tb;
+      }
+    }
+  }
+  const bool fin = (fin_mode == 2) || (fin_mode == 1 && gp);
+  const bool norms = np != 0;
   if (!fin && !do_coeff && !do_loop && !norms) return;
-  if (norms) {  // ‖G‖², ‖pv‖² of the iteration that just ended (src/sdplr.jl:224-234): waves 14 and 15
-    if (wave >= 14) {
-      const int nbp = (wave == 14) ? c->nb_gnorm : c->nb_pvnorm;
-      const double* p = slot_partials(partials, wave == 14 ? SLOT_GNORM2 : SLOT_PVNORM2);
-      double t = 0.0;
-      for (int i = lane; i < nbp; i += 64) t += p[i];
-      t = wave_sum(t);
-      if (lane == 0) gd.nrm[wave - 14] = t;
-    }
-  }
-  for (int t = tid; t < SDPLR_HMAX * SDPLR_HMAX; t += 1024) {
-    gd.SY[t] = c->SY[t];
-    gd.YY[t] = c->YY[t];
-  }
-  if (tid < SDPLR_HMAX) {
-    gd.Sg[tid] = c->Sg[tid];
-    gd.Yg[tid] = c->Yg[tid];
-    gd.rho[tid] = c->rho[tid];
-  }
-  int latest = c->latest;
-  if (fin) {
-    for (int sidx = wave; sidx < 5 * h; sidx += 16) {
-      const int q = sidx / h, l = sidx % h;
-      const double* p = slot_partials(partials, SLOT_GRAM + q * SDPLR_HMAX + l);
-      double t = 0.0;
-      for (int i = lane; i < nb_partials; i += 64) t += p[i];
-      t = wave_sum(t);
-      if (lane == 0) gd.red[q * SDPLR_HMAX + l] = t;
-    }
-  }
   __syncthreads();
-  if (tid == 0 && fin) {
-    const int j = (fin_mode == 1) ? (latest % h) : jfixed;
-    for (int l = 0; l < h; l++) {
-      gd.SY[j * SDPLR_HMAX + l] = gd.red[0 * SDPLR_HMAX + l];
-      if (l != j) gd.SY[l * SDPLR_HMAX + j] = gd.red[1 * SDPLR_HMAX + l];
-      gd.YY[j * SDPLR_HMAX + l] = gd.red[2 * SDPLR_HMAX + l];
-      gd.YY[l * SDPLR_HMAX + j] = gd.red[2 * SDPLR_HMAX + l];
-      gd.Sg[l] = gd.red[3 * SDPLR_HMAX + l];
-      gd.Yg[l] = gd.red[4 * SDPLR_HMAX + l];
-    }
-    if (fin_mode == 1) {
-      gd.rho[j] = 1.0 / gd.SY[j * SDPLR_HMAX + j];
-      latest = j + 1;
-      c->latest = latest;
-      c->gram_pending = 0;
-    }
-  }
+  if (tid == 0) seam_serial(gd, h, jfixed, fin_mode, do_loop, do_coeff, fin, norms);
   __syncthreads();
-  if (fin) {  // write the Gram data back (coalesced)
-    for (int t = tid; t < SDPLR_HMAX * SDPLR_HMAX; t += 1024) {
-      c->SY[t] = gd.SY[t];
-      c->YY[t] = gd.YY[t];
-    }
-    if (tid < SDPLR_HMAX) {
-      c->Sg[tid] = gd.Sg[tid];
-      c->Yg[tid] = gd.Yg[tid];
-      c->rho[tid] = gd.rho[tid];
-    }
+  {
+    const unsigned long long* src = reinterpret_cast<const unsigned long long*>(&gd.c);
+    unsigned long long* dst = reinterpret_cast<unsigned long long*>(c);
+    for (int t = tid; t < (int)(sizeof(DevCtrl) / 8); t += 1024) dst[t] = src[t];
   }
-  if (tid != 0) return;
-  if (norms) {
-    const double g = sqrt(gd.nrm[0]), pn = sqrt(gd.nrm[1] + c->pv2_extra);
-    c->gnorm = c->grel ? g / c->normC : g;
-    c->pvnorm = c->prel ? pn / c->normb : pn;
-    c->norms_pending = 0;
-  }
-  if (do_loop) {
-    if (c->done) return;
-    if (c->reldelta_exit) {                            // :238-241 (after g! and the norms)
-      c->reldelta_exit = 0;
-      c->done = 1;
-      c->exit_reason = EXIT_RELDELTA;
-      return;
-    }
-    if (c->iters > 0 && c->iters >= c->max_iters) {  // :272-277 (checked after the update)
-      c->done = 1;
-      c->exit_reason = EXIT_ITERS;
-      return;
-    }
-    if (!(c->gnorm > c->cur_gtol)) {                  // :190
-      c->done = 1;
-      c->exit_reason = EXIT_GTOL;
-      return;
-    }
-    c->iters += 1;
-    c->lastval = c->L;
-  }
-  if (do_coeff) lbfgs_coefficients(c, gd, h, (fin && fin_mode == 1) ? latest : c->latest);
 }
 
 // ---- direction: dir = ∓(G − Σ α_l y_l + Σ γ_l s_l); y_next = −G; partial ⟨dir, G⟩ -----------------
@@ -204,7 +220,7 @@ __global__ void __launch_bounds__(SDPLR_NT)
 k_lbfgs_dir(const DevCtrl* __restrict__ c, FactorArena A, long long N, int h, int negate,
             int check_done, double* __restrict__ partials) {
   __shared__ double sh[8];
-  if (check_done && c->done) return;
+  const int dn = check_done ? c->done : 0;  // fetched with the coefficients, tested before the first pass
   const double* G = aslot(A, AS_G);
   double* dir = aslot(A, AS_D);
   const int latest = c->latest;
@@ -227,6 +243,7 @@ k_lbfgs_dir(const DevCtrl* __restrict__ c, FactorArena A, long long N, int h, in
   }
   double* ynext = (h > 0) ? aslot(A, as_y0(A) + (latest % h)) : nullptr;
   const double sgn = negate ? -1.0 : 1.0;
+  if (dn) return;
   double desc = 0.0;
   const long long N2 = N >> 1;
   const long long stride = (long long)gridDim.x * SDPLR_NT;
@@ -298,8 +315,9 @@ __global__ void __launch_bounds__(SDPLR_NT)
 k_descent(DevCtrl* __restrict__ c, FactorArena A, long long N, int nb_partials, int apply,
           int check_done, const double* __restrict__ partials) {
   __shared__ double sh[8];
-  if (check_done && c->done) return;
+  const int dn = check_done ? c->done : 0;  // in flight together with the partials
   const double desc = reduce_partials(slot_partials(partials, SLOT_DESCENT), nb_partials, sh);
+  if (dn) return;
   if (blockIdx.x == 0 && threadIdx.x == 0) c->descent = desc;
   if (!apply) return;
   if (!(isnan(desc) || desc >= 0.0)) return;
@@ -334,9 +352,10 @@ __global__ void __launch_bounds__(SDPLR_NT, HM <= 4 ? 4 : (HM <= 8 ? 2 : 1))
 k_lbfgs_update(const DevCtrl* __restrict__ c, FactorArena A, long long N, int h, int jfixed,
                int check_done, double* __restrict__ partials) {
   __shared__ double sh[5 * HM * (SDPLR_NT / 64)];
-  if (check_done && (c->done || c->reldelta_exit)) return;  // :239-241 breaks before lbfgs_update!
+  const int dn = check_done ? (c->done | c->reldelta_exit) : 0;  // :239-241 breaks before lbfgs_update!
   const int j = UPDATE ? (c->latest % h) : jfixed;
   const double alpha = c->alpha;
+  if (dn) return;  // (all four scalars were requested together)
   const double* G = aslot(A, AS_G);
   double* dir = aslot(A, AS_D);
   double* Sj = aslot(A, AS_S0 + j);

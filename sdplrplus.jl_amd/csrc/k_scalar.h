@@ -451,7 +451,11 @@ k_ls_solve_fast(DevCtrl* __restrict__ c, int m, int gid_g, int n_extra, const in
                 const double* __restrict__ lr_D, double* __restrict__ lrW, double* __restrict__ lrWS,
                 const double* __restrict__ partials, int check_done) {
   __shared__ double sh[10 * (SDPLR_NT / 64)];
-  if (check_done && c->done) return;
+  const int dn = check_done ? c->done : 0;
+  // every scalar the serial part needs, requested up front: their latency overlaps the partial sums below
+  // instead of forming a chain of dependent global round trips in thread 0
+  const double sigma = c->sigma, obj0 = c->obj, amax = c->alpha_max, last = c->lastval, feps = c->fprec_eps;
+  const double rd_m = A_RD[m], dd_m = A_DD[m];
   double s[10];
 #pragma unroll
   for (int k = 0; k < 10; k++) s[k] = 0.0;
@@ -461,17 +465,18 @@ k_ls_solve_fast(DevCtrl* __restrict__ c, int m, int gid_g, int n_extra, const in
     s[8] += slot_partials(partials, SLOT_PD)[i];
     s[9] += slot_partials(partials, SLOT_DW)[i];
   }
+  if (dn) return;
   block_sum<10>(s, sh);
   __shared__ double sh_alpha;
   __shared__ int sh_err;
   if (threadIdx.x == 0) {
-    const double sigma = c->sigma;
-    A_RD[gid_g] = s[8] + s[8];   // ⟨A_g, RDᵀ+DRᵀ⟩ = 2⟨P, D⟩
-    A_DD[gid_g] = s[9];          // ⟨A_g, DDᵀ⟩ = ⟨D, W⟩
+    const double g_rd = s[8] + s[8], g_dd = s[9];
+    A_RD[gid_g] = g_rd;   // ⟨A_g, RDᵀ+DRᵀ⟩ = 2⟨P, D⟩
+    A_DD[gid_g] = g_dd;   // ⟨A_g, DDᵀ⟩ = ⟨D, W⟩
     for (int t = 0; t < n_extra; t++) {
       const int k = extra[t];
       if (k >= m) continue;
-      const double l = lam[k], nq0 = pv_raw[k], q1 = A_RD[k], q2 = A_DD[k];
+      const double l = lam[k], nq0 = pv_raw[k], q1 = (k == gid_g) ? g_rd : A_RD[k], q2 = (k == gid_g) ? g_dd : A_DD[k];
       s[0] += l * nq0;
       s[1] += nq0 * nq0;
       s[2] += l * q1;
@@ -481,7 +486,7 @@ k_ls_solve_fast(DevCtrl* __restrict__ c, int m, int gid_g, int n_extra, const in
       s[6] += q1 * q2;
       s[7] += q2 * q2;
     }
-    const double p0 = c->obj, p1 = A_RD[m], p2 = A_DD[m];
+    const double p0 = obj0, p1 = (gid_g == m) ? g_rd : rd_m, p2 = (gid_g == m) ? g_dd : dd_m;
     double bq[5];
     bq[0] = p0 - s[0] + sigma * s[1] / 2;
     bq[1] = p1 - s[2] + sigma * s[3];
@@ -490,7 +495,7 @@ k_ls_solve_fast(DevCtrl* __restrict__ c, int m, int gid_g, int n_extra, const in
     bq[4] = sigma * s[7] / 2;
     for (int k = 0; k < 5; k++) c->biquad[k] = bq[k];
     double a = 0.0, f = bq[0];
-    const int rc = quartic_argmin(bq, c->alpha_max, &a, &f);
+    const int rc = quartic_argmin(bq, amax, &a, &f);
     sh_err = rc;
     sh_alpha = a;
     if (rc != 0) {
@@ -499,14 +504,14 @@ k_ls_solve_fast(DevCtrl* __restrict__ c, int m, int gid_g, int n_extra, const in
     } else {
       c->alpha = a;
       c->L = f;
-      const double last = c->lastval;
       const double rel_delta = (last - f) / fmax(1.0, fmax(fabs(f), fabs(last)));
-      c->reldelta_exit = (rel_delta < c->fprec_eps) ? 1 : 0;
+      c->reldelta_exit = (rel_delta < feps) ? 1 : 0;
       // commit of the extra slots
       double pv2 = 0.0;
       for (int t = 0; t < n_extra; t++) {
         const int k = extra[t];
-        const double v = pv_raw[k] + a * (a * A_DD[k] + A_RD[k]);
+        const double q1 = (k == gid_g) ? g_rd : A_RD[k], q2 = (k == gid_g) ? g_dd : A_DD[k];
+        const double v = pv_raw[k] + a * (a * q2 + q1);
         pv_raw[k] = v;
         if (k == m) {
           c->obj = v;

@@ -666,13 +666,27 @@ k_fast_step2(int n, int m, DevFast ff, double* __restrict__ R, const double* __r
              const double* __restrict__ WS, double* __restrict__ partials, DevCtrl* __restrict__ c,
              int check_done) {
   __shared__ double sh[2 * (SDPLR_NT / 64)];
-  if (check_done && c->done) return;
+  // the flag is fetched together with the scalars and the first row, and tested before anything is stored:
+  // one memory round trip at the head of the kernel instead of three
+  const int dn = check_done ? c->done : 0;
   constexpr int G = SDPLR_NT / LPR;
   const int lane = threadIdx.x % LPR;
   const long long total = (long long)gridDim.x * G;
   const double a = c->alpha, sigma = c->sigma, yg = yvec[ff.gid_g];
   double red[2] = {0.0, 0.0};  // ‖G‖², ‖pv‖² (row-attached slots)
+  const int ch0 = lane * VEC;
   for (long long j = (long long)blockIdx.x * G + threadIdx.x / LPR; j < n; j += total) {
+    // the row's first chunk is requested before the (dependent) walk over its constraints
+    vecd<VEC> x0, p0, d0, w0;
+#pragma unroll
+    for (int k = 0; k < VEC; k++) x0.v[k] = p0.v[k] = d0.v[k] = w0.v[k] = 0.0;
+    if (ch0 < r) {
+      x0 = ldrow<VEC>(R + j * r + ch0);
+      p0 = ldrow<VEC>(P + j * r + ch0);
+      d0 = ldrow<VEC>(D + j * r + ch0);
+      w0 = ldrow<VEC>(W + j * r + ch0);
+    }
+    if (dn) return;
     double dj = 0.0;
     for (int e = ff.drow_ptr[j]; e < ff.drow_ptr[j + 1]; e++) {  // every lane of the group: same values
       const int k = ff.drow_gid[e];
@@ -699,9 +713,14 @@ k_fast_step2(int n, int m, DevFast ff, double* __restrict__ R, const double* __r
         const int k = ff.drow_gid[e];
         pv_raw[k] = pv_raw[k] + a * (a * A_DD[k] + A_RD[k]);
       }
-    for (int ch = lane * VEC; ch < r; ch += LPR * VEC) {
-      vecd<VEC> x = ldrow<VEC>(R + j * r + ch), pp = ldrow<VEC>(P + j * r + ch);
-      const vecd<VEC> d = ldrow<VEC>(D + j * r + ch), w = ldrow<VEC>(W + j * r + ch);
+    for (int ch = ch0; ch < r; ch += LPR * VEC) {
+      vecd<VEC> x = x0, pp = p0, d = d0, w = w0;
+      if (ch != ch0) {
+        x = ldrow<VEC>(R + j * r + ch);
+        pp = ldrow<VEC>(P + j * r + ch);
+        d = ldrow<VEC>(D + j * r + ch);
+        w = ldrow<VEC>(W + j * r + ch);
+      }
       vecd<VEC> g;
 #pragma unroll
       for (int k = 0; k < VEC; k++) {
@@ -895,7 +914,7 @@ k_spmm_tile(DevTile tl, int n, int m, DevFast ff, const double* __restrict__ R, 
   // [G][K+1][LPR·VEC] partial rows, [G][K][2] row dots, [G][8] line-search sums
   extern __shared__ double tile_lds[];
   __shared__ double sh[10 * (SDPLR_NT / 64)];
-  if (check_done && c->done) return;
+  const int dn = check_done ? c->done : 0;  // tested below, once the first tile's pointers are on their way
   constexpr int G = SDPLR_NT / LPR;
   constexpr int RW = LPR * VEC;
   const int lane = threadIdx.x % LPR, grp = threadIdx.x / LPR;
@@ -911,6 +930,7 @@ k_spmm_tile(DevTile tl, int n, int m, DevFast ff, const double* __restrict__ R, 
     const int beg = tl.ptr[tile], end = tl.ptr[tile + 1];
     const long long j0 = tl.row0[tile];
     const int nrows = tl.row0[tile + 1] - (int)j0;
+    if (dn) return;
     for (int k = lane; k < K; k += LPR) dots[2 * k] = dots[2 * k + 1] = 0.0;
     __builtin_amdgcn_wave_barrier();
     for (int chb = 0; chb < r; chb += RW) {

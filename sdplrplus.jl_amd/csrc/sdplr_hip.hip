@@ -71,7 +71,7 @@ struct sdplr_hip_solver {
   DevSparse sp_fast{};       // sp with the segmented-reduction plan restricted to the diagonal-only matrices
   DevSparse spg{};           // the general matrix A_g alone, as a symmetric CSR with fixed values
   DevTile tile{};            // the same matrix as column-sorted K-row tiles (k_spmm_tile)
-  int nb_tile = 0;
+  int nb_tile = 0, nb_step = 1;
   bool use_tile = false;
   int tile_lpr = 0;          // the lists are padded to multiples of this sub-wave width
   bool fast_singleton = false;   // every diagonal-only matrix has exactly one entry (k_sparse.h, singleton form)
@@ -287,6 +287,8 @@ int alloc_factors(S* s) {
   s->nb_sddmm = blocks_for(s->nnzT, G, 8192);
   s->nb_spmm = blocks_for(s->n, G, 768);  // + up to 256 hub-row blocks share the partial slot
   s->nb_tile = blocks_for(s->tile.n_tiles, G, 1024);
+  s->nb_step = blocks_for(s->n, G, 2048);
+  if (const char* e = getenv("SDPLR_HIP_NB_STEP")) s->nb_step = std::max(1, std::min(atoi(e), SDPLR_MAXNB));
   return SDPLR_OK;
 }
 
@@ -1168,7 +1170,7 @@ void enq_iteration_fast2(S* s) {
   // two kernels — 166 VGPRs and scratch — and dropped)
   {
     ProfScope ps(s, "fast_step");                                                     // :219-234
-    LV_DISPATCH((k_fast_step2<LPR, VEC><<<s->nb_spmm, SDPLR_NT, 0, s->stream>>>((int)s->n, (int)s->m, s->ff, R, D, P, W, G, (int)s->r, s->y, s->lambda, s->lambda_ub, s->pv_raw, s->pv_lb, s->pv, s->A_RD, s->A_DD, s->lr, s->lr_WS, s->partials, s->ctrl, 1)))
+    LV_DISPATCH((k_fast_step2<LPR, VEC><<<s->nb_step, SDPLR_NT, 0, s->stream>>>((int)s->n, (int)s->m, s->ff, R, D, P, W, G, (int)s->r, s->y, s->lambda, s->lambda_ub, s->pv_raw, s->pv_lb, s->pv, s->A_RD, s->A_DD, s->lr, s->lr_WS, s->partials, s->ctrl, 1)))
   }
   enq_lbfgs_update(s, 1);                                                             // :244-246
 }
