@@ -74,6 +74,9 @@ struct sdplr_hip_solver {
   int nb_tile = 0, nb_step = 1;
   bool use_tile = false;
   int tile_lpr = 0;          // the lists are padded to multiples of this sub-wave width
+  std::vector<int> h_gptr, h_gcol;   // host CSR of A_g (kept: the tiles are rebuilt when the rank changes)
+  std::vector<double> h_gval;
+  std::vector<void*> tile_allocs;
   bool fast_singleton = false;   // every diagonal-only matrix has exactly one entry (k_sparse.h, singleton form)
   const int* extra_slots = nullptr;  // slots not attached to a row: A_g and the low-rank matrices
   int n_extra = 0;
@@ -264,6 +267,68 @@ void choose_shape(S* s) {
   while (lpr < need && lpr < 64) lpr <<= 1;
   s->LPR = lpr;
   s->HM = s->h <= 4 ? 4 : (s->h <= 8 ? 8 : 16);
+}
+
+// Column-sorted row tiles of A_g for k_spmm_tile (k_sparse.h), from the host copy of its CSR.  Tiles are
+// ⌊n/T⌋ or ⌈n/T⌉ consecutive rows; T fills 1024 blocks (4 per CU) exactly when that keeps a tile within 8
+// rows, so every CU carries the same number of equally long lists and all sweeps stay in phase.  Every list is
+// padded to a multiple of the sub-wave width with (dump row K, column = the tile's first row, value 0) entries,
+// and the arrays end with 2·64 more entries so that the kernel's look-ahead stays in bounds.
+int build_tiles(S* s) {
+  const int64_t n = s->n;
+  for (void* p : s->tile_allocs) {
+    (void)hipFree(p);
+    s->allocs.erase(std::remove(s->allocs.begin(), s->allocs.end(), p), s->allocs.end());
+  }
+  s->tile_allocs.clear();
+  s->use_tile = false;
+  s->tile = DevTile{};
+  if (s->h_gptr.empty() || n >= (1LL << SDPLR_TILE_COLBITS) || getenv("SDPLR_HIP_NO_TILE") != nullptr) return SDPLR_OK;
+  const std::vector<int>&g_ptr = s->h_gptr, &g_col = s->h_gcol;
+  const std::vector<double>& g_val = s->h_gval;
+  choose_shape(s);
+  const int G = SDPLR_NT / s->LPR, L = s->LPR;
+  int64_t nt = std::min<int64_t>(n, 1024LL * G);
+  if ((n + nt - 1) / nt > 8) nt = (n + 7) / 8;
+  if (const char* e = getenv("SDPLR_HIP_TILE_K")) { const int kk = std::max(1, std::min(atoi(e), 8)); nt = (n + kk - 1) / kk; }
+  std::vector<int> t_row(nt + 1), t_ptr(nt + 1, 0), t_ent;
+  for (int64_t t = 0; t <= nt; t++) t_row[t] = (int)((t * n) / nt);
+  int K = 1;
+  for (int64_t t = 0; t < nt; t++) K = std::max(K, t_row[t + 1] - t_row[t]);
+  std::vector<double> t_val;
+  t_ent.reserve(g_col.size() + (size_t)nt * L / 2 + 128);
+  t_val.reserve(g_col.size() + (size_t)nt * L / 2 + 128);
+  std::vector<std::pair<int, int>> tmp;  // (column, position in the CSR)
+  std::vector<int> rowof;
+  for (int64_t t = 0; t < nt; t++) {
+    const int64_t r0 = t_row[t], r1 = t_row[t + 1];
+    const int b = g_ptr[r0], e = g_ptr[r1];
+    tmp.clear();
+    for (int q = b; q < e; q++) tmp.push_back({g_col[q], q});
+    std::sort(tmp.begin(), tmp.end());  // by column, then by CSR position (= by row)
+    int64_t row = r0;
+    rowof.assign(e - b, 0);
+    for (int q = b; q < e; q++) { while (q >= g_ptr[row + 1]) row++; rowof[q - b] = (int)(row - r0); }
+    for (int q = 0; q < e - b; q++) {
+      t_ent.push_back((rowof[tmp[q].second - b] << SDPLR_TILE_COLBITS) | tmp[q].first);
+      t_val.push_back(g_val[tmp[q].second]);
+    }
+    while (t_ent.size() % L) { t_ent.push_back((K << SDPLR_TILE_COLBITS) | (int)r0); t_val.push_back(0.0); }
+    t_ptr[t + 1] = (int)t_ent.size();
+  }
+  for (int q = 0; q < 128; q++) { t_ent.push_back(0); t_val.push_back(0.0); }
+  int rc;
+  const size_t first = s->allocs.size();
+  if ((rc = upload(s, &s->tile.row0, t_row))) return rc;
+  if ((rc = upload(s, &s->tile.ptr, t_ptr))) return rc;
+  if ((rc = upload(s, &s->tile.ent, t_ent))) return rc;
+  if ((rc = upload(s, &s->tile.val, t_val))) return rc;
+  s->tile_allocs.assign(s->allocs.begin() + first, s->allocs.end());
+  s->tile.K = K;
+  s->tile.n_tiles = (int)nt;
+  s->tile_lpr = L;
+  s->use_tile = true;
+  return SDPLR_OK;
 }
 
 int alloc_factors(S* s) {
@@ -623,54 +688,10 @@ int32_t sdplr_hip_finalize(S* s) {
       if ((rc = upload(s, &sg.colptr, g_ptr))) return rc;
       if ((rc = upload(s, &sg.rowval, g_col))) return rc;
       { const double* gv = nullptr; if ((rc = upload(s, &gv, g_val))) return rc; sg.nzval = const_cast<double*>(gv); }
-      // column-sorted K-row tiles of A_g for k_spmm_tile; K is chosen so that one tile per sub-wave group
-      // fills the chip once (≈1024 resident blocks), which keeps every group's sweep in phase
-      if (n < (1LL << SDPLR_TILE_COLBITS) && getenv("SDPLR_HIP_NO_TILE") == nullptr) {
-        choose_shape(s);
-        const int G = SDPLR_NT / s->LPR;
-        // tiles of ⌊n/T⌋ or ⌈n/T⌉ consecutive rows; T fills 1024 blocks (4 per CU) exactly when that keeps a
-        // tile within 8 rows, so every CU carries the same number of equally long lists
-        int64_t nt = std::min<int64_t>(n, 1024LL * G);
-        if ((n + nt - 1) / nt > 8) nt = (n + 7) / 8;
-        if (const char* e = getenv("SDPLR_HIP_TILE_K")) { const int kk = std::max(1, std::min(atoi(e), 8)); nt = (n + kk - 1) / kk; }
-        std::vector<int> t_row(nt + 1), t_ptr(nt + 1, 0), t_ent;
-        for (int64_t t = 0; t <= nt; t++) t_row[t] = (int)((t * n) / nt);
-        int K = 1;
-        for (int64_t t = 0; t < nt; t++) K = std::max(K, t_row[t + 1] - t_row[t]);
-        // every list is padded to a multiple of LPR with (dump row K, column = the tile's first row, value 0)
-        // entries, and the arrays end with 2·64 more entries so that the kernel's look-ahead stays in bounds
-        const int L = s->LPR;
-        std::vector<double> t_val;
-        t_ent.reserve(g_col.size() + (size_t)nt * L / 2 + 128);
-        t_val.reserve(g_col.size() + (size_t)nt * L / 2 + 128);
-        std::vector<std::pair<int, int>> tmp;  // (column, position in the CSR)
-        std::vector<int> rowof;
-        for (int64_t t = 0; t < nt; t++) {
-          const int64_t r0 = t_row[t], r1 = t_row[t + 1];
-          const int b = g_ptr[r0], e = g_ptr[r1];
-          tmp.clear();
-          for (int q = b; q < e; q++) tmp.push_back({g_col[q], q});
-          std::sort(tmp.begin(), tmp.end());  // by column, then by CSR position (= by row)
-          int64_t row = r0;
-          rowof.assign(e - b, 0);
-          for (int q = b; q < e; q++) { while (q >= g_ptr[row + 1]) row++; rowof[q - b] = (int)(row - r0); }
-          for (int q = 0; q < e - b; q++) {
-            t_ent.push_back((rowof[tmp[q].second - b] << SDPLR_TILE_COLBITS) | tmp[q].first);
-            t_val.push_back(g_val[tmp[q].second]);
-          }
-          while (t_ent.size() % L) { t_ent.push_back((K << SDPLR_TILE_COLBITS) | (int)r0); t_val.push_back(0.0); }
-          t_ptr[t + 1] = (int)t_ent.size();
-        }
-        for (int q = 0; q < 128; q++) { t_ent.push_back(0); t_val.push_back(0.0); }
-        s->tile_lpr = L;
-        if ((rc = upload(s, &s->tile.row0, t_row))) return rc;
-        s->tile.K = K;
-        s->tile.n_tiles = (int)nt;
-        if ((rc = upload(s, &s->tile.ptr, t_ptr))) return rc;
-        if ((rc = upload(s, &s->tile.ent, t_ent))) return rc;
-        if ((rc = upload(s, &s->tile.val, t_val))) return rc;
-        s->use_tile = true;
-      }
+      // host copy of A_g's CSR: the column-sweep tiles depend on the sub-wave width, i.e. on the rank, and are
+      // rebuilt by reset_rank
+      s->h_gptr = g_ptr; s->h_gcol = g_col; s->h_gval = g_val;
+      if ((rc = build_tiles(s))) return rc;
       s->ff.gid_g = s->h_gids[kg];
       if ((rc = upload(s, &s->ff.diagpos, diagpos))) return rc;
       if ((rc = upload(s, &s->ff.drow_ptr, d_ptr))) return rc;
@@ -738,8 +759,9 @@ int32_t sdplr_hip_reset_rank(S* s, int64_t new_r) {
   for (int k = 0; k < 2; k++)
     if (s->graph_exec[k]) { (void)hipGraphExecDestroy(s->graph_exec[k]); s->graph_exec[k] = nullptr; }
   s->r = new_r;
-  int rc = alloc_factors(s);
+  int rc = s->fast ? build_tiles(s) : SDPLR_OK;
   if (rc) return rc;
+  if ((rc = alloc_factors(s))) return rc;
   const int64_t m = s->m;
   HIPCK(s, hipMemsetAsync(s->lambda, 0, std::max<int64_t>(m, 1) * sizeof(double), s->stream));
   HIPCK(s, hipMemsetAsync(s->pv, 0, std::max<int64_t>(m, 1) * sizeof(double), s->stream));

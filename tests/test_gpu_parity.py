@@ -430,6 +430,69 @@ def test_code_paths_agree(hip_abi, oracle_abi, family, toggles, monkeypatch):
     assert np.all(np.abs(np.array(base[:3]) - np.array(ora[:3])) <= (1e-6 if armijo else 1e-8) * scale) and rel(Rb, Ro) < 10 * tolR
 
 
+@pytest.mark.parametrize("r,n,p,tile_k", [
+    (1, 90, 0.2, None), (2, 90, 0.2, None), (3, 64, 0.3, 4), (5, 70, 0.3, None), (8, 120, 0.1, 8),
+    (16, 150, 0.1, 3), (27, 150, 0.1, None), (32, 400, 0.05, 8), (32, 1000, 0.02, None), (48, 200, 0.1, 5),
+    (64, 130, 0.2, 8), (100, 90, 0.3, 2), (128, 70, 0.3, None), (200, 60, 0.4, 7),
+])
+def test_column_sweep_tiles_match_row_kernel(hip_abi, oracle_abi, r, n, p, tile_k, monkeypatch):
+    """W = A_g·D on the singleton fast path has two forms: one sub-wave group per row (k_spmm_fast) and the
+    column-sweep tiles (k_spmm_tile: K-row tiles, column-sorted padded lists, LDS-resident partial rows).
+    Both fold a row's products in increasing column order, so R after 12 iterations must agree to round-off of
+    the line-search scalars only — for every sub-wave shape (LPR, VEC), ragged ranks, multi-chunk rows
+    (r > 128), forced tile heights, tiles with empty lists (isolated vertices) — and match the CPU oracle."""
+    rng = np.random.Generator(np.random.PCG64(1000 + r))
+    A = problems.make_random_graph(n, p, rng)
+    while A.nnz == 0:
+        A = problems.make_random_graph(n, p, rng)
+    data = problems.maxcut_data(A)
+    normC, normb = data.normC(), float(np.linalg.norm(data.b))
+
+    def run(abi):
+        s_, _ = make_solver(abi, data, r, seed=5)
+        st = s_.fg(normC, normb)
+        out = s_.inner_loop(normC, normb, True, True, False, 0.0, -1e300, 12, 0.0, *st)
+        R = s_.Rt
+        s_.close()
+        return out, R
+
+    if tile_k is not None:
+        monkeypatch.setenv("SDPLR_HIP_TILE_K", str(tile_k))
+    tile, Rt_ = run(hip_abi)
+    monkeypatch.setenv("SDPLR_HIP_NO_TILE", "1")
+    rowk, Rr = run(hip_abi)
+    ora, Ro = run(oracle_abi)
+    assert tile[4] == rowk[4] == ora[4] == 12
+    assert np.allclose(tile[:3], rowk[:3], rtol=1e-10, atol=1e-12) and rel(Rt_, Rr) < 1e-10
+    assert np.allclose(tile[:3], ora[:3], rtol=1e-8, atol=1e-10) and rel(Rt_, Ro) < 1e-8
+
+
+def test_column_sweep_tiles_survive_rank_update(hip_abi, oracle_abi):
+    """rank_update! (src/coreop.jl:518-526) changes the sub-wave width the tile lists are padded for: the
+    library rebuilds them in reset_rank, and the iterations after the rank change still match the oracle."""
+    from sdplrplus_jl_amd import cabi
+    A = problems.gnp_graph(300, 0.05, 77)
+    data = problems.maxcut_data(A)
+    normC, normb = data.normC(), float(np.linalg.norm(data.b))
+    outs = []
+    for abi in (hip_abi, oracle_abi):
+        s_, _ = make_solver(abi, data, 8, seed=5)
+        st = s_.fg(normC, normb)
+        s_.inner_loop(normC, normb, True, True, False, 0.0, -1e300, 5, 0.0, *st)
+        s_.reset_rank(24)                      # LPR 4 → 16
+        R0 = 2.0 * np.random.Generator(np.random.PCG64(9)).random((data.n, 24)) - 1.0
+        s_.set_vec(cabi.V_B, data.b)
+        s_.set_factor(cabi.F_RT, R0)
+        s_.lbfgs_clear()
+        st = s_.fg(normC, normb)
+        out = s_.inner_loop(normC, normb, True, True, False, 0.0, -1e300, 10, 0.0, *st)
+        outs.append((out, s_.Rt))
+        s_.close()
+    (g, Rg), (o, Ro) = outs
+    assert g[4] == o[4] == 10
+    assert np.allclose(g[:3], o[:3], rtol=1e-8, atol=1e-10) and rel(Rg, Ro) < 1e-8
+
+
 def test_lanczos_paths_agree(hip_abi, monkeypatch):
     data, C, As, bs = make_data("minimum_bisection", 6, 60, 0.2)
     g, _ = make_solver(hip_abi, data, 4, seed=3)
