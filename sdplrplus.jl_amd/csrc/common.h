@@ -55,6 +55,8 @@ struct DevCtrl {
   // ---- L-BFGS (src/lbfgs.jl:4-28) ----
   int latest;          // 1-based, as in the reference
   int gram_pending;    // set by k_lbfgs_update, consumed by k_lbfgs_boundary
+  int fallback;        // set by the seam kernel: the coming direction is not a descent direction (src/sdplr.jl:202)
+  int pad_;
   double rho[SDPLR_HMAX], a[SDPLR_HMAX];
   double c_alpha[SDPLR_HMAX], c_gamma[SDPLR_HMAX];   // two-loop coefficients of the current direction
   double SY[SDPLR_HMAX * SDPLR_HMAX];                // SY[a][b] = ⟨s_a, y_b⟩

@@ -93,7 +93,7 @@ __device__ inline void lbfgs_coefficients(SeamLds& gd, int h, int latest) {
 
 // the serial part of the seam, on the LDS copy of the control block (thread 0)
 __device__ inline void seam_serial(SeamLds& gd, int h, int jfixed, int fin_mode, int do_loop, int do_coeff,
-                                   bool fin, bool norms) {
+                                   bool fin, bool norms, int desc_mode) {
   DevCtrl& c = gd.c;
   int latest = c.latest;
   if (fin) {
@@ -141,6 +141,19 @@ __device__ inline void seam_serial(SeamLds& gd, int h, int jfixed, int fin_mode,
     c.lastval = c.L;
   }
   if (do_coeff) lbfgs_coefficients(gd, h, latest);
+  if (desc_mode) {
+    // descent = ⟨dir, G⟩ (src/sdplr.jl:201) of the direction the coefficients above define,
+    // dir = ∓(G − Σ α_l y_l + Σ γ_l s_l), from the same Gram data — before the direction exists, so that
+    // k_lbfgs_dir can take the steepest-descent fallback of :202-205 in its own pass and no reduction kernel
+    // has to sit between the direction and its first consumer.  desc_mode: 1 = negated direction, 2 = not.
+    const double g = c.grel ? c.gnorm * c.normC : c.gnorm;
+    double d = norms ? gd.nrm[0] : g * g;
+    for (int l = 0; l < h; l++) d -= c.c_alpha[l] * c.Yg[l];
+    for (int l = 0; l < h; l++) d += c.c_gamma[l] * c.Sg[l];
+    if (desc_mode == 1) d = -d;
+    c.descent = d;
+    c.fallback = (isnan(d) || d >= 0.0) ? 1 : 0;
+  }
 }
 
 // The seam between two inner iterations, one block of 1024 threads:
@@ -155,7 +168,7 @@ __device__ inline void seam_serial(SeamLds& gd, int h, int jfixed, int fin_mode,
 // global round trips.
 __global__ void __launch_bounds__(1024)
 k_lbfgs_boundary(DevCtrl* __restrict__ c, int h, int jfixed, int fin_mode, int do_loop, int do_coeff,
-                 int nb_partials, const double* __restrict__ partials) {
+                 int nb_partials, const double* __restrict__ partials, int desc_mode) {
   __shared__ SeamLds gd;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   // Everything this kernel reads from global memory is requested in one go — the flags, the control block
@@ -203,7 +216,7 @@ k_lbfgs_boundary(DevCtrl* __restrict__ c, int h, int jfixed, int fin_mode, int d
   const bool norms = np != 0;
   if (!fin && !do_coeff && !do_loop && !norms) return;
   __syncthreads();
-  if (tid == 0) seam_serial(gd, h, jfixed, fin_mode, do_loop, do_coeff, fin, norms);
+  if (tid == 0) seam_serial(gd, h, jfixed, fin_mode, do_loop, do_coeff, fin, norms, desc_mode);
   __syncthreads();
   {
     const unsigned long long* src = reinterpret_cast<const unsigned long long*>(&gd.c);
@@ -218,12 +231,15 @@ k_lbfgs_boundary(DevCtrl* __restrict__ c, int h, int jfixed, int fin_mode, int d
 template <int HM>
 __global__ void __launch_bounds__(SDPLR_NT)
 k_lbfgs_dir(const DevCtrl* __restrict__ c, FactorArena A, long long N, int h, int negate,
-            int check_done, double* __restrict__ partials) {
+            int check_done, double* __restrict__ partials, int inline_fallback) {
   __shared__ double sh[8];
   const int dn = check_done ? c->done : 0;  // fetched with the coefficients, tested before the first pass
-  const double* G = aslot(A, AS_G);
+  double* G = aslot(A, AS_G);
   double* dir = aslot(A, AS_D);
   const int latest = c->latest;
+  // inline_fallback: the seam kernel has already evaluated ⟨dir, G⟩ from the Gram data and decided
+  // (c->fallback) whether this direction is replaced by steepest descent, src/sdplr.jl:202-205: G ← −G, dir ← G
+  const int fb = inline_fallback ? c->fallback : 0;
   int order[HM];
   double ca[HM], cg[HM];
   {
@@ -281,6 +297,11 @@ k_lbfgs_dir(const DevCtrl* __restrict__ c, FactorArena A, long long N, int h, in
     double2 d;
     d.x = sgn * r.x;
     d.y = sgn * r.y;
+    if (fb) {
+      d.x = -g.x;
+      d.y = -g.y;
+      reinterpret_cast<double2*>(G)[i] = d;
+    }
     reinterpret_cast<double2*>(dir)[i] = d;
     if (ynext) {
       double2 ng;
@@ -300,11 +321,16 @@ k_lbfgs_dir(const DevCtrl* __restrict__ c, FactorArena A, long long N, int h, in
 #pragma unroll
     for (int k = HM - 1; k >= 0; k--)
       if (k < h) r += cg[k] * aslot(A, AS_S0 + order[k])[e];
-    const double d = sgn * r;
+    double d = sgn * r;
+    if (fb) {
+      d = -g;
+      G[e] = d;
+    }
     dir[e] = d;
     if (ynext) ynext[e] = -g;
     desc += d * g;
   }
+  if (inline_fallback) return;  // no consumer for the partials: ⟨dir, G⟩ came from the seam kernel
   desc = block_sum1(desc, sh);
   if (threadIdx.x == 0) slot_partials(partials, SLOT_DESCENT)[blockIdx.x] = desc;
 }

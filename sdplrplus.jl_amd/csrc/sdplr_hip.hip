@@ -73,6 +73,7 @@ struct sdplr_hip_solver {
   DevTile tile{};            // the same matrix as column-sorted K-row tiles (k_spmm_tile)
   int nb_tile = 0, nb_step = 1;
   bool use_tile = false;
+  bool dot_descent = false;  // SDPLR_HIP_DOT_DESCENT: in-loop ⟨dir, G⟩ by reduction (k_descent) instead of the Gram form
   int tile_lpr = 0;          // the lists are padded to multiples of this sub-wave width
   std::vector<int> h_gptr, h_gcol;   // host CSR of A_g (kept: the tiles are rebuilt when the rank changes)
   std::vector<double> h_gval;
@@ -612,6 +613,7 @@ int32_t sdplr_hip_finalize(S* s) {
     }
   }
   // ---- structured fast path: classify the sparse matrices ----
+  s->dot_descent = getenv("SDPLR_HIP_DOT_DESCENT") != nullptr;
   if (s->have_sparse && getenv("SDPLR_HIP_NO_FAST") == nullptr) {
     std::vector<int> general;
     for (int64_t k = 0; k < s->n_sparse; k++) {
@@ -1003,9 +1005,9 @@ void enq_f(S* s) {
 }
 
 // 1-block seam kernel: fold update partials / loop tests / two-loop coefficients (k_dense.h)
-void enq_boundary(S* s, int jfixed, int fin_mode, int do_loop, int do_coeff) {
+void enq_boundary(S* s, int jfixed, int fin_mode, int do_loop, int do_coeff, int desc_mode = 0) {
   ProfScope ps(s, "lbfgs_boundary");
-  k_lbfgs_boundary<<<1, 1024, 0, s->stream>>>(s->ctrl, (int)s->h, jfixed, fin_mode, do_loop, do_coeff, s->nb_upd, s->partials);
+  k_lbfgs_boundary<<<1, 1024, 0, s->stream>>>(s->ctrl, (int)s->h, jfixed, fin_mode, do_loop, do_coeff, s->nb_upd, s->partials, desc_mode);
 }
 void enq_gram_row(S* s, int j) {
   HM_DISPATCH((k_lbfgs_update<HM, false><<<s->nb_upd, SDPLR_NT, 0, s->stream>>>(s->ctrl, s->arena, s->N, (int)s->h, j, 0, s->partials)))
@@ -1030,11 +1032,16 @@ void enq_lbfgs_dir(S* s, int negate, int in_loop, int apply_fallback) {
   // m == 0: the reference returns right after copyto!(dir, grad), before the negation
   // (src/lbfgs.jl:88-91); the caller's descent test then falls back to −G (src/sdplr.jl:202-205).
   if (s->h == 0) negate = 0;
-  enq_boundary(s, 0, in_loop ? 1 : 0, in_loop, 1);
+  // Inside the device-driven loop ⟨dir, G⟩ is evaluated by the seam kernel from the Gram data (the same data
+  // the direction's coefficients come from) and the fallback is taken by k_lbfgs_dir itself: one launch fewer
+  // per iteration.  The stand-alone operator (and SDPLR_HIP_DOT_DESCENT=1) reduces the dot product instead.
+  const int analytic = (in_loop && apply_fallback && !s->dot_descent) ? 1 : 0;
+  enq_boundary(s, 0, in_loop ? 1 : 0, in_loop, 1, analytic ? (negate ? 1 : 2) : 0);
   {
     ProfScope ps(s, "lbfgs_dir");
-    HM_DISPATCH((k_lbfgs_dir<HM><<<s->nb_dense, SDPLR_NT, 0, s->stream>>>(s->ctrl, s->arena, s->N, (int)s->h, negate, in_loop, s->partials)))
+    HM_DISPATCH((k_lbfgs_dir<HM><<<s->nb_dense, SDPLR_NT, 0, s->stream>>>(s->ctrl, s->arena, s->N, (int)s->h, negate, in_loop, s->partials, analytic)))
   }
+  if (analytic) return;
   ProfScope ps(s, "descent");
   const int nb = apply_fallback ? s->nb_dense : 1;
   k_descent<<<nb, SDPLR_NT, 0, s->stream>>>(s->ctrl, s->arena, s->N, s->nb_dense, apply_fallback, in_loop, s->partials);

@@ -169,6 +169,41 @@ def test_inner_loop_trajectory(hip_abi, oracle_abi, family):
         s_.close()
 
 
+@pytest.mark.parametrize("family,h", [("maxcut", 0), ("maxcut", 4), ("cutnorm", 4), ("minimum_bisection", 3)])
+def test_inner_loop_takes_the_steepest_descent_fallback(hip_abi, oracle_abi, family, h):
+    """src/sdplr.jl:201-205: when ⟨dir, G⟩ is NaN or ≥ 0 the loop replaces the direction by steepest descent
+    (G ← −G; dir ← G).  Inside the device loop that test is evaluated by the seam kernel from the Gram data
+    and applied by k_lbfgs_dir itself; the oracle reduces the dot product as the reference does.  Cases: no
+    history at all (h = 0: lbfgs_dir! returns +G, every iteration falls back) and a history whose ρ have
+    newest pair the host has replaced by (s = G, y = 0, ρ ≪ 0), which makes the two-loop direction an ascent one."""
+    from sdplrplus_jl_amd import cabi
+    data, C, As, bs = make_data(family, 4, 14, 0.4)
+    g, o = pair(hip_abi, oracle_abi, data, 3, 13, h=h)
+    normC, normb = data.normC(), float(np.linalg.norm(data.b))
+    sg, so = g.fg(normC, normb), o.fg(normC, normb)
+    if h > 0:
+        sg = g.inner_loop(normC, normb, True, True, False, 0.0, -1e300, h + 1, 0.0, *sg)[:3]
+        so = o.inner_loop(normC, normb, True, True, False, 0.0, -1e300, h + 1, 0.0, *so)[:3]
+        for s_ in (g, o):   # newest pair: s = G with a large negative ρ ⇒ gᵀHg < 0
+            j = int(s_.get_scalar(cabi.S_LBFGS_LATEST)) - 1
+            G = s_.Gt
+            s_.set_factor(cabi.F_LBFGS_S + j, G)
+            s_.set_factor(cabi.F_LBFGS_Y + j, np.zeros_like(G))
+            rho = s_.get_vec(cabi.V_LBFGS_RHO)
+            rho[j] = -1e6 / float(np.sum(G * G))
+            s_.set_vec(cabi.V_LBFGS_RHO, rho)
+        dg, do = g.lbfgs_dir(True), o.lbfgs_dir(True)
+        assert do > 0 and dg == pytest.approx(do, rel=1e-9)
+    for it in range(3):
+        rg = g.inner_loop(normC, normb, True, True, False, 0.0, -1e300, 1, 0.0, *sg)
+        ro = o.inner_loop(normC, normb, True, True, False, 0.0, -1e300, 1, 0.0, *so)
+        assert rg[4] == ro[4] == 1
+        assert np.allclose(rg[:3], ro[:3], rtol=1e-8, atol=1e-12), (it, rg, ro)
+        assert rel(g.Rt, o.Rt) < 1e-8 and rel(g.Gt, o.Gt) < 1e-7
+        sg, so = rg[:3], ro[:3]
+    g.close(); o.close()
+
+
 @pytest.mark.parametrize("family", ["maxcut", "minimum_bisection", "lovasz_theta"])
 def test_lanczos_and_dual_obj(hip_abi, oracle_abi, family):
     data, C, As, bs = make_data(family, 3, 12, 0.4)
@@ -391,6 +426,7 @@ def test_concurrent_handles_match_serial(hip_abi):
 
 @pytest.mark.parametrize("family,toggles", [
     ("maxcut", ["SDPLR_HIP_NO_FAST"]), ("maxcut", ["SDPLR_HIP_NO_FAST2"]), ("maxcut", ["SDPLR_HIP_NO_GRAPH"]),
+    ("maxcut", ["SDPLR_HIP_DOT_DESCENT"]), ("cutnorm", ["SDPLR_HIP_DOT_DESCENT"]), ("ineq_0.05", ["SDPLR_HIP_DOT_DESCENT"]),
     ("minimum_bisection", ["SDPLR_HIP_NO_FAST"]),
     ("minimum_bisection", ["SDPLR_HIP_NO_FAST2"]), ("cutnorm", ["SDPLR_HIP_NO_FAST"]),
     ("mu_conductance_0.05", ["SDPLR_HIP_NO_FAST"]), ("ineq_0.05", ["SDPLR_HIP_NO_FAST"]),
