@@ -289,11 +289,36 @@ int build_tiles(S* s) {
   const std::vector<double>& g_val = s->h_gval;
   choose_shape(s);
   const int G = SDPLR_NT / s->LPR, L = s->LPR;
-  int64_t nt = std::min<int64_t>(n, 1024LL * G);
-  if ((n + nt - 1) / nt > 8) nt = (n + 7) / 8;
-  if (const char* e = getenv("SDPLR_HIP_TILE_K")) { const int kk = std::max(1, std::min(atoi(e), 8)); nt = (n + kk - 1) / kk; }
-  std::vector<int> t_row(nt + 1), t_ptr(nt + 1, 0), t_ent;
-  for (int64_t t = 0; t <= nt; t++) t_row[t] = (int)((t * n) / nt);
+  const int64_t cap = 1024LL * G, nnz = g_ptr[n];
+  std::vector<int> t_row;
+  if (const char* e = getenv("SDPLR_HIP_TILE_K")) {   // fixed tile height (tests)
+    const int kk = std::max(1, std::min(atoi(e), 8));
+    for (int64_t r0 = 0; r0 < n; r0 += kk) t_row.push_back((int)r0);
+  } else {
+    // Tiles of (nearly) equal NONZERO count, at most 8 rows each: a group's position in the column sweep is
+    // the fraction of its list it has consumed, so equally long lists keep all groups on the same narrow band
+    // of D (with equal row counts the lists differ by ±15 % and the band outgrows the L2).  The tile count
+    // is steered to at most `cap` so that the grid is one resident wave of blocks.
+    int64_t want = std::min<int64_t>(n, cap);
+    for (int attempt = 0; attempt < 6; attempt++) {
+      t_row.clear();
+      int64_t r0 = 0, t = 0;
+      while (r0 < n) {
+        t_row.push_back((int)r0);
+        const double goal = (double)(t + 1) * (double)(nnz + n) / (double)want;   // rows count as one entry too
+        int64_t r1 = r0 + 1;
+        while (r1 < n && r1 - r0 < 8 && (double)(g_ptr[r1 + 1] + r1 + 1) <= goal) r1++;
+        r0 = r1;
+        t++;
+      }
+      if ((int64_t)t_row.size() <= cap || (n + 7) / 8 > cap) break;
+      want -= ((int64_t)t_row.size() - cap) + 8;
+      if (want < 1) { want = 1; }
+    }
+  }
+  const int64_t nt = (int64_t)t_row.size();
+  t_row.push_back((int)n);
+  std::vector<int> t_ptr(nt + 1, 0), t_ent;
   int K = 1;
   for (int64_t t = 0; t < nt; t++) K = std::max(K, t_row[t + 1] - t_row[t]);
   std::vector<double> t_val;
