@@ -449,13 +449,18 @@ k_ls_solve_fast(DevCtrl* __restrict__ c, int m, int gid_g, int n_extra, const in
                 double* __restrict__ pv_raw, const double* __restrict__ lb, double* __restrict__ pv,
                 double* __restrict__ y, int lr_ST, int r, const int* __restrict__ lr_col_gid,
                 const double* __restrict__ lr_D, double* __restrict__ lrW, double* __restrict__ lrWS,
-                const double* __restrict__ partials, int check_done) {
+                const double* __restrict__ partials, int check_done,
+                int lr_tail, int lr_n, const int* __restrict__ lr_mat_ptr, const int* __restrict__ lr_mat_gid) {
   __shared__ double sh[10 * (SDPLR_NT / 64)];
   const int dn = check_done ? c->done : 0;
   // every scalar the serial part needs, requested up front: their latency overlaps the partial sums below
   // instead of forming a chain of dependent global round trips in thread 0
   const double sigma = c->sigma, obj0 = c->obj, amax = c->alpha_max, last = c->lastval, feps = c->fprec_eps;
-  const double rd_m = A_RD[m], dd_m = A_DD[m];
+  double rd_m = 0.0, dd_m = 0.0;
+  if (!lr_tail) {
+    rd_m = A_RD[m];
+    dd_m = A_DD[m];
+  }
   double s[10];
 #pragma unroll
   for (int k = 0; k < 10; k++) s[k] = 0.0;
@@ -466,6 +471,32 @@ k_ls_solve_fast(DevCtrl* __restrict__ c, int m, int gid_g, int n_extra, const in
     s[9] += slot_partials(partials, SLOT_DW)[i];
   }
   if (dn) return;
+  if (lr_tail) {
+    // the tail of k_lr_finalize, mode 2 (src/linesearch.jl:10-16 for the low-rank matrices):
+    // A_RD[gid] = 2·Σ_c D_c⟨W0_c, W1_c⟩, A_DD[gid] = Σ_c D_c‖W1_c‖², from the projections W = [RᵀB; DᵀB]
+    const int per = lr_ST * r;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int t = wave; t < lr_n; t += SDPLR_NT / 64) {   // one wave per matrix, lanes over the rank
+      double s0 = 0.0, s1 = 0.0;
+      for (int cc = lr_mat_ptr[t]; cc < lr_mat_ptr[t + 1]; cc++) {
+        double d0 = 0.0, d1 = 0.0;
+        for (int k = lane; k < r; k += 64) {
+          const double w0 = lrW[cc * r + k], w1 = lrW[per + cc * r + k];
+          d0 += w0 * w1;
+          d1 += w1 * w1;
+        }
+        s0 += wave_sum(d0) * lr_D[cc];
+        s1 += wave_sum(d1) * lr_D[cc];
+      }
+      if (lane == 0) {
+        A_RD[lr_mat_gid[t]] = 2.0 * s0;
+        A_DD[lr_mat_gid[t]] = s1;
+      }
+    }
+    __syncthreads();
+    rd_m = A_RD[m];
+    dd_m = A_DD[m];
+  }
   block_sum<10>(s, sh);
   __shared__ double sh_alpha;
   __shared__ int sh_err;

@@ -409,6 +409,23 @@ k_lr_finalize(DevLowRank lr, int r, int F, int nb, const double* __restrict__ lr
   }
 }
 
+// first stage of k_lr_finalize alone, one wave per output and four outputs per block: used when the partials
+// come from many blocks (k_spmm_tile's fused projections) and one block would spend its time reading them
+__global__ void __launch_bounds__(SDPLR_NT)
+k_lr_reduce(int nout, int nb, const double* __restrict__ lr_part, double* __restrict__ W,
+            const DevCtrl* __restrict__ c, int check_done) {
+  const int dn = check_done ? c->done : 0;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int t = blockIdx.x * (SDPLR_NT / 64) + wave;
+  if (t >= nout) return;
+  const double* p = lr_part + (long long)t * nb;
+  double s = 0.0;
+  for (int b = lane; b < nb; b += 64) s += p[b];
+  s = wave_sum(s);
+  if (dn) return;
+  if (lane == 0) W[t] = s;
+}
+
 // ⟨B[c], x⟩ partials for the SpMV low-rank term; grid.y = column
 __global__ void __launch_bounds__(SDPLR_NT)
 k_lr_btx(DevLowRank lr, const double* __restrict__ x, int n, double* __restrict__ part /* [ST][gridDim.x] */,
@@ -905,12 +922,13 @@ __device__ __forceinline__ double group_bcast(double v, int src) {
   return __hiloint2double(group_bcast<LPR>(__double2hiint(v), src), group_bcast<LPR>(__double2loint(v), src));
 }
 
-template <int LPR, int VEC>
+template <int LPR, int VEC, int LRN>
 __global__ void __launch_bounds__(SDPLR_NT, 4)
 k_spmm_tile(DevTile tl, int n, int m, DevFast ff, const double* __restrict__ R, const double* __restrict__ D,
             const double* __restrict__ P, double* __restrict__ W, int r, const double* __restrict__ lam,
             const double* __restrict__ pv_raw, double* __restrict__ A_RD, double* __restrict__ A_DD,
-            double* __restrict__ partials, const DevCtrl* __restrict__ c, int check_done) {
+            double* __restrict__ partials, const DevCtrl* __restrict__ c, int check_done,
+            DevLowRank lr, double* __restrict__ lr_part) {
   // [G][K+1][LPR·VEC] partial rows, [G][K][2] row dots, [G][8] line-search sums
   extern __shared__ double tile_lds[];
   __shared__ double sh[10 * (SDPLR_NT / 64)];
@@ -923,8 +941,21 @@ k_spmm_tile(DevTile tl, int n, int m, DevFast ff, const double* __restrict__ R, 
   double* rows = tile_lds + (size_t)grp * (K + 1) * RW + lane * VEC;
   double* dots = tile_lds + (size_t)G * (K + 1) * RW + (size_t)grp * K * 2;
   double* ls = tile_lds + (size_t)G * (K + 1) * RW + (size_t)G * K * 2 + (size_t)grp * 8;  // per group
+  // per WAVE: running low-rank projections [2·LRN][RW] (kept out of the registers the ring needs)
+  double* lrw = tile_lds + (size_t)G * (K + 1) * RW + (size_t)G * (K * 2 + 8) +
+                (size_t)(threadIdx.x >> 6) * (2 * LRN * RW) + lane * VEC;
   const double sigma = c->sigma;
   double pd = 0.0, dw = 0.0;  // ⟨P,D⟩, ⟨D,W⟩
+  // LRN > 0 (single chunk only): the projections RᵀB_c and DᵀB_c of k_lr_project<…,2> for the first LRN = ST
+  // low-rank columns ride on the rows the epilogue loads anyway (src/coreop.jl:125-126) — one pass over R and D
+  // saved per iteration
+  constexpr int LRA = LRN > 0 ? LRN : 1;
+  if ((threadIdx.x & 63) < LPR) {
+#pragma unroll
+    for (int cc = 0; cc < 2 * LRN; cc++)
+#pragma unroll
+      for (int q = 0; q < VEC; q++) lrw[cc * RW + q] = 0.0;
+  }
   for (int k = lane; k < 8; k += LPR) ls[k] = 0.0;
   for (long long tile = (long long)blockIdx.x * G + grp; tile < tl.n_tiles; tile += (long long)gridDim.x * G) {
     const int beg = tl.ptr[tile], end = tl.ptr[tile + 1];
@@ -1015,17 +1046,23 @@ k_spmm_tile(DevTile tl, int n, int m, DevFast ff, const double* __restrict__ R, 
         ne = fe;
         nv = fv;
       }
-      // the tile's rows, four at a time (one memory round trip for twelve row loads, eight interleaved group
+      constexpr int EB = LRN > 0 ? 2 : 4;   // rows per step (the projections need registers of their own)
+      // the tile's rows, EB at a time (one memory round trip for twelve row loads, eight interleaved group
       // sums): W out, row dots, ⟨P,D⟩ and ⟨D,W⟩ partials.  Loads are clamped, not predicated.
 #if SDPLR_TILE_EXP == 4   /* experiment: no epilogue */
-      for (int k = 0; k < 0; k += 4) {
+      for (int k = 0; k < 0; k += EB) {
 #else
-      for (int k = 0; k < nrows; k += 4) {
+      double lr0[LRA][VEC], lr1[LRA][VEC];
+#pragma unroll
+      for (int cc = 0; cc < LRA; cc++)
+#pragma unroll
+        for (int q = 0; q < VEC; q++) lr0[cc][q] = lr1[cc][q] = 0.0;
+      for (int k = 0; k < nrows; k += EB) {
 #endif
-        vecd<VEC> xr[4], xd[4], xp[4], w[4];
+        vecd<VEC> xr[EB], xd[EB], xp[EB], w[EB];
         const long long chs = act ? ch : 0;
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
+        for (int i = 0; i < EB; i++) {
           const long long j = j0 + min(k + i, nrows - 1);
           xr[i] = ldrow<VEC>(R + j * r + chs);
           xd[i] = ldrow<VEC>(D + j * r + chs);
@@ -1033,9 +1070,9 @@ k_spmm_tile(DevTile tl, int n, int m, DevFast ff, const double* __restrict__ R, 
 #pragma unroll
           for (int q = 0; q < VEC; q++) w[i].v[q] = rows[min(k + i, nrows - 1) * RW + q];
         }
-        double rd[4], dd[4];
+        double rd[EB], dd[EB];
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
+        for (int i = 0; i < EB; i++) {
           const bool ok = act && k + i < nrows;
           if (ok) strow<VEC>(W + (j0 + k + i) * r + ch, w[i]);
           rd[i] = dd[i] = 0.0;
@@ -1051,21 +1088,45 @@ k_spmm_tile(DevTile tl, int n, int m, DevFast ff, const double* __restrict__ R, 
           dd[i] = ok ? dd[i] : 0.0;
           pd += ok ? tp : 0.0;
           dw += ok ? tw : 0.0;
+#pragma unroll
+          for (int cc = 0; cc < LRN; cc++) {
+            const double b = ok ? lr.Bcat[(long long)cc * n + j0 + k + i] : 0.0;
+#pragma unroll
+            for (int q = 0; q < VEC; q++) {
+              lr0[cc][q] += xr[i].v[q] * b;
+              lr1[cc][q] += xd[i].v[q] * b;
+            }
+          }
         }
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
+        for (int i = 0; i < EB; i++) {
           rd[i] = group_sum<LPR>(rd[i]);
           dd[i] = group_sum<LPR>(dd[i]);
         }
         if (lane == 0) {
 #pragma unroll
-          for (int i = 0; i < 4; i++)
+          for (int i = 0; i < EB; i++)
             if (k + i < nrows) {
               dots[2 * (k + i)] += rd[i];
               dots[2 * (k + i) + 1] += dd[i];
             }
         }
       }
+#pragma unroll
+      for (int cc = 0; cc < LRN; cc++)
+#pragma unroll
+        for (int q = 0; q < VEC; q++) {   // the wave's groups first (fixed order), then into the wave's LDS slot
+          double a0 = lr0[cc][q], a1 = lr1[cc][q];
+#pragma unroll
+          for (int o = LPR; o < 64; o <<= 1) {
+            a0 += __shfl_xor(a0, o, 64);
+            a1 += __shfl_xor(a1, o, 64);
+          }
+          if ((threadIdx.x & 63) < LPR) {
+            lrw[cc * RW + q] += a0;
+            lrw[(LRN + cc) * RW + q] += a1;
+          }
+        }
       __builtin_amdgcn_wave_barrier();
     }
     // the constraints attached to the tile's rows, one lane per row; their line-search sums are reduced over
@@ -1104,9 +1165,25 @@ k_spmm_tile(DevTile tl, int n, int m, DevFast ff, const double* __restrict__ R, 
     }
     __builtin_amdgcn_wave_barrier();
   }
+  double lsk[8];
+#pragma unroll
+  for (int k = 0; k < 8; k++) lsk[k] = (lane == 0) ? ls[k] : 0.0;
+  if constexpr (LRN > 0) {  // block partials of the projections, in k_lr_project's layout (block index fastest)
+    __syncthreads();
+    const double* all = tile_lds + (size_t)G * (K + 1) * RW + (size_t)G * (K * 2 + 8);
+    for (int t = threadIdx.x; t < 2 * LRN * RW; t += SDPLR_NT) {
+      const int ch = t % RW;
+      if (ch < r) {
+        double sum = 0.0;
+        for (int w = 0; w < SDPLR_NT / 64; w++) sum += all[(size_t)w * (2 * LRN * RW) + t];
+        // t = (f·LRN + cc)·RW + ch
+        lr_part[((long long)(t / RW / LRN) * lr.ST + (t / RW) % LRN) * r * gridDim.x + (long long)ch * gridDim.x + blockIdx.x] = sum;
+      }
+    }
+  }
   double acc[10];
 #pragma unroll
-  for (int k = 0; k < 8; k++) acc[k] = (lane == 0) ? ls[k] : 0.0;
+  for (int k = 0; k < 8; k++) acc[k] = lsk[k];
   acc[8] = pd;
   acc[9] = dw;
   block_sum<10>(acc, sh);

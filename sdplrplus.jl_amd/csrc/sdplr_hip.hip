@@ -73,6 +73,7 @@ struct sdplr_hip_solver {
   DevTile tile{};            // the same matrix as column-sorted K-row tiles (k_spmm_tile)
   int nb_tile = 0, nb_step = 1;
   bool use_tile = false;
+  bool no_lrfuse = false;    // SDPLR_HIP_NO_LRFUSE: low-rank projections by k_lr_project even on the tile path
   bool dot_descent = false;  // SDPLR_HIP_DOT_DESCENT: in-loop ⟨dir, G⟩ by reduction (k_descent) instead of the Gram form
   int tile_lpr = 0;          // the lists are padded to multiples of this sub-wave width
   std::vector<int> h_gptr, h_gcol;   // host CSR of A_g (kept: the tiles are rebuilt when the rank changes)
@@ -639,6 +640,7 @@ int32_t sdplr_hip_finalize(S* s) {
   }
   // ---- structured fast path: classify the sparse matrices ----
   s->dot_descent = getenv("SDPLR_HIP_DOT_DESCENT") != nullptr;
+  s->no_lrfuse = getenv("SDPLR_HIP_NO_LRFUSE") != nullptr;
   if (s->have_sparse && getenv("SDPLR_HIP_NO_FAST") == nullptr) {
     std::vector<int> general;
     for (int64_t k = 0; k < s->n_sparse; k++) {
@@ -742,7 +744,7 @@ int32_t sdplr_hip_finalize(S* s) {
   s->nb_nnzS = blocks_for(s->nnzS, SDPLR_NT, 4096);
   s->nb_n = blocks_for(n, SDPLR_NT, 1024);
   // low-rank scratch depends on r: allocated for the largest rank seen (reset_rank re-allocates)
-  if ((rc = dzero(s, &s->lr_part, (size_t)s->nb_lr * 2 * std::max(lr.ST, 1) * s->r))) return rc;
+  if ((rc = dzero(s, &s->lr_part, (size_t)std::max(s->nb_lr, 1024) * 2 * std::max(lr.ST, 1) * s->r))) return rc;
   if ((rc = dzero(s, &s->lr_W, (size_t)2 * std::max(lr.ST, 1) * s->r))) return rc;
   if ((rc = dzero(s, &s->lr_WS, (size_t)std::max(lr.ST, 1) * s->r))) return rc;
   // release host staging
@@ -793,7 +795,7 @@ int32_t sdplr_hip_reset_rank(S* s, int64_t new_r) {
   HIPCK(s, hipMemsetAsync(s->lambda, 0, std::max<int64_t>(m, 1) * sizeof(double), s->stream));
   HIPCK(s, hipMemsetAsync(s->pv, 0, std::max<int64_t>(m, 1) * sizeof(double), s->stream));
   for (double* p : {s->y, s->pv_raw, s->A_RD, s->A_DD}) HIPCK(s, hipMemsetAsync(p, 0, (m + 1) * sizeof(double), s->stream));
-  if ((rc = dzero(s, &s->lr_part, (size_t)s->nb_lr * 2 * std::max(s->lr.ST, 1) * s->r))) return rc;
+  if ((rc = dzero(s, &s->lr_part, (size_t)std::max(s->nb_lr, 1024) * 2 * std::max(s->lr.ST, 1) * s->r))) return rc;
   if ((rc = dzero(s, &s->lr_W, (size_t)2 * std::max(s->lr.ST, 1) * s->r))) return rc;
   if ((rc = dzero(s, &s->lr_WS, (size_t)std::max(s->lr.ST, 1) * s->r))) return rc;
   if ((rc = pull(s))) return rc;
@@ -1205,20 +1207,30 @@ void enq_iteration_fast(S* s, int armijo) {
 void enq_iteration_fast2(S* s) {
   double *R = aslot(s->arena, AS_R), *G = aslot(s->arena, AS_G), *D = aslot(s->arena, AS_D);
   double *P = fast_P(s), *W = fast_W(s);
+  bool lr_fused = false;
   enq_lbfgs_dir(s, 1, 1, 1);                                                          // :197-205
   {
     ProfScope ps(s, "spmm_W");   // W = A_g·D + row dots + line-search sums of the row-attached constraints
     if (s->use_tile && s->tile_lpr == s->LPR && s->n * s->r * 8 < (1LL << 32)) {
-      const size_t lds = ((size_t)SDPLR_NT * s->VEC * (s->tile.K + 1) + (size_t)(SDPLR_NT / s->LPR) * (2 * s->tile.K + 8)) * sizeof(double);
-      LV_DISPATCH((k_spmm_tile<LPR, VEC><<<s->nb_tile, SDPLR_NT, lds, s->stream>>>(s->tile, (int)s->n, (int)s->m, s->ff, R, D, P, W, (int)s->r, s->lambda, s->pv_raw, s->A_RD, s->A_DD, s->partials, s->ctrl, 1)))
+      lr_fused = s->lr.ST == 1 && s->r <= (int64_t)s->LPR * s->VEC && !s->no_lrfuse;
+      const size_t lds = ((size_t)SDPLR_NT * s->VEC * (s->tile.K + 1) + (size_t)(SDPLR_NT / s->LPR) * (2 * s->tile.K + 8) + (lr_fused ? (size_t)(SDPLR_NT / 64) * 2 * s->LPR * s->VEC : 0)) * sizeof(double);
+      if (lr_fused) { LV_DISPATCH((k_spmm_tile<LPR, VEC, 1><<<s->nb_tile, SDPLR_NT, lds, s->stream>>>(s->tile, (int)s->n, (int)s->m, s->ff, R, D, P, W, (int)s->r, s->lambda, s->pv_raw, s->A_RD, s->A_DD, s->partials, s->ctrl, 1, s->lr, s->lr_part))) }
+      else { LV_DISPATCH((k_spmm_tile<LPR, VEC, 0><<<s->nb_tile, SDPLR_NT, lds, s->stream>>>(s->tile, (int)s->n, (int)s->m, s->ff, R, D, P, W, (int)s->r, s->lambda, s->pv_raw, s->A_RD, s->A_DD, s->partials, s->ctrl, 1, s->lr, s->lr_part))) }
     } else {
       LV_DISPATCH((k_spmm_fast<LPR, VEC><<<s->nb_spmm, SDPLR_NT, 0, s->stream>>>(s->spg, (int)s->m, s->ff, R, D, P, W, (int)s->r, s->lambda, s->pv_raw, s->A_RD, s->A_DD, s->partials, s->ctrl, 1)))
     }
   }
-  enq_lowrank(s, R, D, 2, 2, s->A_RD, s->A_DD, 1);
+  if (lr_fused) {  // the projections came out of the tile kernel: sum the block partials (many blocks, one wave
+                   // per output); the mode-2 tail of k_lr_finalize is taken by k_ls_solve_fast
+    ProfScope ps(s, "lr_reduce");
+    const int nout = 2 * s->lr.ST * (int)s->r;
+    k_lr_reduce<<<(nout + 3) / 4, SDPLR_NT, 0, s->stream>>>(nout, s->nb_tile, s->lr_part, s->lr_W, s->ctrl, 1);
+  } else {
+    enq_lowrank(s, R, D, 2, 2, s->A_RD, s->A_DD, 1);
+  }
   {
     ProfScope ps(s, "ls_solve_fast");
-    k_ls_solve_fast<<<1, SDPLR_NT, 0, s->stream>>>(s->ctrl, (int)s->m, s->ff.gid_g, s->n_extra, s->extra_slots, (s->use_tile && s->tile_lpr == s->LPR && s->n * s->r * 8 < (1LL << 32)) ? s->nb_tile : s->nb_spmm, s->A_RD, s->A_DD, s->lambda, s->lambda_ub, s->pv_raw, s->pv_lb, s->pv, s->y, s->lr.ST, (int)s->r, s->lr.col_gid, s->lr.Dcat, s->lr_W, s->lr_WS, s->partials, 1);
+    k_ls_solve_fast<<<1, SDPLR_NT, 0, s->stream>>>(s->ctrl, (int)s->m, s->ff.gid_g, s->n_extra, s->extra_slots, (s->use_tile && s->tile_lpr == s->LPR && s->n * s->r * 8 < (1LL << 32)) ? s->nb_tile : s->nb_spmm, s->A_RD, s->A_DD, s->lambda, s->lambda_ub, s->pv_raw, s->pv_lb, s->pv, s->y, s->lr.ST, (int)s->r, s->lr.col_gid, s->lr.Dcat, s->lr_W, s->lr_WS, s->partials, 1, lr_fused ? 1 : 0, s->lr.n_lr, s->lr.mat_ptr, s->lr.mat_gid);
   }
   // (a variant fusing this step kernel with lbfgs_update! was measured at 111 µs against 38 + 59 µs for the
   // two kernels — 166 VGPRs and scratch — and dropped)

@@ -428,7 +428,8 @@ def test_concurrent_handles_match_serial(hip_abi):
     ("maxcut", ["SDPLR_HIP_NO_FAST"]), ("maxcut", ["SDPLR_HIP_NO_FAST2"]), ("maxcut", ["SDPLR_HIP_NO_GRAPH"]),
     ("maxcut", ["SDPLR_HIP_DOT_DESCENT"]), ("cutnorm", ["SDPLR_HIP_DOT_DESCENT"]), ("ineq_0.05", ["SDPLR_HIP_DOT_DESCENT"]),
     ("minimum_bisection", ["SDPLR_HIP_NO_FAST"]),
-    ("minimum_bisection", ["SDPLR_HIP_NO_FAST2"]), ("cutnorm", ["SDPLR_HIP_NO_FAST"]),
+    ("minimum_bisection", ["SDPLR_HIP_NO_FAST2"]), ("minimum_bisection", ["SDPLR_HIP_NO_LRFUSE"]),
+    ("minimum_bisection", ["SDPLR_HIP_NO_TILE"]), ("cutnorm", ["SDPLR_HIP_NO_FAST"]),
     ("mu_conductance_0.05", ["SDPLR_HIP_NO_FAST"]), ("ineq_0.05", ["SDPLR_HIP_NO_FAST"]),
 ])
 def test_code_paths_agree(hip_abi, oracle_abi, family, toggles, monkeypatch):
