@@ -999,8 +999,15 @@ void enq_At_preprocess(S* s, int chk) {
 }
 
 // Y = scale·(X·S + low-rank); slot ≥ 0 also yields the ‖Y‖² partials
-void enq_At_left(S* s, double* Y, const double* X, double scale, int slot, int chk) {
-  enq_lowrank(s, X, X, 1, 3, nullptr, nullptr, chk);
+// lr_step: X is the point the line search has just moved to and lr_W still holds [X_oldᵀB; DᵀB] from its
+// 𝒜 pass, so X_newᵀB = X_oldᵀB + α·DᵀB (exact by linearity) and no pass over X is needed for the low-rank term
+void enq_At_left(S* s, double* Y, const double* X, double scale, int slot, int chk, bool lr_step = false) {
+  if (lr_step && s->lr.ST > 0) {
+    ProfScope ps(s, "fast_lr_ws");
+    k_fast_lr_ws<<<1, SDPLR_NT, 0, s->stream>>>(s->lr, (int)s->r, s->lr_W, s->y, s->lr_WS, s->ctrl, chk);
+  } else {
+    enq_lowrank(s, X, X, 1, 3, nullptr, nullptr, chk);
+  }
   ProfScope ps(s, "spmm");
   LV_DISPATCH((k_spmm<LPR, VEC><<<s->nb_spmm, SDPLR_NT, 0, s->stream>>>(s->sp, X, Y, (int)s->r, scale, s->lr, s->lr_WS, slot, s->partials, s->ctrl, chk)))
   if (s->sp.n_long_rows > 0) {
@@ -1014,10 +1021,10 @@ void enq_copy2y(S* s, int chk) {
 }
 
 // g!: src/coreop.jl:305-317; y_done = 1 when the line-search commit already produced y
-void enq_g(S* s, int chk, bool y_done) {
+void enq_g(S* s, int chk, bool y_done, bool lr_step = false) {
   if (!y_done) enq_copy2y(s, chk);
   enq_At_preprocess(s, chk);
-  enq_At_left(s, aslot(s->arena, AS_G), aslot(s->arena, AS_R), 2.0, SLOT_GNORM2, chk);
+  enq_At_left(s, aslot(s->arena, AS_G), aslot(s->arena, AS_R), 2.0, SLOT_GNORM2, chk, lr_step);
 }
 
 // f!: src/coreop.jl:11-31
@@ -1113,7 +1120,7 @@ void enq_iteration(S* s, int armijo) {
   enq_lbfgs_dir(s, 1, 1, 1);                 // :197-205
   enq_linesearch(s, armijo, 1, 1);           // :210-214
   enq_axpy_R(s, 1);                          // :219
-  enq_g(s, 1, true);                         // :221
+  enq_g(s, 1, true, !s->no_lrfuse);          // :221
   // norms and the exit tests (:224-241, :272-277, :190) are folded by the next seam kernel
   enq_lbfgs_update(s, 1);                    // :244-246
 }

@@ -430,6 +430,7 @@ def test_concurrent_handles_match_serial(hip_abi):
     ("minimum_bisection", ["SDPLR_HIP_NO_FAST"]),
     ("minimum_bisection", ["SDPLR_HIP_NO_FAST2"]), ("minimum_bisection", ["SDPLR_HIP_NO_LRFUSE"]),
     ("minimum_bisection", ["SDPLR_HIP_NO_TILE"]), ("cutnorm", ["SDPLR_HIP_NO_FAST"]),
+    ("lovasz_theta", ["SDPLR_HIP_NO_LRFUSE"]), ("minimum_bisection", ["SDPLR_HIP_NO_FAST", "SDPLR_HIP_NO_LRFUSE"]),
     ("mu_conductance_0.05", ["SDPLR_HIP_NO_FAST"]), ("ineq_0.05", ["SDPLR_HIP_NO_FAST"]),
 ])
 def test_code_paths_agree(hip_abi, oracle_abi, family, toggles, monkeypatch):
