@@ -374,12 +374,12 @@ int alloc_factors(S* s) {
   const int G = SDPLR_NT / s->LPR;
   s->nb_dense = blocks_for((s->N + 1) / 2, SDPLR_NT, 1024);
   if (const char* e = getenv("SDPLR_HIP_NB_DENSE")) s->nb_dense = std::max(1, std::min(atoi(e), SDPLR_MAXNB));
-  s->nb_upd = std::min(s->nb_dense, 512);
+  s->nb_upd = std::min(s->nb_dense, 256);  // one block per CU streams at full rate; fewer Gram partials for the seam kernel
   if (const char* e = getenv("SDPLR_HIP_NB_UPD")) s->nb_upd = std::max(1, std::min(atoi(e), SDPLR_MAXNB));
   s->nb_sddmm = blocks_for(s->nnzT, G, 8192);
   s->nb_spmm = blocks_for(s->n, G, 768);  // + up to 256 hub-row blocks share the partial slot
   s->nb_tile = blocks_for(s->tile.n_tiles, G, 1024);
-  s->nb_step = blocks_for(s->n, G, 2048);
+  s->nb_step = blocks_for(s->n, G, 1024);  // its ‖G‖², ‖pv‖² partials are folded by the one-block seam kernel: keep them few
   if (const char* e = getenv("SDPLR_HIP_NB_STEP")) s->nb_step = std::max(1, std::min(atoi(e), SDPLR_MAXNB));
   return SDPLR_OK;
 }
