@@ -1317,47 +1317,65 @@ k_lz_spmv(DevSparse sp, DevCtrl* __restrict__ c, const double* __restrict__ u, d
           DevLowRank lr, const double* __restrict__ yvec, const double* __restrict__ btx_part, int nb_prev,
           double* __restrict__ coef_out, double* __restrict__ beta_out, double* __restrict__ partials) {
   __shared__ double sh[8];
-  __shared__ double coef[SDPLR_LRMAX * 8];
-  if (c->lz_done) return;
-  for (int cc = 0; cc < lr.ST; cc++) {  // low-rank coefficients y[gid]·D_c·⟨B_c, u⟩ (src/structs.jl:117-127)
-    const double sidx = reduce_partials(btx_part + (long long)cc * nb_prev, nb_prev, sh);
-    if (threadIdx.x == 0) {
-      const double cf = yvec[lr.col_gid[cc]] * lr.Dcat[cc] * sidx;
-      if (cc < SDPLR_LRMAX * 8) coef[cc] = cf;
-      if (blockIdx.x == 0) coef_out[cc] = cf;
-    }
-    __syncthreads();
+  // Everything the head needs is requested at once — the stop flag, the first trip's row pointers, the partials
+  // of the low-rank coefficients and (block 0) of ‖u‖² — and every wave sums the partials for itself (lanes
+  // stride them, fixed-order butterfly): no block barrier and one memory round trip before the SpMV proper
+  // instead of flag → partials → barrier → partials → pointers.
+  const int dn = c->lz_done;
+  constexpr int G = SDPLR_NT / LPR, RIF = 4;
+  const int lane = threadIdx.x % LPR, wl = threadIdx.x & 63;
+  const long long total = (long long)gridDim.x * G;
+  const long long jfirst = (long long)blockIdx.x * G + threadIdx.x / LPR;
+  int beg0[RIF], end0[RIF];
+#pragma unroll
+  for (int k = 0; k < RIF; k++) {
+    const long long j = min(jfirst + k * total, (long long)sp.n - 1);
+    beg0[k] = sp.colptr[j];
+    end0[k] = sp.colptr[j + 1];
   }
-  if (blockIdx.x == 0) {  // close the previous step (see header)
-    const double nn = reduce_partials(slot_partials(partials, SLOT_LZ_N), nb_prev, sh);
-    if (threadIdx.x == 0) {
-      const double g = sqrt(nn);
-      const long long st = c->lz_steps;
-      if (st > 0) {
-        beta_out[st - 1] = g;                                                  // beta[i] = ‖Av‖  (:492)
-        if (fabs(g) < sqrt((double)sp.n) * 2.220446049250313e-16) c->lz_done = 1;   // (:494-496)
-      }
-      if (st >= c->lz_qmax) c->lz_done = 1;
-      c->lz_gamma_prev = c->lz_gamma_cur;
-      c->lz_gamma_cur = g;
-      c->lz_beta_prev = (st > 0) ? g : 0.0;
+  double coef[SDPLR_LRMAX];
+#pragma unroll
+  for (int cc = 0; cc < SDPLR_LRMAX; cc++) {  // low-rank coefficients y[gid]·D_c·⟨B_c, u⟩ (src/structs.jl:117-127)
+    coef[cc] = 0.0;
+    if (cc < lr.ST) {
+      double sidx = 0.0;
+      for (int i = wl; i < nb_prev; i += 64) sidx += btx_part[(long long)cc * nb_prev + i];
+      sidx = wave_sum(sidx);
+      coef[cc] = yvec[lr.col_gid[cc]] * lr.Dcat[cc] * sidx;
+      if (blockIdx.x == 0 && threadIdx.x == 0) coef_out[cc] = coef[cc];
     }
+  }
+  double nn = 0.0;
+  if (blockIdx.x == 0 && threadIdx.x < 64) {
+    const double* pn = slot_partials(partials, SLOT_LZ_N);
+    for (int i = wl; i < nb_prev; i += 64) nn += pn[i];
+    nn = wave_sum(nn);
+  }
+  if (dn) return;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {  // close the previous step (see header)
+    const double g = sqrt(nn);
+    const long long st = c->lz_steps;
+    if (st > 0) {
+      beta_out[st - 1] = g;                                                  // beta[i] = ‖Av‖  (:492)
+      if (fabs(g) < sqrt((double)sp.n) * 2.220446049250313e-16) c->lz_done = 1;   // (:494-496)
+    }
+    if (st >= c->lz_qmax) c->lz_done = 1;
+    c->lz_gamma_prev = c->lz_gamma_cur;
+    c->lz_gamma_cur = g;
+    c->lz_beta_prev = (st > 0) ? g : 0.0;
   }
   // Four rows per sub-wave group in flight: the row pointers, then the first (index, value) pair of every
   // row, then the four gathers are issued back to back — the kernel is bound by the chain
-  // colptr → rowval → x[rowval] of each row, not by bandwidth (18 → see DESIGN.md for the measured effect).
-  constexpr int G = SDPLR_NT / LPR, RIF = 4;
-  const int lane = threadIdx.x % LPR;
-  const long long total = (long long)gridDim.x * G;
+  // colptr → rowval → x[rowval] of each row, not by bandwidth.
   double dot = 0.0;
-  for (long long j0 = (long long)blockIdx.x * G + threadIdx.x / LPR; j0 < sp.n; j0 += RIF * total) {
+  for (long long j0 = jfirst; j0 < sp.n; j0 += RIF * total) {
     int beg[RIF], end[RIF];
 #pragma unroll
     for (int k = 0; k < RIF; k++) {
       const long long j = j0 + k * total;
       if (j < sp.n) {
-        beg[k] = sp.colptr[j];
-        end[k] = sp.colptr[j + 1];
+        beg[k] = (j0 == jfirst) ? beg0[k] : sp.colptr[j];
+        end[k] = (j0 == jfirst) ? end0[k] : sp.colptr[j + 1];
         if (sp.n_long_rows > 0 && end[k] - beg[k] > sp.long_thresh) end[k] = beg[k];  // hub row: k_spmv_long
       } else {
         beg[k] = end[k] = 0;
@@ -1389,7 +1407,9 @@ k_lz_spmv(DevSparse sp, DevCtrl* __restrict__ c, const double* __restrict__ u, d
       const double v = group_sum<LPR>(tj[k]);
       if (lane == 0 && j < sp.n && !(sp.n_long_rows > 0 && sp.colptr[j + 1] - sp.colptr[j] > sp.long_thresh)) {
         double tv = v;
-        for (int cc = 0; cc < lr.ST; cc++) tv += coef[cc] * lr.Bcat[(long long)cc * sp.n + j];
+#pragma unroll
+        for (int cc = 0; cc < SDPLR_LRMAX; cc++)
+          if (cc < lr.ST) tv += coef[cc] * lr.Bcat[(long long)cc * sp.n + j];
         t[j] = tv;
         dot += u[j] * tv;
       }

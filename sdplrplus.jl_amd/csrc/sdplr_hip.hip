@@ -99,6 +99,7 @@ struct sdplr_hip_solver {
   // kernel shapes
   int LPR = 1, VEC = 1, HM = 4;
   int nb_lzv = 1;  // grid of k_lz_spmv
+  int lz_graph_reps = 0;
   int nb_upd = 1;  // grid of k_lbfgs_update (its per-block partials are folded by one block)
   int nb_dense = 1, nb_m = 1, nb_sddmm = 1, nb_spmm = 1, nb_spmv = 1, nb_nnzT = 1, nb_nnzS = 1, nb_n = 1;
 
@@ -1375,6 +1376,11 @@ int run_lanczos(S* s, int64_t q, const double* v0, double* alpha, double* beta, 
     enq_lz_step(s, b1, b2, b0);
     enq_lz_step(s, b2, b0, b1);
   };
+  // one graph = `reps` rotations (24 steps by default): a graph launch costs several µs of idle device time,
+  // a step that falls through after the last one ≈ 9 µs
+  int reps = 8;
+  if (const char* e = getenv("SDPLR_HIP_LZ_REPS")) reps = std::max(1, std::min(atoi(e), 64));
+  if (s->lz_graph && s->lz_graph_reps != reps) { (void)hipGraphExecDestroy(s->lz_graph); s->lz_graph = nullptr; }
   const int64_t rounds = (q + 1 + 2) / 3;   // q steps + the closing k_lz_spmv of step q+1
   bool use_graph = !s->prof_on && !s->graph_disabled && getenv("SDPLR_HIP_NO_GRAPH") == nullptr;
   if (use_graph && !s->lz_graph && api_lock) {
@@ -1384,10 +1390,11 @@ int run_lanczos(S* s, int64_t q, const double* v0, double* alpha, double* beta, 
       hipGraph_t graph = nullptr;
       bool ok = hipStreamBeginCapture(s->stream, hipStreamCaptureModeRelaxed) == hipSuccess;
       if (ok) {
-        three();
+        for (int t = 0; t < reps; t++) three();
         ok = hipStreamEndCapture(s->stream, &graph) == hipSuccess && graph != nullptr;
       }
       if (ok) ok = hipGraphInstantiate(&s->lz_graph, graph, nullptr, nullptr, 0) == hipSuccess;
+      s->lz_graph_reps = reps;
       if (graph) (void)hipGraphDestroy(graph);
       if (!ok) {
         (void)hipGetLastError();
@@ -1398,9 +1405,10 @@ int run_lanczos(S* s, int64_t q, const double* v0, double* alpha, double* beta, 
     api_lock->lock();
   }
   if (!s->lz_graph) use_graph = false;
-  for (int64_t k = 0; k < rounds; k++) {
-    if (use_graph) HIPCK(s, hipGraphLaunch(s->lz_graph, s->stream));
-    else three();
+  if (use_graph) {
+    for (int64_t k = 0; k < rounds; k += reps) HIPCK(s, hipGraphLaunch(s->lz_graph, s->stream));
+  } else {
+    for (int64_t k = 0; k < rounds; k++) three();
   }
   HIPCK(s, hipGetLastError());
   HIPCK(s, hipMemcpyAsync(alpha, s->lz_alpha, q * sizeof(double), hipMemcpyDeviceToHost, s->stream));
