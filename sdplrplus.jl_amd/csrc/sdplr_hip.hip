@@ -641,6 +641,7 @@ int32_t sdplr_hip_finalize(S* s) {
   }
   // ---- structured fast path: classify the sparse matrices ----
   s->dot_descent = getenv("SDPLR_HIP_DOT_DESCENT") != nullptr;
+  if (const char* e = getenv("SDPLR_HIP_GRAPH_ITERS")) s->graph_iters = std::max(1, std::min(atoi(e), 64));
   s->no_lrfuse = getenv("SDPLR_HIP_NO_LRFUSE") != nullptr;
   if (s->have_sparse && getenv("SDPLR_HIP_NO_FAST") == nullptr) {
     std::vector<int> general;
