@@ -71,6 +71,32 @@ __device__ __forceinline__ void strow(double* __restrict__ p, const vecd<VEC>& o
   }
 }
 
+#ifndef SDPLR_STEP_TR
+#define SDPLR_STEP_TR 4   /* rows per tile of k_fast_step2 (2: 4541, 4: 4565, 8: 4458, 16: 4389 it/s on the north-star instance) */
+#endif
+// base + 32-bit byte offset: with a wave-uniform base the load/store takes the base from SGPRs and the offset
+// from ONE VGPR (global_load … v_off, s[base:base+1]) instead of a 64-bit address pair per array
+__device__ __forceinline__ const double* rowat(const double* base, unsigned off) {
+  return reinterpret_cast<const double*>(reinterpret_cast<const char*>(base) + off);
+}
+__device__ __forceinline__ double* rowat(double* base, unsigned off) {
+  return reinterpret_cast<double*>(reinterpret_cast<char*>(base) + off);
+}
+// non-temporal row load: history that streams through once per kernel should not displace reused lines
+template <int VEC>
+__device__ __forceinline__ vecd<VEC> ldrow_nt(const double* __restrict__ p) {
+  vecd<VEC> o;
+  if constexpr (VEC == 2) {
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    const d2 t = __builtin_nontemporal_load(reinterpret_cast<const d2*>(p));
+    o.v[0] = t.x;
+    o.v[VEC - 1] = t.y;
+  } else {
+    o.v[0] = __builtin_nontemporal_load(p);
+  }
+  return o;
+}
+
 // ---- SDDMM over the upper-triangular pattern --------------------------------------------------------
 // MODE 0: UVt0[q] = ⟨U_c, U_r⟩                                   𝒜_sparse_formUUt!  src/coreop.jl:174-186
 // MODE 1: UVt0[q] = (⟨U_c, V_r⟩ + ⟨V_c, U_r⟩)/2                   𝒜_sparse_formUVt!  src/coreop.jl:188-203
@@ -673,16 +699,25 @@ k_rowdots_ls(int n, int m, DevFast ff, const double* __restrict__ R, const doubl
 
 // step + row-attached commit + g! in structured form (see k_fast_step); extra slots were committed by
 // k_ls_solve_fast, whose y values (y_g, low-rank owners) are read here.
-template <int LPR, int VEC>
+// HMU > 0: lbfgs_update! (src/lbfgs.jl:129-149) rides the same pass — k_lbfgs_update<HMU, true>'s work on the
+// row chunk this lane already holds: dir *= α, s_j = dir, y_j += G_new, and the five families of Gram dots of
+// the new pair against the HMU history slots.  One launch, one read of D and no re-read of G saved per
+// iteration.  The 5·HMU running sums of a lane live in LDS (ds_add_f64 without return, one address per lane and
+// sum: applied in issue order, so each is an ordinary sequential sum) because in registers they pushed the fused
+// kernel to 166 VGPRs and scratch.  Skipped, as lbfgs_update! is, when the relative-decrease exit has been
+// decided (src/sdplr.jl:239-241).
+template <int LPR, int VEC, int HMU>
 __global__ void __launch_bounds__(SDPLR_NT)
-k_fast_step2(int n, int m, DevFast ff, double* __restrict__ R, const double* __restrict__ D,
+k_fast_step2(int n, int m, DevFast ff, double* __restrict__ R, double* __restrict__ D,
              double* __restrict__ P, const double* __restrict__ W, double* __restrict__ Gout, int r,
              double* __restrict__ yvec, const double* __restrict__ lam, const double* __restrict__ lam_ub,
              double* __restrict__ pv_raw, const double* __restrict__ lb, double* __restrict__ pv,
              const double* __restrict__ A_RD, const double* __restrict__ A_DD, DevLowRank lr,
              const double* __restrict__ WS, double* __restrict__ partials, DevCtrl* __restrict__ c,
-             int check_done) {
+             int check_done, FactorArena A, int h) {
+  constexpr int HA = HMU > 0 ? HMU : 1;
   __shared__ double sh[2 * (SDPLR_NT / 64)];
+  extern __shared__ double accl[];  // HMU > 0: [5·HMU][NT] running Gram sums, one column per lane
   // the flag is fetched together with the scalars and the first row, and tested before anything is stored:
   // one memory round trip at the head of the kernel instead of three
   const int dn = check_done ? c->done : 0;
@@ -690,75 +725,189 @@ k_fast_step2(int n, int m, DevFast ff, double* __restrict__ R, const double* __r
   const int lane = threadIdx.x % LPR;
   const long long total = (long long)gridDim.x * G;
   const double a = c->alpha, sigma = c->sigma, yg = yvec[ff.gid_g];
+  const bool upd = HMU > 0 && c->reldelta_exit == 0;
+  const int jslot = HMU > 0 ? (c->latest % h) : 0;
   double red[2] = {0.0, 0.0};  // ‖G‖², ‖pv‖² (row-attached slots)
   const int ch0 = lane * VEC;
-  for (long long j = (long long)blockIdx.x * G + threadIdx.x / LPR; j < n; j += total) {
-    // the row's first chunk is requested before the (dependent) walk over its constraints
-    vecd<VEC> x0, p0, d0, w0;
+  double* const Sj = HMU > 0 ? aslot(A, AS_S0 + jslot) : nullptr;
+  double* const Yj = HMU > 0 ? aslot(A, as_y0(A) + jslot) : nullptr;
+  const double* slp[HA];
+  const double* ylp[HA];
 #pragma unroll
-    for (int k = 0; k < VEC; k++) x0.v[k] = p0.v[k] = d0.v[k] = w0.v[k] = 0.0;
-    if (ch0 < r) {
-      x0 = ldrow<VEC>(R + j * r + ch0);
-      p0 = ldrow<VEC>(P + j * r + ch0);
-      d0 = ldrow<VEC>(D + j * r + ch0);
-      w0 = ldrow<VEC>(W + j * r + ch0);
-    }
+  for (int l = 0; l < HA; l++) {   // slots l ≥ h alias slot 0 (loaded, never used): every load unconditional
+    slp[l] = HMU > 0 ? aslot(A, AS_S0 + ((l < h) ? l : 0)) : nullptr;
+    ylp[l] = HMU > 0 ? aslot(A, as_y0(A) + ((l < h) ? l : 0)) : nullptr;
+  }
+  if (HMU > 0) {
+#pragma unroll
+    for (int k = 0; k < 5 * HMU; k++) accl[k * SDPLR_NT + threadIdx.x] = 0.0;
+  }
+  // A group takes TR ≤ LPR consecutive rows at a time.  Phase A: lane k walks the constraints attached to row
+  // j0 + k (commit of src/linesearch.jl:118-124, y of src/coreop.jl:229-236, the row's diagonal coefficient
+  // d_j) — one dependent pointer → slot → values chain for TR rows instead of one per row.  Phase B: the rows
+  // stream through, two at a time, with d_j handed over from the owning lane.
+  constexpr int TR = LPR < SDPLR_STEP_TR ? LPR : SDPLR_STEP_TR;   // rows per tile
+  const long long ntiles = ((long long)n + TR - 1) / TR;
+  for (long long tile = (long long)blockIdx.x * G + threadIdx.x / LPR; tile < ntiles; tile += total) {
+    const long long j0 = tile * TR;
+    const int nrows = (int)min((long long)TR, (long long)n - j0);
     if (dn) return;
-    double dj = 0.0;
-    for (int e = ff.drow_ptr[j]; e < ff.drow_ptr[j + 1]; e++) {  // every lane of the group: same values
-      const int k = ff.drow_gid[e];
-      const double v = pv_raw[k] + a * (a * A_DD[k] + A_RD[k]);   // src/linesearch.jl:118
-      double yk;
-      if (k < m) {
-        yk = -fmin(lam_ub[k], lam[k] - sigma * v);                // src/coreop.jl:233
-        if (lane == 0) {
-          const double pc = fmax(v, lb[k]);                       // src/linesearch.jl:122-124
+    double djl = 0.0;
+    if (lane < nrows) {
+      const long long j = j0 + lane;
+      const int e0 = ff.drow_ptr[j], e1 = ff.drow_ptr[j + 1];
+      for (int e = e0; e < e1; e++) {
+        const int k = ff.drow_gid[e];
+        const double v = pv_raw[k] + a * (a * A_DD[k] + A_RD[k]);   // src/linesearch.jl:118
+        double yk;
+        if (k < m) {
+          yk = -fmin(lam_ub[k], lam[k] - sigma * v);                // src/coreop.jl:233
+          const double pc = fmax(v, lb[k]);                         // src/linesearch.jl:122-124
           pv[k] = pc;
           red[1] += pc * pc;
+        } else {
+          yk = 1.0;                                                  // the cost slot, src/coreop.jl:235
+          c->obj = v;
         }
-      } else {
-        yk = 1.0;                                                  // the cost slot, src/coreop.jl:235
-        if (lane == 0) c->obj = v;
+        djl += ff.drow_val[e] * yk;
+        yvec[k] = yk;
+        pv_raw[k] = v;
       }
-      dj += ff.drow_val[e] * yk;
-      if (lane == 0) yvec[k] = yk;
     }
-    // pv_raw must be rewritten only after every lane of the group has read it
-    __builtin_amdgcn_wave_barrier();
-    if (lane == 0)
-      for (int e = ff.drow_ptr[j]; e < ff.drow_ptr[j + 1]; e++) {
-        const int k = ff.drow_gid[e];
-        pv_raw[k] = pv_raw[k] + a * (a * A_DD[k] + A_RD[k]);
-      }
-    for (int ch = ch0; ch < r; ch += LPR * VEC) {
-      vecd<VEC> x = x0, pp = p0, d = d0, w = w0;
-      if (ch != ch0) {
-        x = ldrow<VEC>(R + j * r + ch);
-        pp = ldrow<VEC>(P + j * r + ch);
-        d = ldrow<VEC>(D + j * r + ch);
-        w = ldrow<VEC>(W + j * r + ch);
-      }
-      vecd<VEC> g;
+    for (int i0 = 0; i0 < nrows; i0 += 2) {
+      vecd<VEC> xx[2], pq[2], dd[2], ww[2], sv[2][HA], yv[2][HA];
+      double dj[2];
+      unsigned off[2];
 #pragma unroll
-      for (int k = 0; k < VEC; k++) {
-        x.v[k] += a * d.v[k];
-        pp.v[k] += a * w.v[k];
-        g.v[k] = pp.v[k] * yg + x.v[k] * dj;
-      }
-      for (int cc = 0; cc < lr.ST; cc++) {
-        const double b = lr.Bcat[(long long)cc * n + j];
-        const vecd<VEC> ws = ldrow<VEC>(WS + (long long)cc * r + ch);
+      for (int u = 0; u < 2; u++) {
+        const int i = min(i0 + u, nrows - 1);                        // (odd tail: row repeated, not stored twice)
+        const long long j = j0 + i;
+        dj[u] = __shfl(djl, i, LPR);
+        off[u] = (unsigned)(((unsigned long long)j * (unsigned)r + (unsigned)ch0) * 8ull);
 #pragma unroll
-        for (int k = 0; k < VEC; k++) g.v[k] += ws.v[k] * b;
+        for (int q = 0; q < VEC; q++) xx[u].v[q] = pq[u].v[q] = dd[u].v[q] = ww[u].v[q] = 0.0;
+#pragma unroll
+        for (int l = 0; l < HA; l++)
+#pragma unroll
+          for (int q = 0; q < VEC; q++) sv[u][l].v[q] = yv[u][l].v[q] = 0.0;
+        if (ch0 < r) {
+          if (HMU > 0) {
+            // (fused form: one 32-bit byte offset serves all eighteen row accesses — the bases are uniform,
+            // the load adds them — instead of a 64-bit address pair per array; launched only when 8·n·r < 2³²)
+            xx[u] = ldrow<VEC>(rowat(R, off[u]));
+            pq[u] = ldrow<VEC>(rowat(P, off[u]));
+            dd[u] = ldrow<VEC>(rowat(D, off[u]));
+            ww[u] = ldrow<VEC>(rowat(W, off[u]));
+#pragma unroll
+            for (int l = 0; l < HMU; l++) {
+              sv[u][l] = ldrow_nt<VEC>(rowat(slp[l], off[u]));
+              yv[u][l] = ldrow_nt<VEC>(rowat(ylp[l], off[u]));
+            }
+          } else {
+            xx[u] = ldrow<VEC>(R + j * r + ch0);
+            pq[u] = ldrow<VEC>(P + j * r + ch0);
+            dd[u] = ldrow<VEC>(D + j * r + ch0);
+            ww[u] = ldrow<VEC>(W + j * r + ch0);
+          }
+        }
       }
 #pragma unroll
-      for (int k = 0; k < VEC; k++) {
-        g.v[k] *= 2.0;
-        red[0] += g.v[k] * g.v[k];
+      for (int u = 0; u < 2; u++) {
+        if (i0 + u >= nrows) break;
+        const long long j = j0 + i0 + u;
+        for (int ch = ch0; ch < r; ch += LPR * VEC) {
+          vecd<VEC> x = xx[u], pp = pq[u], d = dd[u], w = ww[u];
+          if (HMU == 0 && ch != ch0) {   // (the fused form is launched for single-chunk rows only, r ≤ LPR·VEC)
+            x = ldrow<VEC>(R + j * r + ch);
+            pp = ldrow<VEC>(P + j * r + ch);
+            d = ldrow<VEC>(D + j * r + ch);
+            w = ldrow<VEC>(W + j * r + ch);
+          }
+          vecd<VEC> g;
+#pragma unroll
+          for (int q = 0; q < VEC; q++) {
+            x.v[q] += a * d.v[q];
+            pp.v[q] += a * w.v[q];
+            g.v[q] = pp.v[q] * yg + x.v[q] * dj[u];
+          }
+          for (int cc = 0; cc < lr.ST; cc++) {
+            const double bb = lr.Bcat[(long long)cc * n + j];
+            const vecd<VEC> ws = ldrow<VEC>(WS + (long long)cc * r + ch);
+#pragma unroll
+            for (int q = 0; q < VEC; q++) g.v[q] += ws.v[q] * bb;
+          }
+#pragma unroll
+          for (int q = 0; q < VEC; q++) {
+            g.v[q] *= 2.0;
+            red[0] += g.v[q] * g.v[q];
+          }
+          if (HMU > 0) {
+            strow<VEC>(rowat(R, off[u]), x);
+            strow<VEC>(rowat(P, off[u]), pp);
+            strow<VEC>(rowat(Gout, off[u]), g);
+          } else {
+            strow<VEC>(R + j * r + ch, x);
+            strow<VEC>(P + j * r + ch, pp);
+            strow<VEC>(Gout + j * r + ch, g);
+          }
+          if (HMU > 0 && upd) {
+            vecd<VEC> sn, yn;
+#pragma unroll
+            for (int q = 0; q < VEC; q++) yn.v[q] = 0.0;
+#pragma unroll
+            for (int l = 0; l < HMU; l++)      // the stored y_j holds −G_old, written by lbfgs_dir!
+              if (l == jslot) yn = yv[u][l];
+#pragma unroll
+            for (int q = 0; q < VEC; q++) {
+              sn.v[q] = a * d.v[q];            // BLAS.scal!(stepsize, dir)  (src/lbfgs.jl:142)
+              yn.v[q] += g.v[q];               // axpy!(1, grad, y_j)  (:145)
+            }
+            strow<VEC>(rowat(D, off[u]), sn);
+            strow<VEC>(rowat(Sj, off[u]), sn);   // copy!(s_j, dir)  (:143)
+            strow<VEC>(rowat(Yj, off[u]), yn);
+#pragma unroll
+            for (int l = 0; l < HMU; l++)
+              if (l < h) {
+                const vecd<VEC> sl = (l == jslot) ? sn : sv[u][l];
+                const vecd<VEC> yl = (l == jslot) ? yn : yv[u][l];
+                double q0 = 0.0, q1 = 0.0, q2 = 0.0, q3 = 0.0, q4 = 0.0;
+#pragma unroll
+                for (int q = 0; q < VEC; q++) {
+                  q0 += sn.v[q] * yl.v[q];
+                  q1 += sl.v[q] * yn.v[q];
+                  q2 += yn.v[q] * yl.v[q];
+                  q3 += sl.v[q] * g.v[q];
+                  q4 += yl.v[q] * g.v[q];
+                }
+                double* ac = accl + threadIdx.x;
+                (void)__hip_atomic_fetch_add(ac + (0 * HMU + l) * SDPLR_NT, q0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                (void)__hip_atomic_fetch_add(ac + (1 * HMU + l) * SDPLR_NT, q1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                (void)__hip_atomic_fetch_add(ac + (2 * HMU + l) * SDPLR_NT, q2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                (void)__hip_atomic_fetch_add(ac + (3 * HMU + l) * SDPLR_NT, q3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                (void)__hip_atomic_fetch_add(ac + (4 * HMU + l) * SDPLR_NT, q4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+              }
+          }
+          if (HMU > 0) break;
+        }
       }
-      strow<VEC>(R + j * r + ch, x);
-      strow<VEC>(P + j * r + ch, pp);
-      strow<VEC>(Gout + j * r + ch, g);
+    }
+  }
+  if (dn) return;
+  if constexpr (HMU > 0) {
+    // block sums of the running Gram sums straight out of LDS, one wave per sum (lanes stride the NT columns,
+    // fixed-order butterfly) — a register-resident block_sum<20> here cost the whole kernel its occupancy
+    __syncthreads();
+    if (upd) {
+      const int wave = threadIdx.x >> 6, wl = threadIdx.x & 63;
+      for (int k = wave; k < 5 * HMU; k += SDPLR_NT / 64) {
+        double t = 0.0;
+#pragma unroll
+        for (int i = 0; i < SDPLR_NT / 64; i++) t += accl[k * SDPLR_NT + wl + 64 * i];
+        t = wave_sum(t);
+        const int q = k / HMU, l = k % HMU;
+        if (wl == 0 && l < h) slot_partials(partials, SLOT_GRAM + q * SDPLR_HMAX + l)[blockIdx.x] = t;
+      }
+      if (blockIdx.x == 0 && threadIdx.x == 0) c->gram_pending = 1;  // consumed by k_lbfgs_boundary
     }
   }
   block_sum<2>(red, sh);

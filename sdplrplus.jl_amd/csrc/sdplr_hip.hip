@@ -73,6 +73,8 @@ struct sdplr_hip_solver {
   DevTile tile{};            // the same matrix as column-sorted K-row tiles (k_spmm_tile)
   int nb_tile = 0, nb_step = 1;
   bool use_tile = false;
+  bool no_updfuse = false;   // SDPLR_HIP_NO_UPDFUSE: lbfgs_update! as a kernel of its own on the singleton fast path
+  int gram_nb = 1;           // number of Gram partials the latest enqueued producer writes (k_lbfgs_update / fused step)
   bool no_lrfuse = false;    // SDPLR_HIP_NO_LRFUSE: low-rank projections by k_lr_project even on the tile path
   bool dot_descent = false;  // SDPLR_HIP_DOT_DESCENT: in-loop ⟨dir, G⟩ by reduction (k_descent) instead of the Gram form
   int tile_lpr = 0;          // the lists are padded to multiples of this sub-wave width
@@ -380,7 +382,8 @@ int alloc_factors(S* s) {
   s->nb_sddmm = blocks_for(s->nnzT, G, 8192);
   s->nb_spmm = blocks_for(s->n, G, 768);  // + up to 256 hub-row blocks share the partial slot
   s->nb_tile = blocks_for(s->tile.n_tiles, G, 1024);
-  s->nb_step = blocks_for(s->n, G, 1024);  // its ‖G‖², ‖pv‖² partials are folded by the one-block seam kernel: keep them few
+  { const int tr = std::min<int>(s->LPR, SDPLR_STEP_TR); s->nb_step = blocks_for((s->n + tr - 1) / tr, G, 1024); }  // one group per tile of LPR rows; its ‖G‖², ‖pv‖² (and Gram)
+                                                                    // partials are folded by the one-block seam kernel: keep them few
   if (const char* e = getenv("SDPLR_HIP_NB_STEP")) s->nb_step = std::max(1, std::min(atoi(e), SDPLR_MAXNB));
   return SDPLR_OK;
 }
@@ -643,6 +646,7 @@ int32_t sdplr_hip_finalize(S* s) {
   s->dot_descent = getenv("SDPLR_HIP_DOT_DESCENT") != nullptr;
   if (const char* e = getenv("SDPLR_HIP_GRAPH_ITERS")) s->graph_iters = std::max(1, std::min(atoi(e), 64));
   s->no_lrfuse = getenv("SDPLR_HIP_NO_LRFUSE") != nullptr;
+  s->no_updfuse = getenv("SDPLR_HIP_NO_UPDFUSE") != nullptr;
   if (s->have_sparse && getenv("SDPLR_HIP_NO_FAST") == nullptr) {
     std::vector<int> general;
     for (int64_t k = 0; k < s->n_sparse; k++) {
@@ -1043,9 +1047,10 @@ void enq_f(S* s) {
 // 1-block seam kernel: fold update partials / loop tests / two-loop coefficients (k_dense.h)
 void enq_boundary(S* s, int jfixed, int fin_mode, int do_loop, int do_coeff, int desc_mode = 0) {
   ProfScope ps(s, "lbfgs_boundary");
-  k_lbfgs_boundary<<<1, 1024, 0, s->stream>>>(s->ctrl, (int)s->h, jfixed, fin_mode, do_loop, do_coeff, s->nb_upd, s->partials, desc_mode);
+  k_lbfgs_boundary<<<1, 1024, 0, s->stream>>>(s->ctrl, (int)s->h, jfixed, fin_mode, do_loop, do_coeff, s->gram_nb, s->partials, desc_mode);
 }
 void enq_gram_row(S* s, int j) {
+  s->gram_nb = s->nb_upd;
   HM_DISPATCH((k_lbfgs_update<HM, false><<<s->nb_upd, SDPLR_NT, 0, s->stream>>>(s->ctrl, s->arena, s->N, (int)s->h, j, 0, s->partials)))
   enq_boundary(s, j, 2, 0, 0);
 }
@@ -1086,6 +1091,7 @@ void enq_lbfgs_dir(S* s, int negate, int in_loop, int apply_fallback) {
 // lbfgs_update!: the pass over the history; its partials are folded by the next seam kernel
 void enq_lbfgs_update(S* s, int chk) {
   if (s->h == 0) return;
+  s->gram_nb = s->nb_upd;
   ProfScope ps(s, "lbfgs_update");
   HM_DISPATCH((k_lbfgs_update<HM, true><<<s->nb_upd, SDPLR_NT, 0, s->stream>>>(s->ctrl, s->arena, s->N, (int)s->h, 0, chk, s->partials)))
 }
@@ -1119,6 +1125,7 @@ void enq_axpy_R(S* s, int chk) {
 
 // one pass of the while body, src/sdplr.jl:190-278, entirely device-driven
 void enq_iteration(S* s, int armijo) {
+  s->gram_nb = s->nb_upd;                    // this path's lbfgs_update! grid (read by the seam kernel)
   enq_lbfgs_dir(s, 1, 1, 1);                 // :197-205
   enq_linesearch(s, armijo, 1, 1);           // :210-214
   enq_axpy_R(s, 1);                          // :219
@@ -1145,6 +1152,7 @@ void enq_fast_refresh_P(S* s) {
 void enq_iteration_fast(S* s, int armijo) {
   double *R = aslot(s->arena, AS_R), *G = aslot(s->arena, AS_G), *D = aslot(s->arena, AS_D);
   double *P = fast_P(s), *W = fast_W(s);
+  s->gram_nb = s->nb_upd;
   enq_lbfgs_dir(s, 1, 1, 1);                                                          // :197-205
   // ---- line search head: 𝒜(RDᵀ+DRᵀ), 𝒜(DDᵀ)  (src/linesearch.jl:8-18) ----
   if (!s->all_covered) {
@@ -1217,6 +1225,9 @@ void enq_iteration_fast2(S* s) {
   double *R = aslot(s->arena, AS_R), *G = aslot(s->arena, AS_G), *D = aslot(s->arena, AS_D);
   double *P = fast_P(s), *W = fast_W(s);
   bool lr_fused = false;
+  // lbfgs_update! fused into the step kernel for h ≤ 4 (its Gram partials then come from nb_step blocks)
+  const bool upd_fused = s->h >= 1 && s->h <= 4 && s->r <= (int64_t)s->LPR * s->VEC && s->n * s->r * 8 < (1LL << 32) && !s->no_updfuse;
+  s->gram_nb = upd_fused ? s->nb_step : s->nb_upd;
   enq_lbfgs_dir(s, 1, 1, 1);                                                          // :197-205
   {
     ProfScope ps(s, "spmm_W");   // W = A_g·D + row dots + line-search sums of the row-attached constraints
@@ -1245,9 +1256,13 @@ void enq_iteration_fast2(S* s) {
   // two kernels — 166 VGPRs and scratch — and dropped)
   {
     ProfScope ps(s, "fast_step");                                                     // :219-234
-    LV_DISPATCH((k_fast_step2<LPR, VEC><<<s->nb_step, SDPLR_NT, 0, s->stream>>>((int)s->n, (int)s->m, s->ff, R, D, P, W, G, (int)s->r, s->y, s->lambda, s->lambda_ub, s->pv_raw, s->pv_lb, s->pv, s->A_RD, s->A_DD, s->lr, s->lr_WS, s->partials, s->ctrl, 1)))
+    if (upd_fused) {   // … and lbfgs_update! (:244-246) in the same pass
+      LV_DISPATCH((k_fast_step2<LPR, VEC, 4><<<s->nb_step, SDPLR_NT, 5 * 4 * SDPLR_NT * sizeof(double), s->stream>>>((int)s->n, (int)s->m, s->ff, R, D, P, W, G, (int)s->r, s->y, s->lambda, s->lambda_ub, s->pv_raw, s->pv_lb, s->pv, s->A_RD, s->A_DD, s->lr, s->lr_WS, s->partials, s->ctrl, 1, s->arena, (int)s->h)))
+    } else {
+      LV_DISPATCH((k_fast_step2<LPR, VEC, 0><<<s->nb_step, SDPLR_NT, 0, s->stream>>>((int)s->n, (int)s->m, s->ff, R, D, P, W, G, (int)s->r, s->y, s->lambda, s->lambda_ub, s->pv_raw, s->pv_lb, s->pv, s->A_RD, s->A_DD, s->lr, s->lr_WS, s->partials, s->ctrl, 1, s->arena, (int)s->h)))
+    }
   }
-  enq_lbfgs_update(s, 1);                                                             // :244-246
+  if (!upd_fused) enq_lbfgs_update(s, 1);                                             // :244-246
 }
 
 // host restatement of the Sturm bisection for the Lanczos tridiagonal

@@ -426,6 +426,7 @@ def test_concurrent_handles_match_serial(hip_abi):
 
 @pytest.mark.parametrize("family,toggles", [
     ("maxcut", ["SDPLR_HIP_NO_FAST"]), ("maxcut", ["SDPLR_HIP_NO_FAST2"]), ("maxcut", ["SDPLR_HIP_NO_GRAPH"]),
+    ("maxcut", ["SDPLR_HIP_NO_UPDFUSE"]), ("minimum_bisection", ["SDPLR_HIP_NO_UPDFUSE"]),
     ("maxcut", ["SDPLR_HIP_DOT_DESCENT"]), ("cutnorm", ["SDPLR_HIP_DOT_DESCENT"]), ("ineq_0.05", ["SDPLR_HIP_DOT_DESCENT"]),
     ("minimum_bisection", ["SDPLR_HIP_NO_FAST"]),
     ("minimum_bisection", ["SDPLR_HIP_NO_FAST2"]), ("minimum_bisection", ["SDPLR_HIP_NO_LRFUSE"]),
@@ -619,7 +620,8 @@ def test_unusual_structures(hip_abi, oracle_abi, kind, r):
     assert np.max(np.abs(g.primal_vio_raw - primal_vio_dense(C, As, bs, g.Rt))) < 1e-8 * (1 + np.max(np.abs(g.primal_vio_raw)))
     v0 = rng.standard_normal(n)
     (dg, eg), (do, eo) = g.dual_obj(5.0, 0, v0), o.dual_obj(5.0, 0, v0)
-    assert eg == pytest.approx(eo, rel=1e-7, abs=1e-9) and dg == pytest.approx(do, rel=1e-7, abs=1e-9)
+    # λ_min inherits the 1e-8 agreement of R on the scale of ‖S‖ = O(1), not on its own (it can be ≈ 1e-2)
+    assert eg == pytest.approx(eo, rel=1e-7, abs=2e-7) and dg == pytest.approx(do, rel=1e-7, abs=1e-6)
     g.close(); o.close()
 
 
