@@ -361,6 +361,11 @@ int build_tiles(S* s) {
   return SDPLR_OK;
 }
 
+// lbfgs_update! rides k_fast_step2 (singleton fast path) for h ≤ 4, single-chunk rows and 32-bit row offsets
+bool step_fuses_update(const S* s) {
+  return s->h >= 1 && s->h <= 4 && s->r <= (int64_t)s->LPR * s->VEC && s->n * s->r * 8 < (1LL << 32) && !s->no_updfuse;
+}
+
 int alloc_factors(S* s) {
   s->N = s->n * s->r;
   long long stride = (s->N + 31) / 32 * 32;
@@ -382,7 +387,7 @@ int alloc_factors(S* s) {
   s->nb_sddmm = blocks_for(s->nnzT, G, 8192);
   s->nb_spmm = blocks_for(s->n, G, 768);  // + up to 256 hub-row blocks share the partial slot
   s->nb_tile = blocks_for(s->tile.n_tiles, G, 1024);
-  { const int tr = std::min<int>(s->LPR, SDPLR_STEP_TR); s->nb_step = blocks_for((s->n + tr - 1) / tr, G, 1024); }  // one group per tile of LPR rows; its ‖G‖², ‖pv‖² (and Gram)
+  { const int tr = std::min<int>(s->LPR, SDPLR_STEP_TR); s->nb_step = blocks_for((s->n + tr - 1) / tr, G, step_fuses_update(s) ? 512 : 1024); }  // one group per tile of LPR rows; its ‖G‖², ‖pv‖² (and Gram)
                                                                     // partials are folded by the one-block seam kernel: keep them few
   if (const char* e = getenv("SDPLR_HIP_NB_STEP")) s->nb_step = std::max(1, std::min(atoi(e), SDPLR_MAXNB));
   return SDPLR_OK;
@@ -1226,7 +1231,7 @@ void enq_iteration_fast2(S* s) {
   double *P = fast_P(s), *W = fast_W(s);
   bool lr_fused = false;
   // lbfgs_update! fused into the step kernel for h ≤ 4 (its Gram partials then come from nb_step blocks)
-  const bool upd_fused = s->h >= 1 && s->h <= 4 && s->r <= (int64_t)s->LPR * s->VEC && s->n * s->r * 8 < (1LL << 32) && !s->no_updfuse;
+  const bool upd_fused = step_fuses_update(s);
   s->gram_nb = upd_fused ? s->nb_step : s->nb_upd;
   enq_lbfgs_dir(s, 1, 1, 1);                                                          // :197-205
   {
