@@ -862,7 +862,8 @@ k_fast_step2(int n, int m, DevFast ff, double* __restrict__ R, double* __restric
               sn.v[q] = a * d.v[q];            // BLAS.scal!(stepsize, dir)  (src/lbfgs.jl:142)
               yn.v[q] += g.v[q];               // axpy!(1, grad, y_j)  (:145)
             }
-            strow<VEC>(rowat(D, off[u]), sn);
+            // dir *= α (:142) is not stored here: nothing reads the scaled direction before lbfgs_dir!
+            // overwrites it, and the host copies s_j into dirt when the loop is left (sdplr_hip_inner_loop)
             strow<VEC>(rowat(Sj, off[u]), sn);   // copy!(s_j, dir)  (:143)
             strow<VEC>(rowat(Yj, off[u]), yn);
 #pragma unroll

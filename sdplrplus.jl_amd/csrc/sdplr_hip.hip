@@ -1772,6 +1772,10 @@ int32_t sdplr_hip_inner_loop(S* s, double normC, double normb, int32_t grel, int
   if (fastp) enq_At_preprocess(s, 0);  // leave S consistent with the y of the last step, as g! would
   if ((rc = pull(s))) return rc;
   if (c->done) why = c->exit_reason;   // the device's verdict wins over the host's time check
+  if (fast2 && step_fuses_update(s) && c->iters > 0 && c->err == 0 && why != EXIT_RELDELTA) {
+    // the fused step + update kernel leaves `dirt *= α` (src/lbfgs.jl:142) to this copy: dirt = s_latest
+    HIPCK(s, hipMemcpyAsync(aslot(s->arena, AS_D), aslot(s->arena, AS_S0 + (c->latest - 1)), s->N * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
+  }
   if (dbg)
     fprintf(stderr, "[sdplr_hip] inner_loop: %d batches (%s), host enqueue %.3f ms, host wait %.3f ms, iters %lld\n",
             n_batches, use_graph ? "graph" : "eager", 1e3 * t_enq, 1e3 * t_wait, (long long)c->iters);

@@ -151,6 +151,9 @@ def test_inner_loop_trajectory(hip_abi, oracle_abi, family):
         assert rg[4] == ro[4] == 1 and rg[5] == ro[5] == 2
         assert np.allclose(rg[:3], ro[:3], rtol=1e-8, atol=1e-12), (it, rg, ro)
         assert rel(g.Rt, o.Rt) < 1e-8
+        # dirt left as lbfgs_update! leaves it (dirt *= α, src/lbfgs.jl:142) — the fused step kernel skips that
+        # store inside the loop and the library restores it from s_latest on the way out
+        assert rel(g.dirt, o.dirt) < 1e-7
         sg, so = rg[:3], ro[:3]
     # many iterations in one call, early exit by the gradient test
     g2, o2 = pair(hip_abi, oracle_abi, data, r, 11)
@@ -159,12 +162,16 @@ def test_inner_loop_trajectory(hip_abi, oracle_abi, family):
     ro = o2.inner_loop(normC, normb, True, True, armijo, 0.3 * so[1], -1e300, 500, 0.0, *so)
     assert rg[4] == ro[4] and rg[5] == ro[5] == 0
     assert np.allclose(rg[:3], ro[:3], rtol=1e-6)
+    assert rel(g2.dirt, o2.dirt) < 1e-5
     # iteration budget exit
     rg = g2.inner_loop(normC, normb, True, True, armijo, 0.0, -1e300, 5, 0.0, *rg[:3])
     assert rg[4] == 5 and rg[5] == 2
     # relative-decrease exit with a huge fprec (always fires after the first step)
     rg = g2.inner_loop(normC, normb, True, True, armijo, 0.0, 1e300, 50, 0.0, *rg[:3])
     assert rg[4] == 1 and rg[5] == 1
+    ro = o2.inner_loop(normC, normb, True, True, armijo, 0.0, -1e300, 5, 0.0, *ro[:3])
+    ro = o2.inner_loop(normC, normb, True, True, armijo, 0.0, 1e300, 50, 0.0, *ro[:3])
+    assert ro[4] == 1 and ro[5] == 1 and rel(g2.dirt, o2.dirt) < 1e-5   # no lbfgs_update! before this exit: dirt unscaled
     for s_ in (g, o, g2, o2):
         s_.close()
 
