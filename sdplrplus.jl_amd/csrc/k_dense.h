@@ -257,7 +257,8 @@ k_lbfgs_dir(const DevCtrl* __restrict__ c, FactorArena A, long long N, int h, in
       j = (j <= 0) ? h - 1 : j - 1;
     }
   }
-  double* ynext = (h > 0) ? aslot(A, as_y0(A) + (latest % h)) : nullptr;
+  // inline_fallback == 2: the fused step + update kernel reads G_old from the G array itself, nothing to park
+  double* ynext = (h > 0 && inline_fallback != 2) ? aslot(A, as_y0(A) + (latest % h)) : nullptr;
   const double sgn = negate ? -1.0 : 1.0;
   if (dn) return;
   double desc = 0.0;

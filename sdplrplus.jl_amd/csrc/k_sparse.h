@@ -709,12 +709,12 @@ k_rowdots_ls(int n, int m, DevFast ff, const double* __restrict__ R, const doubl
 template <int LPR, int VEC, int HMU>
 __global__ void __launch_bounds__(SDPLR_NT)
 k_fast_step2(int n, int m, DevFast ff, double* __restrict__ R, double* __restrict__ D,
-             double* __restrict__ P, const double* __restrict__ W, double* __restrict__ Gout, int r,
+             double* __restrict__ P, const double* __restrict__ W, double* Gout, int r,
              double* __restrict__ yvec, const double* __restrict__ lam, const double* __restrict__ lam_ub,
              double* __restrict__ pv_raw, const double* __restrict__ lb, double* __restrict__ pv,
              const double* __restrict__ A_RD, const double* __restrict__ A_DD, DevLowRank lr,
              const double* __restrict__ WS, double* __restrict__ partials, DevCtrl* __restrict__ c,
-             int check_done, FactorArena A, int h) {
+             int check_done, FactorArena A, int h, int gold_in_G) {
   constexpr int HA = HMU > 0 ? HMU : 1;
   __shared__ double sh[2 * (SDPLR_NT / 64)];
   extern __shared__ double accl[];  // HMU > 0: [5·HMU][NT] running Gram sums, one column per lane
@@ -726,6 +726,8 @@ k_fast_step2(int n, int m, DevFast ff, double* __restrict__ R, double* __restric
   const long long total = (long long)gridDim.x * G;
   const double a = c->alpha, sigma = c->sigma, yg = yvec[ff.gid_g];
   const bool upd = HMU > 0 && c->reldelta_exit == 0;
+  // slot j's stream carries −G_old (parked by lbfgs_dir!) or, with gold_in_G, the G array itself: ±G_old
+  const double gs = (HMU > 0 && gold_in_G) ? (c->fallback ? 1.0 : -1.0) : 1.0;
   const int jslot = HMU > 0 ? (c->latest % h) : 0;
   double red[2] = {0.0, 0.0};  // ‖G‖², ‖pv‖² (row-attached slots)
   const int ch0 = lane * VEC;
@@ -737,6 +739,11 @@ k_fast_step2(int n, int m, DevFast ff, double* __restrict__ R, double* __restric
   for (int l = 0; l < HA; l++) {   // slots l ≥ h alias slot 0 (loaded, never used): every load unconditional
     slp[l] = HMU > 0 ? aslot(A, AS_S0 + ((l < h) ? l : 0)) : nullptr;
     ylp[l] = HMU > 0 ? aslot(A, as_y0(A) + ((l < h) ? l : 0)) : nullptr;
+    // y_j = G_new − G_old (src/lbfgs.jl:121-123,145): G_old is still in the G array when this lane reaches the
+    // element — it is read there, in place of the −G_old that lbfgs_dir! would have parked in slot j (the
+    // in-loop direction kernel skips that store: N bytes per iteration less)
+    // (gold_in_G; if the direction kernel took the steepest-descent fallback it has flipped G: sign gs)
+    if (HMU > 0 && gold_in_G && l == jslot) ylp[l] = Gout;
   }
   if (HMU > 0) {
 #pragma unroll
@@ -850,17 +857,28 @@ k_fast_step2(int n, int m, DevFast ff, double* __restrict__ R, double* __restric
             strow<VEC>(P + j * r + ch, pp);
             strow<VEC>(Gout + j * r + ch, g);
           }
+          if (HMU > 0 && !upd) {   // leaving through the relative-decrease exit: y_next = −G_old as lbfgs_dir! leaves it
+            vecd<VEC> go;
+#pragma unroll
+            for (int q = 0; q < VEC; q++) go.v[q] = 0.0;
+#pragma unroll
+            for (int l = 0; l < HMU; l++)
+              if (l == jslot) go = yv[u][l];
+#pragma unroll
+            for (int q = 0; q < VEC; q++) go.v[q] = gs * go.v[q];
+            if (gold_in_G) strow<VEC>(rowat(Yj, off[u]), go);
+          }
           if (HMU > 0 && upd) {
             vecd<VEC> sn, yn;
 #pragma unroll
             for (int q = 0; q < VEC; q++) yn.v[q] = 0.0;
 #pragma unroll
-            for (int l = 0; l < HMU; l++)      // the stored y_j holds −G_old, written by lbfgs_dir!
+            for (int l = 0; l < HMU; l++)      // slot j's stream is the G array: G_old
               if (l == jslot) yn = yv[u][l];
 #pragma unroll
             for (int q = 0; q < VEC; q++) {
               sn.v[q] = a * d.v[q];            // BLAS.scal!(stepsize, dir)  (src/lbfgs.jl:142)
-              yn.v[q] += g.v[q];               // axpy!(1, grad, y_j)  (:145)
+              yn.v[q] = gs * yn.v[q] + g.v[q]; // y_j = −G_old + G_new  (:122,145)
             }
             // dir *= α (:142) is not stored here: nothing reads the scaled direction before lbfgs_dir!
             // overwrites it, and the host copies s_j into dirt when the loop is left (sdplr_hip_inner_loop)

@@ -1074,7 +1074,7 @@ void ensure_gram(S* s) {
 
 // lbfgs_dir! (+ descent): [seam: pending Gram rows, loop tests, coefficients] → direction → descent
 // (with the optional on-device steepest-descent fallback)
-void enq_lbfgs_dir(S* s, int negate, int in_loop, int apply_fallback) {
+void enq_lbfgs_dir(S* s, int negate, int in_loop, int apply_fallback, bool skip_ynext = false) {
   // m == 0: the reference returns right after copyto!(dir, grad), before the negation
   // (src/lbfgs.jl:88-91); the caller's descent test then falls back to −G (src/sdplr.jl:202-205).
   if (s->h == 0) negate = 0;
@@ -1085,7 +1085,7 @@ void enq_lbfgs_dir(S* s, int negate, int in_loop, int apply_fallback) {
   enq_boundary(s, 0, in_loop ? 1 : 0, in_loop, 1, analytic ? (negate ? 1 : 2) : 0);
   {
     ProfScope ps(s, "lbfgs_dir");
-    HM_DISPATCH((k_lbfgs_dir<HM><<<s->nb_dense, SDPLR_NT, 0, s->stream>>>(s->ctrl, s->arena, s->N, (int)s->h, negate, in_loop, s->partials, analytic)))
+    HM_DISPATCH((k_lbfgs_dir<HM><<<s->nb_dense, SDPLR_NT, 0, s->stream>>>(s->ctrl, s->arena, s->N, (int)s->h, negate, in_loop, s->partials, (analytic && skip_ynext) ? 2 : analytic)))
   }
   if (analytic) return;
   ProfScope ps(s, "descent");
@@ -1233,7 +1233,7 @@ void enq_iteration_fast2(S* s) {
   // lbfgs_update! fused into the step kernel for h ≤ 4 (its Gram partials then come from nb_step blocks)
   const bool upd_fused = step_fuses_update(s);
   s->gram_nb = upd_fused ? s->nb_step : s->nb_upd;
-  enq_lbfgs_dir(s, 1, 1, 1);                                                          // :197-205
+  enq_lbfgs_dir(s, 1, 1, 1, upd_fused && !s->dot_descent);                            // :197-205
   {
     ProfScope ps(s, "spmm_W");   // W = A_g·D + row dots + line-search sums of the row-attached constraints
     if (s->use_tile && s->tile_lpr == s->LPR && s->n * s->r * 8 < (1LL << 32)) {
@@ -1262,9 +1262,9 @@ void enq_iteration_fast2(S* s) {
   {
     ProfScope ps(s, "fast_step");                                                     // :219-234
     if (upd_fused) {   // … and lbfgs_update! (:244-246) in the same pass
-      LV_DISPATCH((k_fast_step2<LPR, VEC, 4><<<s->nb_step, SDPLR_NT, 5 * 4 * SDPLR_NT * sizeof(double), s->stream>>>((int)s->n, (int)s->m, s->ff, R, D, P, W, G, (int)s->r, s->y, s->lambda, s->lambda_ub, s->pv_raw, s->pv_lb, s->pv, s->A_RD, s->A_DD, s->lr, s->lr_WS, s->partials, s->ctrl, 1, s->arena, (int)s->h)))
+      LV_DISPATCH((k_fast_step2<LPR, VEC, 4><<<s->nb_step, SDPLR_NT, 5 * 4 * SDPLR_NT * sizeof(double), s->stream>>>((int)s->n, (int)s->m, s->ff, R, D, P, W, G, (int)s->r, s->y, s->lambda, s->lambda_ub, s->pv_raw, s->pv_lb, s->pv, s->A_RD, s->A_DD, s->lr, s->lr_WS, s->partials, s->ctrl, 1, s->arena, (int)s->h, s->dot_descent ? 0 : 1)))
     } else {
-      LV_DISPATCH((k_fast_step2<LPR, VEC, 0><<<s->nb_step, SDPLR_NT, 0, s->stream>>>((int)s->n, (int)s->m, s->ff, R, D, P, W, G, (int)s->r, s->y, s->lambda, s->lambda_ub, s->pv_raw, s->pv_lb, s->pv, s->A_RD, s->A_DD, s->lr, s->lr_WS, s->partials, s->ctrl, 1, s->arena, (int)s->h)))
+      LV_DISPATCH((k_fast_step2<LPR, VEC, 0><<<s->nb_step, SDPLR_NT, 0, s->stream>>>((int)s->n, (int)s->m, s->ff, R, D, P, W, G, (int)s->r, s->y, s->lambda, s->lambda_ub, s->pv_raw, s->pv_lb, s->pv, s->A_RD, s->A_DD, s->lr, s->lr_WS, s->partials, s->ctrl, 1, s->arena, (int)s->h, 0)))
     }
   }
   if (!upd_fused) enq_lbfgs_update(s, 1);                                             // :244-246

@@ -172,6 +172,10 @@ def test_inner_loop_trajectory(hip_abi, oracle_abi, family):
     ro = o2.inner_loop(normC, normb, True, True, armijo, 0.0, -1e300, 5, 0.0, *ro[:3])
     ro = o2.inner_loop(normC, normb, True, True, armijo, 0.0, 1e300, 50, 0.0, *ro[:3])
     assert ro[4] == 1 and ro[5] == 1 and rel(g2.dirt, o2.dirt) < 1e-5   # no lbfgs_update! before this exit: dirt unscaled
+    # the state that exit leaves behind (history with y_next = −G_old parked, G rewritten by g!) must carry on
+    rg2 = g2.inner_loop(normC, normb, True, True, armijo, 0.0, -1e300, 4, 0.0, *rg[:3])
+    ro2 = o2.inner_loop(normC, normb, True, True, armijo, 0.0, -1e300, 4, 0.0, *ro[:3])
+    assert rg2[4] == ro2[4] == 4 and np.allclose(rg2[:3], ro2[:3], rtol=1e-5) and rel(g2.Rt, o2.Rt) < 1e-5
     for s_ in (g, o, g2, o2):
         s_.close()
 
