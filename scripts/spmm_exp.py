@@ -1,4 +1,5 @@
-"""dev tool: time of the W = A_g·D kernel under an experimental build (SDPLR_HIP_LIBRARY=…); results may be garbage"""
+"""dev tool: time of the W = A_g·D kernel under another build of the library (SDPLR_HIP_LIBRARY=…, e.g. one compiled
+with -DSDPLR_TILE_WIN=8, or with parts of the kernel stubbed out for an ablation — results may then be garbage)"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

@@ -1057,10 +1057,7 @@ k_spmm_fast(DevSparse sg, int m, DevFast ff, const double* __restrict__ R, const
 // while the current gathers are in flight.
 #define SDPLR_TILE_COLBITS 24
 #ifndef SDPLR_TILE_WIN
-#define SDPLR_TILE_WIN 4
-#endif
-#ifndef SDPLR_TILE_EXP
-#define SDPLR_TILE_EXP 0
+#define SDPLR_TILE_WIN 4   /* gathers in flight per group: 2 and 4 equal, 8 and 16 slower (L1/TA-bound, not latency-bound) */
 #endif
 struct DevTile {
   int K, n_tiles;        // K = most rows in any tile
@@ -1164,11 +1161,7 @@ k_spmm_tile(DevTile tl, int n, int m, DevFast ff, const double* __restrict__ R, 
       // enter the loop with nothing but the ring outstanding: the compiler's wait-count merge at the loop
       // header is then exact instead of falling back to vmcnt(0) on every trip
       __builtin_amdgcn_sched_barrier(0);
-#if SDPLR_TILE_EXP == 3   /* experiment: no main loop */
-      for (int base = beg; base < beg; base += LPR) {
-#else
       for (int base = beg; base < end; base += LPR) {
-#endif
         const bool more = base + LPR < end;
         // the chunk after next, fetched first so that by the time it is rotated in (a register copy, which
         // must wait for the load) a whole chunk of gathers has been issued behind it and nothing drains
@@ -1183,14 +1176,9 @@ k_spmm_tile(DevTile tl, int n, int m, DevFast ff, const double* __restrict__ R, 
             // issue order and each lane owns its addresses, so the sum is formed in list order exactly as a
             // read-add-write would form it, but the wave never waits for it)
             const double v = group_bcast<LPR>(cv, k0 + q);
-#if SDPLR_TILE_EXP == 1   /* experiment: no LDS fold */
-#pragma unroll
-            for (int k = 0; k < VEC; k++) pd += x[q].v[k] * v;
-#else
 #pragma unroll
             for (int k = 0; k < VEC; k++)
               (void)__hip_atomic_fetch_add(fold[q] + k, x[q].v[k] * v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-#endif
             // … refill one
             int e2;
             if (k0 + WIN < LPR) {
@@ -1200,12 +1188,7 @@ k_spmm_tile(DevTile tl, int n, int m, DevFast ff, const double* __restrict__ R, 
               e2 = more ? e2 : dump;   // past the end of the list: nothing to gather
             }
             fold[q] = rows + ((unsigned)e2 >> SDPLR_TILE_COLBITS) * (unsigned)RW;
-#if SDPLR_TILE_EXP == 2   /* experiment: no gathers */
-#pragma unroll
-            for (int k = 0; k < VEC; k++) x[q].v[k] = (double)e2;
-#else
             x[q] = ldrow<VEC>(reinterpret_cast<const double*>(Db + (__umul24((unsigned)e2, rowb) + chb8)));
-#endif
             __builtin_amdgcn_sched_barrier(0);  // no clustering of the refills behind the folds
           }
         }
@@ -1217,16 +1200,12 @@ k_spmm_tile(DevTile tl, int n, int m, DevFast ff, const double* __restrict__ R, 
       constexpr int EB = LRN > 0 ? 2 : 4;   // rows per step (the projections need registers of their own)
       // the tile's rows, EB at a time (one memory round trip for twelve row loads, eight interleaved group
       // sums): W out, row dots, ⟨P,D⟩ and ⟨D,W⟩ partials.  Loads are clamped, not predicated.
-#if SDPLR_TILE_EXP == 4   /* experiment: no epilogue */
-      for (int k = 0; k < 0; k += EB) {
-#else
       double lr0[LRA][VEC], lr1[LRA][VEC];
 #pragma unroll
       for (int cc = 0; cc < LRA; cc++)
 #pragma unroll
         for (int q = 0; q < VEC; q++) lr0[cc][q] = lr1[cc][q] = 0.0;
       for (int k = 0; k < nrows; k += EB) {
-#endif
         vecd<VEC> xr[EB], xd[EB], xp[EB], w[EB];
         const long long chs = act ? ch : 0;
 #pragma unroll
