@@ -1225,7 +1225,8 @@ void enq_iteration_fast(S* s, int armijo) {
   enq_lbfgs_update(s, 1);                                                             // :244-246
 }
 
-// singleton form of the fast path (exact line search only): 8 launches per iteration
+// singleton form of the fast path (exact line search only): 5 launches per iteration (seam, direction, gather,
+// line-search solve, step + update), 6 with a rank-1 dense constraint, 6 when lbfgs_update! is not fused (h > 4)
 void enq_iteration_fast2(S* s) {
   double *R = aslot(s->arena, AS_R), *G = aslot(s->arena, AS_G), *D = aslot(s->arena, AS_D);
   double *P = fast_P(s), *W = fast_W(s);
