@@ -223,18 +223,20 @@ k_assemble_full(DevSparse sp, const DevCtrl* __restrict__ c, int check_done) {
 // neighbours); scale = 2 fuses BLAS.scal!(2, Gt) of g! (:315); with slot ≥ 0 the ‖Y‖² partials of
 // norm(Gt) (src/sdplr.jl:225) are produced on the way out.  WS[c,:] = y[gid]·D_c·(XᵀB)[c,:] is the
 // low-rank product of src/structs.jl:135-145 prepared by k_lr_finalize.
+// (bid, nblk: this block's index and the number of blocks working on the short rows — the body is shared by
+// k_spmm and by k_spmm_both, where the hub-row blocks come first in the same grid)
 template <int LPR, int VEC>
-__global__ void __launch_bounds__(SDPLR_NT)
-k_spmm(DevSparse sp, const double* __restrict__ X, double* __restrict__ Y, int r, double scale,
-       DevLowRank lr, const double* __restrict__ WS, int slot, double* __restrict__ partials,
-       const DevCtrl* __restrict__ c, int check_done, const double* __restrict__ Xdot = nullptr) {
+__device__ __forceinline__ void
+spmm_rows(DevSparse sp, const double* __restrict__ X, double* __restrict__ Y, int r, double scale,
+          DevLowRank lr, const double* __restrict__ WS, int slot, double* __restrict__ partials,
+          const DevCtrl* __restrict__ c, int check_done, const double* __restrict__ Xdot, int bid, int nblk) {
   __shared__ double sh[8];
   if (check_done && c->done) return;
   constexpr int G = SDPLR_NT / LPR;
   const int lane = threadIdx.x % LPR;
-  const long long total = (long long)gridDim.x * G;
+  const long long total = (long long)nblk * G;
   double nrm = 0.0;
-  for (long long j = (long long)blockIdx.x * G + threadIdx.x / LPR; j < sp.n; j += total) {
+  for (long long j = (long long)bid * G + threadIdx.x / LPR; j < sp.n; j += total) {
     const int beg = sp.colptr[j], end = sp.colptr[j + 1];
     if (sp.n_long_rows > 0 && end - beg > sp.long_thresh) continue;  // hub row: k_spmm_long
     for (int chb = 0; chb < r; chb += LPR * VEC) {
@@ -293,8 +295,15 @@ k_spmm(DevSparse sp, const double* __restrict__ X, double* __restrict__ Y, int r
   }
   if (slot >= 0) {
     nrm = block_sum1(nrm, sh);
-    if (threadIdx.x == 0) slot_partials(partials, slot)[blockIdx.x] = nrm;
+    if (threadIdx.x == 0) slot_partials(partials, slot)[bid] = nrm;
   }
+}
+template <int LPR, int VEC>
+__global__ void __launch_bounds__(SDPLR_NT)
+k_spmm(DevSparse sp, const double* __restrict__ X, double* __restrict__ Y, int r, double scale,
+       DevLowRank lr, const double* __restrict__ WS, int slot, double* __restrict__ partials,
+       const DevCtrl* __restrict__ c, int check_done, const double* __restrict__ Xdot = nullptr) {
+  spmm_rows<LPR, VEC>(sp, X, Y, r, scale, lr, WS, slot, partials, c, check_done, Xdot, blockIdx.x, gridDim.x);
 }
 
 // ---- SpMV on an n-vector: y = S·x + Σ_c coef[c]·B[c][:], with the partial of ⟨x, y⟩ ----------------
@@ -1347,17 +1356,17 @@ k_spmm_tile(DevTile tl, int n, int m, DevFast ff, const double* __restrict__ R, 
 // block's sub-wave groups, the group partials are added in group order (deterministic).  Partials of the
 // norm / dot go to slot entries [pbase, pbase + n_long_rows).
 template <int LPR, int VEC>
-__global__ void __launch_bounds__(SDPLR_NT)
-k_spmm_long(DevSparse sp, const double* __restrict__ X, double* __restrict__ Y, int r, double scale,
-            DevLowRank lr, const double* __restrict__ WS, int slot, int pbase, double* __restrict__ partials,
-            const DevCtrl* __restrict__ c, int check_done, const double* __restrict__ Xdot) {
+__device__ __forceinline__ void
+spmm_long_rows(DevSparse sp, const double* __restrict__ X, double* __restrict__ Y, int r, double scale,
+               DevLowRank lr, const double* __restrict__ WS, int slot, int pbase, double* __restrict__ partials,
+               const DevCtrl* __restrict__ c, int check_done, const double* __restrict__ Xdot, int bid, int nblk) {
   __shared__ double shg[SDPLR_NT * VEC];
   __shared__ double sh[8];
   if (check_done && c->done) return;
   constexpr int G = SDPLR_NT / LPR;
   const int lane = threadIdx.x % LPR, g = threadIdx.x / LPR;
   double nrm = 0.0;
-  for (int lrow = blockIdx.x; lrow < sp.n_long_rows; lrow += gridDim.x) {
+  for (int lrow = bid; lrow < sp.n_long_rows; lrow += nblk) {
   const long long j = sp.long_rows[lrow];
   const int beg = sp.colptr[j], end = sp.colptr[j + 1];
   for (int chb = 0; chb < r; chb += LPR * VEC) {
@@ -1367,7 +1376,23 @@ k_spmm_long(DevSparse sp, const double* __restrict__ X, double* __restrict__ Y, 
     for (int k = 0; k < VEC; k++) acc.v[k] = 0.0;
     if (ch < r) {
       int p = beg + g;
-      for (; p + 3 * G < end; p += 4 * G) {  // four independent row gathers in flight per group
+      for (; p + 7 * G < end; p += 8 * G) {  // eight independent row gathers in flight per group: the longest
+        long long ii[8];                      // hub row sets this kernel's duration
+        double vv[8];
+        vecd<VEC> xx[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+          ii[q] = sp.rowval[p + q * G];
+          vv[q] = sp.nzval[p + q * G];
+        }
+#pragma unroll
+        for (int q = 0; q < 8; q++) xx[q] = ldrow<VEC>(X + ii[q] * r + ch);
+#pragma unroll
+        for (int q = 0; q < 8; q++)
+#pragma unroll
+          for (int k = 0; k < VEC; k++) acc.v[k] += xx[q].v[k] * vv[q];
+      }
+      for (; p + 3 * G < end; p += 4 * G) {  // four
         const long long i0 = sp.rowval[p], i1 = sp.rowval[p + G], i2 = sp.rowval[p + 2 * G], i3 = sp.rowval[p + 3 * G];
         const double v0 = sp.nzval[p], v1 = sp.nzval[p + G], v2 = sp.nzval[p + 2 * G], v3 = sp.nzval[p + 3 * G];
         const vecd<VEC> x0 = ldrow<VEC>(X + i0 * r + ch), x1 = ldrow<VEC>(X + i1 * r + ch);
@@ -1421,8 +1446,29 @@ k_spmm_long(DevSparse sp, const double* __restrict__ X, double* __restrict__ Y, 
   }
   if (slot >= 0) {
     nrm = block_sum1(nrm, sh);
-    if (threadIdx.x == 0) slot_partials(partials, slot)[pbase + blockIdx.x] = nrm;
+    if (threadIdx.x == 0) slot_partials(partials, slot)[pbase + bid] = nrm;
   }
+}
+template <int LPR, int VEC>
+__global__ void __launch_bounds__(SDPLR_NT)
+k_spmm_long(DevSparse sp, const double* __restrict__ X, double* __restrict__ Y, int r, double scale,
+            DevLowRank lr, const double* __restrict__ WS, int slot, int pbase, double* __restrict__ partials,
+            const DevCtrl* __restrict__ c, int check_done, const double* __restrict__ Xdot) {
+  spmm_long_rows<LPR, VEC>(sp, X, Y, r, scale, lr, WS, slot, pbase, partials, c, check_done, Xdot, blockIdx.x, gridDim.x);
+}
+// Both in one grid: the first nb_long blocks take the hub rows (the longest work items start first), the rest
+// the short rows — the two row sets are disjoint, and as two launches the hub rows (a few hundred rows, tens of
+// µs of dependent gather rounds for the longest) ran after the short ones instead of beside them.
+template <int LPR, int VEC>
+__global__ void __launch_bounds__(SDPLR_NT)
+k_spmm_both(DevSparse sp, const double* __restrict__ X, double* __restrict__ Y, int r, double scale,
+            DevLowRank lr, const double* __restrict__ WS, int slot, double* __restrict__ partials,
+            const DevCtrl* __restrict__ c, int check_done, const double* __restrict__ Xdot, int nb_long) {
+  const int nb_short = gridDim.x - nb_long;
+  if ((int)blockIdx.x < nb_long)
+    spmm_long_rows<LPR, VEC>(sp, X, Y, r, scale, lr, WS, slot, nb_short, partials, c, check_done, Xdot, blockIdx.x, nb_long);
+  else
+    spmm_rows<LPR, VEC>(sp, X, Y, r, scale, lr, WS, slot, partials, c, check_done, Xdot, blockIdx.x - nb_long, nb_short);
 }
 
 // hub rows of the SpMV: one block per row, 256 lanes stride the row

@@ -1020,9 +1020,11 @@ void enq_At_left(S* s, double* Y, const double* X, double scale, int slot, int c
     enq_lowrank(s, X, X, 1, 3, nullptr, nullptr, chk);
   }
   ProfScope ps(s, "spmm");
-  LV_DISPATCH((k_spmm<LPR, VEC><<<s->nb_spmm, SDPLR_NT, 0, s->stream>>>(s->sp, X, Y, (int)s->r, scale, s->lr, s->lr_WS, slot, s->partials, s->ctrl, chk)))
   if (s->sp.n_long_rows > 0) {
-    LV_DISPATCH((k_spmm_long<LPR, VEC><<<std::min(s->sp.n_long_rows, 256), SDPLR_NT, 0, s->stream>>>(s->sp, X, Y, (int)s->r, scale, s->lr, s->lr_WS, slot, s->nb_spmm, s->partials, s->ctrl, chk, nullptr)))
+    const int nbl = std::min(s->sp.n_long_rows, 256);
+    LV_DISPATCH((k_spmm_both<LPR, VEC><<<s->nb_spmm + nbl, SDPLR_NT, 0, s->stream>>>(s->sp, X, Y, (int)s->r, scale, s->lr, s->lr_WS, slot, s->partials, s->ctrl, chk, nullptr, nbl)))
+  } else {
+    LV_DISPATCH((k_spmm<LPR, VEC><<<s->nb_spmm, SDPLR_NT, 0, s->stream>>>(s->sp, X, Y, (int)s->r, scale, s->lr, s->lr_WS, slot, s->partials, s->ctrl, chk)))
   }
 }
 
@@ -1147,9 +1149,11 @@ inline double* fast_W(S* s) { return aslot(s->arena, 3 + 2 * (int)s->h + 1); }
 void enq_fast_refresh_P(S* s) {
   ProfScope ps(s, "spmm_P");
   DevLowRank none{};
-  LV_DISPATCH((k_spmm<LPR, VEC><<<s->nb_spmm, SDPLR_NT, 0, s->stream>>>(s->spg, aslot(s->arena, AS_R), fast_P(s), (int)s->r, 1.0, none, nullptr, -1, s->partials, s->ctrl, 0)))
   if (s->spg.n_long_rows > 0) {
-    LV_DISPATCH((k_spmm_long<LPR, VEC><<<std::min(s->spg.n_long_rows, 256), SDPLR_NT, 0, s->stream>>>(s->spg, aslot(s->arena, AS_R), fast_P(s), (int)s->r, 1.0, none, nullptr, -1, 0, s->partials, s->ctrl, 0, nullptr)))
+    const int nbl = std::min(s->spg.n_long_rows, 256);
+    LV_DISPATCH((k_spmm_both<LPR, VEC><<<s->nb_spmm + nbl, SDPLR_NT, 0, s->stream>>>(s->spg, aslot(s->arena, AS_R), fast_P(s), (int)s->r, 1.0, none, nullptr, -1, s->partials, s->ctrl, 0, nullptr, nbl)))
+  } else {
+    LV_DISPATCH((k_spmm<LPR, VEC><<<s->nb_spmm, SDPLR_NT, 0, s->stream>>>(s->spg, aslot(s->arena, AS_R), fast_P(s), (int)s->r, 1.0, none, nullptr, -1, s->partials, s->ctrl, 0)))
   }
 }
 
@@ -1171,9 +1175,11 @@ void enq_iteration_fast(S* s, int armijo) {
   {
     ProfScope ps(s, "spmm_W");
     DevLowRank none{};
-    LV_DISPATCH((k_spmm<LPR, VEC><<<s->nb_spmm, SDPLR_NT, 0, s->stream>>>(s->spg, D, W, (int)s->r, 1.0, none, nullptr, SLOT_DW, s->partials, s->ctrl, 1, D)))
     if (s->spg.n_long_rows > 0) {
-      LV_DISPATCH((k_spmm_long<LPR, VEC><<<std::min(s->spg.n_long_rows, 256), SDPLR_NT, 0, s->stream>>>(s->spg, D, W, (int)s->r, 1.0, none, nullptr, SLOT_DW, s->nb_spmm, s->partials, s->ctrl, 1, D)))
+      const int nbl = std::min(s->spg.n_long_rows, 256);
+      LV_DISPATCH((k_spmm_both<LPR, VEC><<<s->nb_spmm + nbl, SDPLR_NT, 0, s->stream>>>(s->spg, D, W, (int)s->r, 1.0, none, nullptr, SLOT_DW, s->partials, s->ctrl, 1, D, nbl)))
+    } else {
+      LV_DISPATCH((k_spmm<LPR, VEC><<<s->nb_spmm, SDPLR_NT, 0, s->stream>>>(s->spg, D, W, (int)s->r, 1.0, none, nullptr, SLOT_DW, s->partials, s->ctrl, 1, D)))
     }
   }
   {
