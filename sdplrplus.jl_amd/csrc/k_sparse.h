@@ -218,6 +218,51 @@ k_assemble_full(DevSparse sp, const DevCtrl* __restrict__ c, int check_done) {
     sp.nzval[p] = sp.triu_nzval[sp.mapped[p]];
 }
 
+// The three independent jobs between the line-search commit and the SpMM of g! on the generic in-loop path, in
+// ONE grid (each of them alone sits on the ≈4.5 µs floor of a dependent launch):
+//   blocks [0, nb_ax):            R += α·dirt                                   (src/sdplr.jl:219; k_axpy_R)
+//   blocks [nb_ax, nb_ax+nb_s):   S assembly, both copies from the per-position lists (k_assemble_triu + _full:
+//                                 each full-pattern entry recomputes its triangular value — same terms, same
+//                                 order — so the two copies of an off-diagonal entry write identical bits)
+//   the last block (lr.ST > 0):   low-rank coefficients at the moved point     (k_fast_lr_ws)
+__global__ void __launch_bounds__(SDPLR_NT)
+k_step_jobs(DevSparse sp, const double* __restrict__ y, const DevCtrl* __restrict__ c, double* __restrict__ R,
+            const double* __restrict__ D, long long N, int nb_ax, int nb_s, DevLowRank lr, int r,
+            double* __restrict__ lrW, double* __restrict__ lrWS) {
+  if (c->done) return;
+  const int b = blockIdx.x;
+  if (b < nb_ax) {
+    const double alpha = c->alpha;
+    const long long N2 = N >> 1;
+    const long long stride = (long long)nb_ax * SDPLR_NT;
+    for (long long i = (long long)b * SDPLR_NT + threadIdx.x; i < N2; i += stride) {
+      double2 x = reinterpret_cast<double2*>(R)[i];
+      const double2 d = reinterpret_cast<const double2*>(D)[i];
+      x.x += alpha * d.x;
+      x.y += alpha * d.y;
+      reinterpret_cast<double2*>(R)[i] = x;
+    }
+    if ((N & 1) && b == 0 && threadIdx.x == 0) R[N - 1] += alpha * D[N - 1];
+  } else if (b < nb_ax + nb_s) {
+    const long long stride = (long long)nb_s * SDPLR_NT;
+    for (long long p = (long long)(b - nb_ax) * SDPLR_NT + threadIdx.x; p < sp.nnzS; p += stride) {
+      const int q = sp.mapped[p];
+      double v = 0.0;
+      for (int e = sp.tptr[q]; e < sp.tptr[q + 1]; e++) v += sp.tval[e] * y[sp.tmat[e]];
+      sp.nzval[p] = v;
+      sp.triu_nzval[q] = v;
+    }
+  } else {
+    const double a = c->alpha;
+    const int per = lr.ST * r;
+    for (int t = threadIdx.x; t < per; t += SDPLR_NT) {
+      const double w = lrW[t] + a * lrW[per + t];
+      lrW[t] = w;
+      lrWS[t] = y[lr.col_gid[t / r]] * lr.Dcat[t / r] * w;
+    }
+  }
+}
+
 // ---- SpMM: Y[j,:] = scale·( Σ_{p∈col j} S[p]·X[rowval[p],:] + Σ_c WS[c,:]·B[c][j] ) ----------------------
 // 𝒜t!(y, x, aux, var) src/coreop.jl:260-279 (S is symmetric: column j of the CSC pattern lists row j's
 // neighbours); scale = 2 fuses BLAS.scal!(2, Gt) of g! (:315); with slot ≥ 0 the ‖Y‖² partials of

@@ -1012,6 +1012,7 @@ void enq_At_preprocess(S* s, int chk) {
 // Y = scale·(X·S + low-rank); slot ≥ 0 also yields the ‖Y‖² partials
 // lr_step: X is the point the line search has just moved to and lr_W still holds [X_oldᵀB; DᵀB] from its
 // 𝒜 pass, so X_newᵀB = X_oldᵀB + α·DᵀB (exact by linearity) and no pass over X is needed for the low-rank term
+void enq_spmm_S(S* s, double* Y, const double* X, double scale, int slot, int chk);
 void enq_At_left(S* s, double* Y, const double* X, double scale, int slot, int chk, bool lr_step = false) {
   if (lr_step && s->lr.ST > 0) {
     ProfScope ps(s, "fast_lr_ws");
@@ -1019,6 +1020,10 @@ void enq_At_left(S* s, double* Y, const double* X, double scale, int slot, int c
   } else {
     enq_lowrank(s, X, X, 1, 3, nullptr, nullptr, chk);
   }
+  enq_spmm_S(s, Y, X, scale, slot, chk);
+}
+// the SpMM with S alone (low-rank coefficients lr_WS already in place)
+void enq_spmm_S(S* s, double* Y, const double* X, double scale, int slot, int chk) {
   ProfScope ps(s, "spmm");
   if (s->sp.n_long_rows > 0) {
     const int nbl = std::min(s->sp.n_long_rows, 256);
@@ -1135,8 +1140,16 @@ void enq_iteration(S* s, int armijo) {
   s->gram_nb = s->nb_upd;                    // this path's lbfgs_update! grid (read by the seam kernel)
   enq_lbfgs_dir(s, 1, 1, 1);                 // :197-205
   enq_linesearch(s, armijo, 1, 1);           // :210-214
-  enq_axpy_R(s, 1);                          // :219
-  enq_g(s, 1, true, !s->no_lrfuse);          // :221
+  if (s->n_sparse > 0 && !s->no_lrfuse) {     // :219 and the head of g! (:221) as one launch, then the SpMM
+    {
+      ProfScope ps(s, "step_jobs");
+      k_step_jobs<<<s->nb_dense + s->nb_nnzS + (s->lr.ST > 0 ? 1 : 0), SDPLR_NT, 0, s->stream>>>(s->sp, s->y, s->ctrl, aslot(s->arena, AS_R), aslot(s->arena, AS_D), s->N, s->nb_dense, s->nb_nnzS, s->lr, (int)s->r, s->lr_W, s->lr_WS);
+    }
+    enq_spmm_S(s, aslot(s->arena, AS_G), aslot(s->arena, AS_R), 2.0, SLOT_GNORM2, 1);
+  } else {
+    enq_axpy_R(s, 1);                          // :219
+    enq_g(s, 1, true, !s->no_lrfuse);          // :221
+  }
   // norms and the exit tests (:224-241, :272-277, :190) are folded by the next seam kernel
   enq_lbfgs_update(s, 1);                    // :244-246
 }
