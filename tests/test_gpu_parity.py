@@ -180,7 +180,8 @@ def test_inner_loop_trajectory(hip_abi, oracle_abi, family):
         s_.close()
 
 
-@pytest.mark.parametrize("family,h", [("maxcut", 0), ("maxcut", 4), ("cutnorm", 4), ("minimum_bisection", 3)])
+@pytest.mark.parametrize("family,h", [("maxcut", 0), ("maxcut", 1), ("maxcut", 2), ("maxcut", 4), ("maxcut", 6),
+                                      ("cutnorm", 4), ("minimum_bisection", 3), ("lovasz_theta", 2)])
 def test_inner_loop_takes_the_steepest_descent_fallback(hip_abi, oracle_abi, family, h):
     """src/sdplr.jl:201-205: when ⟨dir, G⟩ is NaN or ≥ 0 the loop replaces the direction by steepest descent
     (G ← −G; dir ← G).  Inside the device loop that test is evaluated by the seam kernel from the Gram data
