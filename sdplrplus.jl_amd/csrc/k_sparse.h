@@ -397,40 +397,54 @@ k_lr_project(DevLowRank lr, const double* __restrict__ X0, const double* __restr
   const long long rows_per_block = ((long long)n + gridDim.x - 1) / gridDim.x;
   const long long lo = (long long)blockIdx.x * rows_per_block;
   const long long hi = (lo + rows_per_block < n) ? lo + rows_per_block : n;
-  for (int f = 0; f < F; f++) {
-    const double* X = f == 0 ? X0 : X1;
-    for (int c0 = 0; c0 < lr.ST; c0 += SDPLR_LRMAX) {
-      const int nc = (lr.ST - c0 < SDPLR_LRMAX) ? lr.ST - c0 : SDPLR_LRMAX;
-      for (int chb = 0; chb < r; chb += LPR * VEC) {
-        const int ch = chb + lane * VEC;
-        double acc[SDPLR_LRMAX][VEC];
+  // one pass over the rows for all F factors (their loads in flight together), SDPLR_LRMAX columns at a time
+  for (int c0 = 0; c0 < lr.ST; c0 += SDPLR_LRMAX) {
+    const int nc = (lr.ST - c0 < SDPLR_LRMAX) ? lr.ST - c0 : SDPLR_LRMAX;
+    for (int chb = 0; chb < r; chb += LPR * VEC) {
+      const int ch = chb + lane * VEC;
+      double acc[F][SDPLR_LRMAX][VEC];
+#pragma unroll
+      for (int f = 0; f < F; f++)
 #pragma unroll
         for (int cc = 0; cc < SDPLR_LRMAX; cc++)
 #pragma unroll
-          for (int k = 0; k < VEC; k++) acc[cc][k] = 0.0;
-        if (ch < r)
-          for (long long i = lo + g; i < hi; i += G) {
-            const vecd<VEC> x = ldrow<VEC>(X + i * r + ch);
+          for (int k = 0; k < VEC; k++) acc[f][cc][k] = 0.0;
+      if (ch < r)
+        for (long long i = lo + g; i < hi; i += 4 * G) {   // four rows per trip: 4·F row loads in flight per lane
+          vecd<VEC> x[4][F];
+          long long ii[4];
+#pragma unroll
+          for (int u = 0; u < 4; u++) {
+            ii[u] = (i + u * G < hi) ? i + u * G : i;        // (a repeated row gets weight 0 below)
+            x[u][0] = ldrow<VEC>(X0 + ii[u] * r + ch);
+            if (F > 1) x[u][F - 1] = ldrow<VEC>(X1 + ii[u] * r + ch);
+          }
+#pragma unroll
+          for (int u = 0; u < 4; u++)
 #pragma unroll
             for (int cc = 0; cc < SDPLR_LRMAX; cc++)
               if (cc < nc) {
-                const double b = lr.Bcat[(long long)(c0 + cc) * n + i];
+                const double b = (i + u * G < hi) ? lr.Bcat[(long long)(c0 + cc) * n + ii[u]] : 0.0;
 #pragma unroll
-                for (int k = 0; k < VEC; k++) acc[cc][k] += x.v[k] * b;
+                for (int f = 0; f < F; f++)
+#pragma unroll
+                  for (int k = 0; k < VEC; k++) acc[f][cc][k] += x[u][f].v[k] * b;
               }
-          }
+        }
+#pragma unroll
+      for (int f = 0; f < F; f++) {
         __syncthreads();
 #pragma unroll
         for (int cc = 0; cc < SDPLR_LRMAX; cc++)
 #pragma unroll
-          for (int k = 0; k < VEC; k++) sh[(g * SDPLR_LRMAX + cc) * (LPR * VEC) + lane * VEC + k] = acc[cc][k];
+          for (int k = 0; k < VEC; k++) sh[(g * SDPLR_LRMAX + cc) * (LPR * VEC) + lane * VEC + k] = acc[f][cc][k];
         __syncthreads();
         for (int t = threadIdx.x; t < nc * LPR * VEC; t += SDPLR_NT) {
           const int cc = t / (LPR * VEC), k = t % (LPR * VEC);
           if (chb + k < r) {
-            double s = 0.0;
-            for (int gg = 0; gg < G; gg++) s += sh[(gg * SDPLR_LRMAX + cc) * (LPR * VEC) + k];
-            lr_part[((((long long)f * lr.ST + c0 + cc) * r + chb + k)) * gridDim.x + blockIdx.x] = s;
+            double sum = 0.0;
+            for (int gg = 0; gg < G; gg++) sum += sh[(gg * SDPLR_LRMAX + cc) * (LPR * VEC) + k];
+            lr_part[((((long long)f * lr.ST + c0 + cc) * r + chb + k)) * gridDim.x + blockIdx.x] = sum;
           }
         }
       }
@@ -450,7 +464,8 @@ k_lr_finalize(DevLowRank lr, int r, int F, int nb, const double* __restrict__ lr
   if (check_done && c->done) return;
   const int per = lr.ST * r;
   const int nout = F * per;
-  {  // one wave per output: lanes stride the nb contiguous per-block partials, fixed-order butterfly
+  if (nb > 0) {  // one wave per output: lanes stride the nb contiguous per-block partials, fixed-order butterfly
+                 // (nb == 0: W has already been summed by k_lr_reduce)
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
     for (int t = wave; t < nout; t += nw) {
       const double* p = lr_part + (long long)t * nb;

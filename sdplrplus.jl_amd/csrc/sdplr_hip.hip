@@ -387,6 +387,7 @@ int alloc_factors(S* s) {
   s->nb_sddmm = blocks_for(s->nnzT, G, 8192);
   s->nb_spmm = blocks_for(s->n, G, 768);  // + up to 256 hub-row blocks share the partial slot
   s->nb_tile = blocks_for(s->tile.n_tiles, G, 1024);
+  s->nb_lr = (s->N >= (1LL << 22)) ? 1024 : 256;   // low-rank projection grid (lr_part is sized for 1024)
   { const int tr = std::min<int>(s->LPR, SDPLR_STEP_TR); s->nb_step = blocks_for((s->n + tr - 1) / tr, G, step_fuses_update(s) ? 512 : 1024); }  // one group per tile of LPR rows; its ‖G‖², ‖pv‖² (and Gram)
                                                                     // partials are folded by the one-block seam kernel: keep them few
   if (const char* e = getenv("SDPLR_HIP_NB_STEP")) s->nb_step = std::max(1, std::min(atoi(e), SDPLR_MAXNB));
@@ -628,7 +629,7 @@ int32_t sdplr_hip_finalize(S* s) {
   for (int k = 0; k < 3; k++)
     if ((rc = dzero(s, &s->lz_buf[k], n))) return rc;
   if ((rc = dzero(s, &s->lz_v0, n))) return rc;
-  s->nb_lr = 256;
+  s->nb_lr = 256;   // (alloc_factors raises it to 1024 for large factors: n·r ≥ 4M)
   if ((rc = dzero(s, &s->lr_btx_part, (size_t)std::max(lr.ST, 1) * SDPLR_MAXNB))) return rc;
   if ((rc = dzero(s, &s->lr_coef, std::max(lr.ST, 1)))) return rc;
   {
@@ -965,8 +966,15 @@ void enq_lowrank(S* s, const double* X0, const double* X1, int F, int mode, doub
     if (F == 1) { LV_DISPATCH((k_lr_project<LPR, VEC, 1><<<s->nb_lr, SDPLR_NT, 0, s->stream>>>(s->lr, X0, X1, (int)s->n, (int)s->r, s->lr_part, s->ctrl, chk))) }
     else { LV_DISPATCH((k_lr_project<LPR, VEC, 2><<<s->nb_lr, SDPLR_NT, 0, s->stream>>>(s->lr, X0, X1, (int)s->n, (int)s->r, s->lr_part, s->ctrl, chk))) }
   }
+  int nbf = s->nb_lr;
+  if (s->nb_lr > 256) {   // many blocks: their partials are summed by many waves, not by the one finalize block
+    ProfScope ps(s, "lr_reduce");
+    const int nout = F * s->lr.ST * (int)s->r;
+    k_lr_reduce<<<(nout + 3) / 4, SDPLR_NT, 0, s->stream>>>(nout, s->nb_lr, s->lr_part, s->lr_W, s->ctrl, chk);
+    nbf = 0;
+  }
   ProfScope ps(s, "lr_finalize");
-  k_lr_finalize<<<1, 1024, 0, s->stream>>>(s->lr, (int)s->r, F, s->nb_lr, s->lr_part, s->lr_W, mode, out0, out1, s->y, s->lr_WS, s->ctrl, chk);
+  k_lr_finalize<<<1, 1024, 0, s->stream>>>(s->lr, (int)s->r, F, nbf, s->lr_part, s->lr_W, mode, out0, out1, s->y, s->lr_WS, s->ctrl, chk);
 }
 
 // mode 0: out0 = 𝒜(UUᵀ); mode 1: out0 = 𝒜((UVᵀ+VUᵀ)/2); mode 2: out0 = 2·𝒜((UVᵀ+VUᵀ)/2), out1 = 𝒜(VVᵀ)
