@@ -1796,7 +1796,10 @@ int32_t sdplr_hip_inner_loop(S* s, double normC, double normb, int32_t grel, int
       cur ^= 1;
     }
   }
-  enq_boundary(s, 0, 1, 0, 0);   // fold the partials of a last lbfgs_update (time-budget exit)
+  // fold the partials of a last lbfgs_update (time-budget exit); a replayed graph does not pass through the
+  // enqueue functions, so the producer's partial count is set here, not inherited
+  s->gram_nb = (fast2 && step_fuses_update(s)) ? s->nb_step : s->nb_upd;
+  enq_boundary(s, 0, 1, 0, 0);
   if (fastp) enq_At_preprocess(s, 0);  // leave S consistent with the y of the last step, as g! would
   if ((rc = pull(s))) return rc;
   if (c->done) why = c->exit_reason;   // the device's verdict wins over the host's time check

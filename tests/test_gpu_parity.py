@@ -180,6 +180,37 @@ def test_inner_loop_trajectory(hip_abi, oracle_abi, family):
         s_.close()
 
 
+@pytest.mark.parametrize("family", ["maxcut", "minimum_bisection", "lovasz_theta"])
+def test_inner_loop_time_budget_exit_leaves_a_consistent_state(hip_abi, oracle_abi, family):
+    """The host's time budget (src/sdplr.jl:299) stops the loop between two batches, i.e. after a whole number
+    of iterations, with the last lbfgs_update!'s Gram partials still unfolded on the device: the library folds
+    them on the way out.  However many iterations it ran, an oracle run of the same count must be at the same
+    point, and both must carry on identically."""
+    from sdplrplus_jl_amd import cabi
+    big = family == "maxcut"    # large enough for the update's and the fused step's grids to differ
+    if big:   # sparse enough to stay on the singleton fast path (no hub rows)
+        data = problems.maxcut_data(problems.gnp_graph(1500, 0.01, 8))
+    else:
+        data, C, As, bs = make_data(family, 8, 16, 0.4)
+    g, o = pair(hip_abi, oracle_abi, data, 8 if big else 3, 31)
+    normC, normb = data.normC(), float(np.linalg.norm(data.b))
+    sg, so = g.fg(normC, normb), o.fg(normC, normb)
+    # a first call captures the hipGraph; rewriting G from the host then makes the next call rebuild a Gram row
+    # through the stand-alone update kernel (another grid) before it REPLAYS the graph
+    sg = g.inner_loop(normC, normb, True, True, False, 0.0, -1e300, 8, 0.0, *sg)[:3]
+    so = o.inner_loop(normC, normb, True, True, False, 0.0, -1e300, 8, 0.0, *so)[:3]
+    g.set_factor(cabi.F_GT, g.Gt)
+    o.set_factor(cabi.F_GT, o.Gt)
+    rg = g.inner_loop(normC, normb, True, True, False, 0.0, -1e300, 10_000, 1e-9, *sg)   # budget: stop at once
+    assert rg[5] == 3 and 0 < rg[4] < 10_000, rg          # EXIT_TIME after at least one batch
+    ro = o.inner_loop(normC, normb, True, True, False, 0.0, -1e300, rg[4], 0.0, *so)
+    assert np.allclose(rg[:3], ro[:3], rtol=1e-6) and rel(g.Rt, o.Rt) < 1e-6
+    rg2 = g.inner_loop(normC, normb, True, True, False, 0.0, -1e300, 5, 0.0, *rg[:3])
+    ro2 = o.inner_loop(normC, normb, True, True, False, 0.0, -1e300, 5, 0.0, *ro[:3])
+    assert rg2[4] == ro2[4] == 5 and np.allclose(rg2[:3], ro2[:3], rtol=1e-5) and rel(g.Rt, o.Rt) < 1e-5
+    g.close(); o.close()
+
+
 @pytest.mark.parametrize("family,h", [("maxcut", 0), ("maxcut", 1), ("maxcut", 2), ("maxcut", 4), ("maxcut", 6),
                                       ("cutnorm", 4), ("minimum_bisection", 3), ("lovasz_theta", 2)])
 def test_inner_loop_takes_the_steepest_descent_fallback(hip_abi, oracle_abi, family, h):
