@@ -654,54 +654,6 @@ k_fast_lr_ws(DevLowRank lr, int r, double* __restrict__ W, const double* __restr
   }
 }
 
-// the step: R += α·D (src/sdplr.jl:219), P += α·W, then g! (src/coreop.jl:305-317) in structured form
-// G = 2·(y_g·P + d(y)∘R + Σ_c WS[c]·B[c]) with the ‖G‖² partials of norm(Gt) (src/sdplr.jl:225)
-template <int LPR, int VEC>
-__global__ void __launch_bounds__(SDPLR_NT)
-k_fast_step(DevSparse sp, DevFast ff, double* __restrict__ R, const double* __restrict__ D,
-            double* __restrict__ P, const double* __restrict__ W, double* __restrict__ Gout, int r,
-            const double* __restrict__ yvec, DevLowRank lr, const double* __restrict__ WS, int slot,
-            double* __restrict__ partials, const DevCtrl* __restrict__ c, int check_done) {
-  __shared__ double sh[8];
-  if (check_done && c->done) return;
-  constexpr int G = SDPLR_NT / LPR;
-  const int lane = threadIdx.x % LPR;
-  const long long total = (long long)gridDim.x * G;
-  const double a = c->alpha, yg = yvec[ff.gid_g];
-  double nrm = 0.0;
-  for (long long j = (long long)blockIdx.x * G + threadIdx.x / LPR; j < sp.n; j += total) {
-    double dj = 0.0;
-    for (int e = ff.drow_ptr[j]; e < ff.drow_ptr[j + 1]; e++) dj += ff.drow_val[e] * yvec[ff.drow_gid[e]];
-    for (int ch = lane * VEC; ch < r; ch += LPR * VEC) {
-      vecd<VEC> x = ldrow<VEC>(R + j * r + ch), pp = ldrow<VEC>(P + j * r + ch);
-      const vecd<VEC> d = ldrow<VEC>(D + j * r + ch), w = ldrow<VEC>(W + j * r + ch);
-      vecd<VEC> g;
-#pragma unroll
-      for (int k = 0; k < VEC; k++) {
-        x.v[k] += a * d.v[k];
-        pp.v[k] += a * w.v[k];
-        g.v[k] = pp.v[k] * yg + x.v[k] * dj;
-      }
-      for (int cc = 0; cc < lr.ST; cc++) {
-        const double b = lr.Bcat[(long long)cc * sp.n + j];
-        const vecd<VEC> ws = ldrow<VEC>(WS + (long long)cc * r + ch);
-#pragma unroll
-        for (int k = 0; k < VEC; k++) g.v[k] += ws.v[k] * b;
-      }
-#pragma unroll
-      for (int k = 0; k < VEC; k++) {
-        g.v[k] *= 2.0;
-        nrm += g.v[k] * g.v[k];
-      }
-      strow<VEC>(R + j * r + ch, x);
-      strow<VEC>(P + j * r + ch, pp);
-      strow<VEC>(Gout + j * r + ch, g);
-    }
-  }
-  nrm = block_sum1(nrm, sh);
-  if (threadIdx.x == 0) slot_partials(partials, slot)[blockIdx.x] = nrm;
-}
-
 // ================================================================================================
 // Fast path, singleton form: every diagonal-only matrix has exactly one entry (MaxCut / MinBisection /
 // CutNorm rows e_i e_iᵀ).  Its 𝒜 values are then row-local — A_RD[k] = 2v⟨R_i,D_i⟩, A_DD[k] = v‖D_i‖² —
@@ -766,8 +718,11 @@ k_rowdots_ls(int n, int m, DevFast ff, const double* __restrict__ R, const doubl
   }
 }
 
-// step + row-attached commit + g! in structured form (see k_fast_step); extra slots were committed by
-// k_ls_solve_fast, whose y values (y_g, low-rank owners) are read here.
+// The step of the structured fast path: R += α·D (src/sdplr.jl:219), P += α·W, then g! (src/coreop.jl:305-317)
+// as G = 2·(y_g·P + d(y)∘R + Σ_c WS[c]·B[c]) with the ‖G‖² partials of norm(Gt) (src/sdplr.jl:225).
+// COMMIT (singleton form): also the commit of the row-attached constraints and their y; the extra slots were
+// committed by k_ls_solve_fast, whose y values (y_g, low-rank owners) are read here.  !COMMIT (general
+// diagonal-only matrices): k_ls_commit has done both, d_j = Σ v·y[gid] is read off.
 // HMU > 0: lbfgs_update! (src/lbfgs.jl:129-149) rides the same pass — k_lbfgs_update<HMU, true>'s work on the
 // row chunk this lane already holds: dir *= α, s_j = dir, y_j += G_new, and the five families of Gram dots of
 // the new pair against the HMU history slots.  One launch, one read of D and no re-read of G saved per
@@ -775,7 +730,7 @@ k_rowdots_ls(int n, int m, DevFast ff, const double* __restrict__ R, const doubl
 // sum: applied in issue order, so each is an ordinary sequential sum) because in registers they pushed the fused
 // kernel to 166 VGPRs and scratch.  Skipped, as lbfgs_update! is, when the relative-decrease exit has been
 // decided (src/sdplr.jl:239-241).
-template <int LPR, int VEC, int HMU>
+template <int LPR, int VEC, int HMU, bool COMMIT>
 __global__ void __launch_bounds__(SDPLR_NT)
 k_fast_step2(int n, int m, DevFast ff, double* __restrict__ R, double* __restrict__ D,
              double* __restrict__ P, const double* __restrict__ W, double* Gout, int r,
@@ -834,6 +789,10 @@ k_fast_step2(int n, int m, DevFast ff, double* __restrict__ R, double* __restric
       const int e0 = ff.drow_ptr[j], e1 = ff.drow_ptr[j + 1];
       for (int e = e0; e < e1; e++) {
         const int k = ff.drow_gid[e];
+        if (!COMMIT) {               // non-singleton form: k_ls_commit has committed and formed y already
+          djl += ff.drow_val[e] * yvec[k];
+          continue;
+        }
         const double v = pv_raw[k] + a * (a * A_DD[k] + A_RD[k]);   // src/linesearch.jl:118
         double yk;
         if (k < m) {
@@ -1001,11 +960,13 @@ k_fast_step2(int n, int m, DevFast ff, double* __restrict__ R, double* __restric
   block_sum<2>(red, sh);
   if (threadIdx.x == 0) {
     slot_partials(partials, SLOT_GNORM2)[blockIdx.x] = red[0];
-    slot_partials(partials, SLOT_PVNORM2)[blockIdx.x] = red[1];
-    if (blockIdx.x == 0) {
-      c->norms_pending = 1;
-      c->nb_gnorm = gridDim.x;
-      c->nb_pvnorm = gridDim.x;
+    if (COMMIT) {     // (otherwise k_ls_commit has produced the ‖pv‖² partials and armed the seam kernel)
+      slot_partials(partials, SLOT_PVNORM2)[blockIdx.x] = red[1];
+      if (blockIdx.x == 0) {
+        c->norms_pending = 1;
+        c->nb_gnorm = gridDim.x;
+        c->nb_pvnorm = gridDim.x;
+      }
     }
   }
 }

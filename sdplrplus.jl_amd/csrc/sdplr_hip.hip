@@ -1182,8 +1182,9 @@ void enq_fast_refresh_P(S* s) {
 void enq_iteration_fast(S* s, int armijo) {
   double *R = aslot(s->arena, AS_R), *G = aslot(s->arena, AS_G), *D = aslot(s->arena, AS_D);
   double *P = fast_P(s), *W = fast_W(s);
-  s->gram_nb = s->nb_upd;
-  enq_lbfgs_dir(s, 1, 1, 1);                                                          // :197-205
+  const bool upd_fused = step_fuses_update(s);
+  s->gram_nb = upd_fused ? s->nb_step : s->nb_upd;
+  enq_lbfgs_dir(s, 1, 1, 1, upd_fused && !s->dot_descent);                            // :197-205
   // ---- line search head: 𝒜(RDᵀ+DRᵀ), 𝒜(DDᵀ)  (src/linesearch.jl:8-18) ----
   if (!s->all_covered) {
     (void)hipMemsetAsync(s->A_RD, 0, (s->m + 1) * sizeof(double), s->stream);
@@ -1238,18 +1239,22 @@ void enq_iteration_fast(S* s, int armijo) {
   }
   {
     ProfScope ps(s, "ls_commit");
-    k_ls_commit<<<s->nb_m, SDPLR_NT, 0, s->stream>>>(s->ctrl, (int)s->m, s->pv_raw, s->A_RD, s->A_DD, s->pv_lb, s->pv, 1, s->y, s->lambda, s->lambda_ub, s->partials, 1, 1, s->nb_spmm);
+    k_ls_commit<<<s->nb_m, SDPLR_NT, 0, s->stream>>>(s->ctrl, (int)s->m, s->pv_raw, s->A_RD, s->A_DD, s->pv_lb, s->pv, 1, s->y, s->lambda, s->lambda_ub, s->partials, 1, 1, s->nb_step);
   }
   if (s->lr.ST > 0) {
     ProfScope ps(s, "fast_lr_ws");
     k_fast_lr_ws<<<1, SDPLR_NT, 0, s->stream>>>(s->lr, (int)s->r, s->lr_W, s->y, s->lr_WS, s->ctrl, 1);
   }
   {
-    ProfScope ps(s, "fast_step");                                                     // :219-221
-    LV_DISPATCH((k_fast_step<LPR, VEC><<<s->nb_spmm, SDPLR_NT, 0, s->stream>>>(s->sp_fast, s->ff, R, D, P, W, G, (int)s->r, s->y, s->lr, s->lr_WS, SLOT_GNORM2, s->partials, s->ctrl, 1)))
+    ProfScope ps(s, "fast_step");                                                     // :219-221 (and :244-246 when fused)
+    if (upd_fused) {
+      LV_DISPATCH((k_fast_step2<LPR, VEC, 4, false><<<s->nb_step, SDPLR_NT, 5 * 4 * SDPLR_NT * sizeof(double), s->stream>>>((int)s->n, (int)s->m, s->ff, R, D, P, W, G, (int)s->r, s->y, s->lambda, s->lambda_ub, s->pv_raw, s->pv_lb, s->pv, s->A_RD, s->A_DD, s->lr, s->lr_WS, s->partials, s->ctrl, 1, s->arena, (int)s->h, s->dot_descent ? 0 : 1)))
+    } else {
+      LV_DISPATCH((k_fast_step2<LPR, VEC, 0, false><<<s->nb_step, SDPLR_NT, 0, s->stream>>>((int)s->n, (int)s->m, s->ff, R, D, P, W, G, (int)s->r, s->y, s->lambda, s->lambda_ub, s->pv_raw, s->pv_lb, s->pv, s->A_RD, s->A_DD, s->lr, s->lr_WS, s->partials, s->ctrl, 1, s->arena, (int)s->h, 0)))
+    }
   }
   // norms and the exit tests (:224-241, :272-277, :190) are folded by the next seam kernel
-  enq_lbfgs_update(s, 1);                                                             // :244-246
+  if (!upd_fused) enq_lbfgs_update(s, 1);                                             // :244-246
 }
 
 // singleton form of the fast path (exact line search only): 5 launches per iteration (seam, direction, gather,
@@ -1290,9 +1295,9 @@ void enq_iteration_fast2(S* s) {
   {
     ProfScope ps(s, "fast_step");                                                     // :219-234
     if (upd_fused) {   // … and lbfgs_update! (:244-246) in the same pass
-      LV_DISPATCH((k_fast_step2<LPR, VEC, 4><<<s->nb_step, SDPLR_NT, 5 * 4 * SDPLR_NT * sizeof(double), s->stream>>>((int)s->n, (int)s->m, s->ff, R, D, P, W, G, (int)s->r, s->y, s->lambda, s->lambda_ub, s->pv_raw, s->pv_lb, s->pv, s->A_RD, s->A_DD, s->lr, s->lr_WS, s->partials, s->ctrl, 1, s->arena, (int)s->h, s->dot_descent ? 0 : 1)))
+      LV_DISPATCH((k_fast_step2<LPR, VEC, 4, true><<<s->nb_step, SDPLR_NT, 5 * 4 * SDPLR_NT * sizeof(double), s->stream>>>((int)s->n, (int)s->m, s->ff, R, D, P, W, G, (int)s->r, s->y, s->lambda, s->lambda_ub, s->pv_raw, s->pv_lb, s->pv, s->A_RD, s->A_DD, s->lr, s->lr_WS, s->partials, s->ctrl, 1, s->arena, (int)s->h, s->dot_descent ? 0 : 1)))
     } else {
-      LV_DISPATCH((k_fast_step2<LPR, VEC, 0><<<s->nb_step, SDPLR_NT, 0, s->stream>>>((int)s->n, (int)s->m, s->ff, R, D, P, W, G, (int)s->r, s->y, s->lambda, s->lambda_ub, s->pv_raw, s->pv_lb, s->pv, s->A_RD, s->A_DD, s->lr, s->lr_WS, s->partials, s->ctrl, 1, s->arena, (int)s->h, 0)))
+      LV_DISPATCH((k_fast_step2<LPR, VEC, 0, true><<<s->nb_step, SDPLR_NT, 0, s->stream>>>((int)s->n, (int)s->m, s->ff, R, D, P, W, G, (int)s->r, s->y, s->lambda, s->lambda_ub, s->pv_raw, s->pv_lb, s->pv, s->A_RD, s->A_DD, s->lr, s->lr_WS, s->partials, s->ctrl, 1, s->arena, (int)s->h, 0)))
     }
   }
   if (!upd_fused) enq_lbfgs_update(s, 1);                                             // :244-246
@@ -1798,12 +1803,12 @@ int32_t sdplr_hip_inner_loop(S* s, double normC, double normb, int32_t grel, int
   }
   // fold the partials of a last lbfgs_update (time-budget exit); a replayed graph does not pass through the
   // enqueue functions, so the producer's partial count is set here, not inherited
-  s->gram_nb = (fast2 && step_fuses_update(s)) ? s->nb_step : s->nb_upd;
+  s->gram_nb = (fastp && step_fuses_update(s)) ? s->nb_step : s->nb_upd;
   enq_boundary(s, 0, 1, 0, 0);
   if (fastp) enq_At_preprocess(s, 0);  // leave S consistent with the y of the last step, as g! would
   if ((rc = pull(s))) return rc;
   if (c->done) why = c->exit_reason;   // the device's verdict wins over the host's time check
-  if (fast2 && step_fuses_update(s) && c->iters > 0 && c->err == 0 && why != EXIT_RELDELTA) {
+  if (fastp && step_fuses_update(s) && c->iters > 0 && c->err == 0 && why != EXIT_RELDELTA) {
     // the fused step + update kernel leaves `dirt *= α` (src/lbfgs.jl:142) to this copy: dirt = s_latest
     HIPCK(s, hipMemcpyAsync(aslot(s->arena, AS_D), aslot(s->arena, AS_S0 + (c->latest - 1)), s->N * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
   }
