@@ -1123,7 +1123,7 @@ k_spmm_tile(DevTile tl, int n, int m, DevFast ff, const double* __restrict__ R, 
             const double* __restrict__ P, double* __restrict__ W, int r, const double* __restrict__ lam,
             const double* __restrict__ pv_raw, double* __restrict__ A_RD, double* __restrict__ A_DD,
             double* __restrict__ partials, const DevCtrl* __restrict__ c, int check_done,
-            DevLowRank lr, double* __restrict__ lr_part) {
+            DevLowRank lr, double* __restrict__ lr_part, int rowout) {
   // [G][K+1][LPR·VEC] partial rows, [G][K][2] row dots, [G][8] line-search sums
   extern __shared__ double tile_lds[];
   __shared__ double sh[10 * (SDPLR_NT / 64)];
@@ -1314,6 +1314,14 @@ k_spmm_tile(DevTile tl, int n, int m, DevFast ff, const double* __restrict__ R, 
     for (int k = lane; k < nrows; k += LPR) {
       const long long j = j0 + k;
       const double rd = dots[2 * k], dd = dots[2 * k + 1];
+      if (rowout) {   // general diagonal-only matrices (k_rowdots's output): the dots go where k_sddmm<…,2> would
+        const int q = ff.diagpos[j];      // put them, A_RD / A_DD here being the two UVt arrays; k_segreduce follows
+        if (q >= 0) {
+          A_RD[q] = rd + rd;
+          A_DD[q] = dd;
+        }
+        continue;
+      }
       const int e0 = ff.drow_ptr[j], e1 = ff.drow_ptr[j + 1];
       for (int e = e0; e < e1; e++) {
         const int gid = ff.drow_gid[e];

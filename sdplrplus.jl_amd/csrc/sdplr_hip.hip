@@ -1190,6 +1190,13 @@ void enq_iteration_fast(S* s, int armijo) {
     (void)hipMemsetAsync(s->A_RD, 0, (s->m + 1) * sizeof(double), s->stream);
     (void)hipMemsetAsync(s->A_DD, 0, (s->m + 1) * sizeof(double), s->stream);
   }
+  // W = A_g·D and the row dots: the column-sweep tile kernel when it applies (no hub rows), else two kernels
+  const bool tiled = s->use_tile && s->tile_lpr == s->LPR && s->n * s->r * 8 < (1LL << 32) && s->spg.n_long_rows == 0;
+  if (tiled) {
+    ProfScope ps(s, "spmm_W");
+    const size_t lds = ((size_t)SDPLR_NT * s->VEC * (s->tile.K + 1) + (size_t)(SDPLR_NT / s->LPR) * (2 * s->tile.K + 8)) * sizeof(double);
+    LV_DISPATCH((k_spmm_tile<LPR, VEC, 0><<<s->nb_tile, SDPLR_NT, lds, s->stream>>>(s->tile, (int)s->n, (int)s->m, s->ff, R, D, P, W, (int)s->r, s->lambda, s->pv_raw, s->sp_fast.UVt0, s->sp_fast.UVt1, s->partials, s->ctrl, 1, s->lr, s->lr_part, 1)))
+  } else {
   {
     ProfScope ps(s, "rowdots");
     LV_DISPATCH((k_rowdots<LPR, VEC><<<s->nb_spmm, SDPLR_NT, 0, s->stream>>>(s->sp_fast, s->ff, R, D, P, (int)s->r, SLOT_PD, s->partials, s->ctrl, 1)))
@@ -1203,6 +1210,7 @@ void enq_iteration_fast(S* s, int armijo) {
     } else {
       LV_DISPATCH((k_spmm<LPR, VEC><<<s->nb_spmm, SDPLR_NT, 0, s->stream>>>(s->spg, D, W, (int)s->r, 1.0, none, nullptr, SLOT_DW, s->partials, s->ctrl, 1, D)))
     }
+  }
   }
   {
     const int nb = s->sp_fast.n_short_blocks + s->sp_fast.n_chunks;
@@ -1218,7 +1226,8 @@ void enq_iteration_fast(S* s, int armijo) {
   }
   {
     ProfScope ps(s, "fast_fill");
-    k_fast_fill<<<1, SDPLR_NT, 0, s->stream>>>(s->ff, s->A_RD, s->A_DD, SLOT_PD, s->nb_spmm, SLOT_DW, s->nb_spmm + std::min(s->spg.n_long_rows, 256), s->partials, s->ctrl, 1);
+    if (tiled) k_fast_fill<<<1, SDPLR_NT, 0, s->stream>>>(s->ff, s->A_RD, s->A_DD, SLOT_PD, s->nb_tile, SLOT_DW, s->nb_tile, s->partials, s->ctrl, 1);
+    else k_fast_fill<<<1, SDPLR_NT, 0, s->stream>>>(s->ff, s->A_RD, s->A_DD, SLOT_PD, s->nb_spmm, SLOT_DW, s->nb_spmm + std::min(s->spg.n_long_rows, 256), s->partials, s->ctrl, 1);
   }
   enq_lowrank(s, R, D, 2, 2, s->A_RD, s->A_DD, 1);
   // ---- scalar stage + commit (with y of the following g!) ----
@@ -1272,8 +1281,8 @@ void enq_iteration_fast2(S* s) {
     if (s->use_tile && s->tile_lpr == s->LPR && s->n * s->r * 8 < (1LL << 32)) {
       lr_fused = s->lr.ST == 1 && s->r <= (int64_t)s->LPR * s->VEC && !s->no_lrfuse;
       const size_t lds = ((size_t)SDPLR_NT * s->VEC * (s->tile.K + 1) + (size_t)(SDPLR_NT / s->LPR) * (2 * s->tile.K + 8) + (lr_fused ? (size_t)(SDPLR_NT / 64) * 2 * s->LPR * s->VEC : 0)) * sizeof(double);
-      if (lr_fused) { LV_DISPATCH((k_spmm_tile<LPR, VEC, 1><<<s->nb_tile, SDPLR_NT, lds, s->stream>>>(s->tile, (int)s->n, (int)s->m, s->ff, R, D, P, W, (int)s->r, s->lambda, s->pv_raw, s->A_RD, s->A_DD, s->partials, s->ctrl, 1, s->lr, s->lr_part))) }
-      else { LV_DISPATCH((k_spmm_tile<LPR, VEC, 0><<<s->nb_tile, SDPLR_NT, lds, s->stream>>>(s->tile, (int)s->n, (int)s->m, s->ff, R, D, P, W, (int)s->r, s->lambda, s->pv_raw, s->A_RD, s->A_DD, s->partials, s->ctrl, 1, s->lr, s->lr_part))) }
+      if (lr_fused) { LV_DISPATCH((k_spmm_tile<LPR, VEC, 1><<<s->nb_tile, SDPLR_NT, lds, s->stream>>>(s->tile, (int)s->n, (int)s->m, s->ff, R, D, P, W, (int)s->r, s->lambda, s->pv_raw, s->A_RD, s->A_DD, s->partials, s->ctrl, 1, s->lr, s->lr_part, 0))) }
+      else { LV_DISPATCH((k_spmm_tile<LPR, VEC, 0><<<s->nb_tile, SDPLR_NT, lds, s->stream>>>(s->tile, (int)s->n, (int)s->m, s->ff, R, D, P, W, (int)s->r, s->lambda, s->pv_raw, s->A_RD, s->A_DD, s->partials, s->ctrl, 1, s->lr, s->lr_part, 0))) }
     } else {
       LV_DISPATCH((k_spmm_fast<LPR, VEC><<<s->nb_spmm, SDPLR_NT, 0, s->stream>>>(s->spg, (int)s->m, s->ff, R, D, P, W, (int)s->r, s->lambda, s->pv_raw, s->A_RD, s->A_DD, s->partials, s->ctrl, 1)))
     }
