@@ -263,6 +263,100 @@ k_step_jobs(DevSparse sp, const double* __restrict__ y, const DevCtrl* __restric
   }
 }
 
+// ---- lbfgs_update! (src/lbfgs.jl:129-149) riding a kernel that produces G_new row by row ----------------
+// The lane that holds a chunk of G_new takes the same chunk of dirt, of G_old (still in the G array: read before
+// the new value is stored; sign gs — it is −G_old's role that lbfgs_dir! would have parked in slot j, flipped
+// once more if the steepest-descent fallback negated G) and of the HMU history pairs, stores s_j = α·dirt and
+// y_j = G_new − G_old, and adds the five families of Gram dots into its own column of the LDS array `accl`
+// ([5·HMU][NT], ds_add_f64 without return).  `dirt *= α` itself is left to the copy at loop exit.
+struct UpdCtx {
+  FactorArena A;
+  const double* D;     // dirt
+  double* accl;
+  double alpha, gs;
+  int h, jslot, upd;
+};
+template <int HMU>
+__device__ __forceinline__ UpdCtx upd_ctx(const DevCtrl* c, FactorArena A, int h, const double* D, double* accl) {
+  UpdCtx u;
+  u.A = A;
+  u.D = D;
+  u.accl = accl;
+  u.alpha = c->alpha;
+  u.gs = c->fallback ? 1.0 : -1.0;
+  u.h = h;
+  u.jslot = c->latest % (h > 0 ? h : 1);
+  u.upd = c->reldelta_exit == 0;
+#pragma unroll
+  for (int k = 0; k < 5 * HMU; k++) accl[k * SDPLR_NT + threadIdx.x] = 0.0;
+  return u;
+}
+// g: the chunk of G_new; gold: the same chunk of the G array as it was; e: element offset of the chunk
+template <int VEC, int HMU>
+__device__ __forceinline__ void upd_row(const UpdCtx& u, const vecd<VEC>& g, const vecd<VEC>& gold, long long e) {
+  double* Yj = aslot(u.A, as_y0(u.A) + u.jslot);
+  if (!u.upd) {   // relative-decrease exit: no update, y_next = −G_old parked as lbfgs_dir! would have
+    vecd<VEC> go;
+#pragma unroll
+    for (int q = 0; q < VEC; q++) go.v[q] = u.gs * gold.v[q];
+    strow<VEC>(Yj + e, go);
+    return;
+  }
+  const vecd<VEC> d = ldrow<VEC>(u.D + e);
+  vecd<VEC> sv[HMU], yv[HMU];
+#pragma unroll
+  for (int l = 0; l < HMU; l++) {
+    const int slot = (l < u.h) ? l : 0;
+    sv[l] = ldrow<VEC>(aslot(u.A, AS_S0 + slot) + e);
+    yv[l] = ldrow<VEC>(aslot(u.A, as_y0(u.A) + slot) + e);
+  }
+  vecd<VEC> sn, yn;
+#pragma unroll
+  for (int q = 0; q < VEC; q++) {
+    sn.v[q] = u.alpha * d.v[q];              // BLAS.scal!(stepsize, dir)  (:142)
+    yn.v[q] = u.gs * gold.v[q] + g.v[q];     // y_j = −G_old + G_new  (:122,145)
+  }
+  strow<VEC>(aslot(u.A, AS_S0 + u.jslot) + e, sn);   // copy!(s_j, dir)  (:143)
+  strow<VEC>(Yj + e, yn);
+#pragma unroll
+  for (int l = 0; l < HMU; l++)
+    if (l < u.h) {
+      const vecd<VEC> sl = (l == u.jslot) ? sn : sv[l];
+      const vecd<VEC> yl = (l == u.jslot) ? yn : yv[l];
+      double q0 = 0.0, q1 = 0.0, q2 = 0.0, q3 = 0.0, q4 = 0.0;
+#pragma unroll
+      for (int q = 0; q < VEC; q++) {
+        q0 += sn.v[q] * yl.v[q];
+        q1 += sl.v[q] * yn.v[q];
+        q2 += yn.v[q] * yl.v[q];
+        q3 += sl.v[q] * g.v[q];
+        q4 += yl.v[q] * g.v[q];
+      }
+      double* ac = u.accl + threadIdx.x;
+      (void)__hip_atomic_fetch_add(ac + (0 * HMU + l) * SDPLR_NT, q0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      (void)__hip_atomic_fetch_add(ac + (1 * HMU + l) * SDPLR_NT, q1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      (void)__hip_atomic_fetch_add(ac + (2 * HMU + l) * SDPLR_NT, q2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      (void)__hip_atomic_fetch_add(ac + (3 * HMU + l) * SDPLR_NT, q3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      (void)__hip_atomic_fetch_add(ac + (4 * HMU + l) * SDPLR_NT, q4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+}
+// block sums of the running Gram sums straight out of LDS, one wave per sum → partial entry `pidx`
+template <int HMU>
+__device__ __forceinline__ void upd_flush(const UpdCtx& u, DevCtrl* c, double* partials, int pidx, bool first_block) {
+  __syncthreads();
+  if (!u.upd) return;
+  const int wave = threadIdx.x >> 6, wl = threadIdx.x & 63;
+  for (int k = wave; k < 5 * HMU; k += SDPLR_NT / 64) {
+    double t = 0.0;
+#pragma unroll
+    for (int i = 0; i < SDPLR_NT / 64; i++) t += u.accl[k * SDPLR_NT + wl + 64 * i];
+    t = wave_sum(t);
+    const int q = k / HMU, l = k % HMU;
+    if (wl == 0 && l < u.h) slot_partials(partials, SLOT_GRAM + q * SDPLR_HMAX + l)[pidx] = t;
+  }
+  if (first_block && threadIdx.x == 0) c->gram_pending = 1;  // consumed by k_lbfgs_boundary
+}
+
 // ---- SpMM: Y[j,:] = scale·( Σ_{p∈col j} S[p]·X[rowval[p],:] + Σ_c WS[c,:]·B[c][j] ) ----------------------
 // 𝒜t!(y, x, aux, var) src/coreop.jl:260-279 (S is symmetric: column j of the CSC pattern lists row j's
 // neighbours); scale = 2 fuses BLAS.scal!(2, Gt) of g! (:315); with slot ≥ 0 the ‖Y‖² partials of
@@ -270,11 +364,12 @@ k_step_jobs(DevSparse sp, const double* __restrict__ y, const DevCtrl* __restric
 // low-rank product of src/structs.jl:135-145 prepared by k_lr_finalize.
 // (bid, nblk: this block's index and the number of blocks working on the short rows — the body is shared by
 // k_spmm and by k_spmm_both, where the hub-row blocks come first in the same grid)
-template <int LPR, int VEC>
+template <int LPR, int VEC, int HMU = 0>
 __device__ __forceinline__ void
-spmm_rows(DevSparse sp, const double* __restrict__ X, double* __restrict__ Y, int r, double scale,
+spmm_rows(DevSparse sp, const double* __restrict__ X, double* Y, int r, double scale,
           DevLowRank lr, const double* __restrict__ WS, int slot, double* __restrict__ partials,
-          const DevCtrl* __restrict__ c, int check_done, const double* __restrict__ Xdot, int bid, int nblk) {
+          const DevCtrl* __restrict__ c, int check_done, const double* __restrict__ Xdot, int bid, int nblk,
+          const UpdCtx* u = nullptr) {
   __shared__ double sh[8];
   if (check_done && c->done) return;
   constexpr int G = SDPLR_NT / LPR;
@@ -334,6 +429,10 @@ spmm_rows(DevSparse sp, const double* __restrict__ X, double* __restrict__ Y, in
       } else {
 #pragma unroll
         for (int k = 0; k < VEC; k++) nrm += acc.v[k] * acc.v[k];
+      }
+      if constexpr (HMU > 0) {
+        const vecd<VEC> gold = ldrow<VEC>(Y + j * r + ch);
+        upd_row<VEC, HMU>(*u, acc, gold, j * r + ch);
       }
       strow<VEC>(Y + j * r + ch, acc);
     }
@@ -1384,11 +1483,12 @@ k_spmm_tile(DevTile tl, int n, int m, DevFast ff, const double* __restrict__ R, 
 // Same result as k_spmm for those rows (which k_spmm skips): the row's nonzeros are dealt round-robin to the
 // block's sub-wave groups, the group partials are added in group order (deterministic).  Partials of the
 // norm / dot go to slot entries [pbase, pbase + n_long_rows).
-template <int LPR, int VEC>
+template <int LPR, int VEC, int HMU = 0>
 __device__ __forceinline__ void
-spmm_long_rows(DevSparse sp, const double* __restrict__ X, double* __restrict__ Y, int r, double scale,
+spmm_long_rows(DevSparse sp, const double* __restrict__ X, double* Y, int r, double scale,
                DevLowRank lr, const double* __restrict__ WS, int slot, int pbase, double* __restrict__ partials,
-               const DevCtrl* __restrict__ c, int check_done, const double* __restrict__ Xdot, int bid, int nblk) {
+               const DevCtrl* __restrict__ c, int check_done, const double* __restrict__ Xdot, int bid, int nblk,
+               const UpdCtx* u = nullptr) {
   __shared__ double shg[SDPLR_NT * VEC];
   __shared__ double sh[8];
   if (check_done && c->done) return;
@@ -1469,6 +1569,10 @@ spmm_long_rows(DevSparse sp, const double* __restrict__ X, double* __restrict__ 
 #pragma unroll
         for (int k = 0; k < VEC; k++) nrm += tot.v[k] * tot.v[k];
       }
+      if constexpr (HMU > 0) {
+        const vecd<VEC> gold = ldrow<VEC>(Y + j * r + ch);
+        upd_row<VEC, HMU>(*u, tot, gold, j * r + ch);
+      }
       strow<VEC>(Y + j * r + ch, tot);
     }
   }
@@ -1498,6 +1602,24 @@ k_spmm_both(DevSparse sp, const double* __restrict__ X, double* __restrict__ Y, 
     spmm_long_rows<LPR, VEC>(sp, X, Y, r, scale, lr, WS, slot, nb_short, partials, c, check_done, Xdot, blockIdx.x, nb_long);
   else
     spmm_rows<LPR, VEC>(sp, X, Y, r, scale, lr, WS, slot, partials, c, check_done, Xdot, blockIdx.x - nb_long, nb_short);
+}
+
+// G = 2·R·S of the in-loop g! with lbfgs_update! riding along (see upd_row): hub blocks first, then short rows;
+// every block contributes one entry to each Gram partial slot (hub block b → b, short block b → nb_long + b)
+template <int LPR, int VEC, int HMU>
+__global__ void __launch_bounds__(SDPLR_NT)
+k_spmm_both_upd(DevSparse sp, const double* __restrict__ X, double* Y, int r, double scale, DevLowRank lr,
+                const double* __restrict__ WS, int slot, double* __restrict__ partials, DevCtrl* __restrict__ c,
+                int nb_long, FactorArena A, int h, const double* __restrict__ D) {
+  extern __shared__ double upd_accl[];
+  if (c->done) return;
+  const UpdCtx u = upd_ctx<HMU>(c, A, h, D, upd_accl);
+  const int nb_short = gridDim.x - nb_long;
+  if ((int)blockIdx.x < nb_long)
+    spmm_long_rows<LPR, VEC, HMU>(sp, X, Y, r, scale, lr, WS, slot, nb_short, partials, c, 0, nullptr, blockIdx.x, nb_long, &u);
+  else
+    spmm_rows<LPR, VEC, HMU>(sp, X, Y, r, scale, lr, WS, slot, partials, c, 0, nullptr, blockIdx.x - nb_long, nb_short, &u);
+  upd_flush<HMU>(u, c, partials, blockIdx.x, blockIdx.x == 0);
 }
 
 // hub rows of the SpMV: one block per row, 256 lanes stride the row

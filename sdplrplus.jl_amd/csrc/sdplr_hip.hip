@@ -1144,14 +1144,27 @@ void enq_axpy_R(S* s, int chk) {
 }
 
 // one pass of the while body, src/sdplr.jl:190-278, entirely device-driven
+// lbfgs_update! rides the SpMM of g! on the generic in-loop path (k_spmm_both_upd) for h ≤ 4
+bool spmm_fuses_update(const S* s) {
+  return s->h >= 1 && s->h <= 4 && s->n_sparse > 0 && !s->no_lrfuse && !s->no_updfuse && !s->dot_descent;
+}
+int spmm_upd_blocks(const S* s) { return s->nb_spmm + std::min(s->sp.n_long_rows, 256); }
+
 void enq_iteration(S* s, int armijo) {
-  s->gram_nb = s->nb_upd;                    // this path's lbfgs_update! grid (read by the seam kernel)
-  enq_lbfgs_dir(s, 1, 1, 1);                 // :197-205
+  const bool upd_fused = spmm_fuses_update(s);
+  s->gram_nb = upd_fused ? spmm_upd_blocks(s) : s->nb_upd;   // the Gram partials' producer grid (read by the seam kernel)
+  enq_lbfgs_dir(s, 1, 1, 1, upd_fused);      // :197-205
   enq_linesearch(s, armijo, 1, 1);           // :210-214
   if (s->n_sparse > 0 && !s->no_lrfuse) {     // :219 and the head of g! (:221) as one launch, then the SpMM
     {
       ProfScope ps(s, "step_jobs");
       k_step_jobs<<<s->nb_dense + s->nb_nnzS + (s->lr.ST > 0 ? 1 : 0), SDPLR_NT, 0, s->stream>>>(s->sp, s->y, s->ctrl, aslot(s->arena, AS_R), aslot(s->arena, AS_D), s->N, s->nb_dense, s->nb_nnzS, s->lr, (int)s->r, s->lr_W, s->lr_WS);
+    }
+    if (upd_fused) {   // … and lbfgs_update! (:244-246) on the rows of G as they are produced
+      ProfScope ps(s, "spmm");
+      const int nbl = std::min(s->sp.n_long_rows, 256);
+      LV_DISPATCH((k_spmm_both_upd<LPR, VEC, 4><<<s->nb_spmm + nbl, SDPLR_NT, 5 * 4 * SDPLR_NT * sizeof(double), s->stream>>>(s->sp, aslot(s->arena, AS_R), aslot(s->arena, AS_G), (int)s->r, 2.0, s->lr, s->lr_WS, SLOT_GNORM2, s->partials, s->ctrl, nbl, s->arena, (int)s->h, aslot(s->arena, AS_D))))
+      return;
     }
     enq_spmm_S(s, aslot(s->arena, AS_G), aslot(s->arena, AS_R), 2.0, SLOT_GNORM2, 1);
   } else {
@@ -1812,13 +1825,14 @@ int32_t sdplr_hip_inner_loop(S* s, double normC, double normb, int32_t grel, int
   }
   // fold the partials of a last lbfgs_update (time-budget exit); a replayed graph does not pass through the
   // enqueue functions, so the producer's partial count is set here, not inherited
-  s->gram_nb = (fastp && step_fuses_update(s)) ? s->nb_step : s->nb_upd;
+  const bool loop_fused = fastp ? step_fuses_update(s) : spmm_fuses_update(s);   // lbfgs_update! rode another kernel
+  s->gram_nb = !loop_fused ? s->nb_upd : (fastp ? s->nb_step : spmm_upd_blocks(s));
   enq_boundary(s, 0, 1, 0, 0);
   if (fastp) enq_At_preprocess(s, 0);  // leave S consistent with the y of the last step, as g! would
   if ((rc = pull(s))) return rc;
   if (c->done) why = c->exit_reason;   // the device's verdict wins over the host's time check
-  if (fastp && step_fuses_update(s) && c->iters > 0 && c->err == 0 && why != EXIT_RELDELTA) {
-    // the fused step + update kernel leaves `dirt *= α` (src/lbfgs.jl:142) to this copy: dirt = s_latest
+  if (loop_fused && c->iters > 0 && c->err == 0 && why != EXIT_RELDELTA) {
+    // the kernels lbfgs_update! rides on leave `dirt *= α` (src/lbfgs.jl:142) to this copy: dirt = s_latest
     HIPCK(s, hipMemcpyAsync(aslot(s->arena, AS_D), aslot(s->arena, AS_S0 + (c->latest - 1)), s->N * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
   }
   if (dbg)

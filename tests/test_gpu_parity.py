@@ -472,6 +472,8 @@ def test_concurrent_handles_match_serial(hip_abi):
     ("maxcut", ["SDPLR_HIP_NO_UPDFUSE"]), ("minimum_bisection", ["SDPLR_HIP_NO_UPDFUSE"]),
     ("mu_conductance_0.05", ["SDPLR_HIP_NO_TILE"]), ("mu_conductance_0.05", ["SDPLR_HIP_NO_UPDFUSE"]),
     ("ineq_0.05", ["SDPLR_HIP_NO_TILE", "SDPLR_HIP_NO_UPDFUSE"]),
+    ("lovasz_theta", ["SDPLR_HIP_NO_UPDFUSE"]), ("maxcut", ["SDPLR_HIP_NO_FAST", "SDPLR_HIP_NO_UPDFUSE"]),
+    ("ineq_0.05", ["SDPLR_HIP_NO_FAST", "SDPLR_HIP_NO_UPDFUSE"]),
     ("maxcut", ["SDPLR_HIP_DOT_DESCENT"]), ("cutnorm", ["SDPLR_HIP_DOT_DESCENT"]), ("ineq_0.05", ["SDPLR_HIP_DOT_DESCENT"]),
     ("minimum_bisection", ["SDPLR_HIP_NO_FAST"]),
     ("minimum_bisection", ["SDPLR_HIP_NO_FAST2"]), ("minimum_bisection", ["SDPLR_HIP_NO_LRFUSE"]),
