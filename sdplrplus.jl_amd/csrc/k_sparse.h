@@ -29,7 +29,7 @@ struct DevSparse {
   const int *short_ids, *chunk_beg, *chunk_end, *long_ids, *long_chunk_ptr;
   double *chunk_partial0, *chunk_partial1;
   double *UVt0, *UVt1;
-  // rows of the full pattern with more than long_thresh nonzeros (hub vertices): one block each (k_spmm_long)
+  // rows of the full pattern with more than long_thresh nonzeros (hub vertices): one block each (spmm_long_rows)
   int n_long_rows, long_thresh;
   const int* long_rows;
 };
@@ -378,7 +378,7 @@ spmm_rows(DevSparse sp, const double* __restrict__ X, double* Y, int r, double s
   double nrm = 0.0;
   for (long long j = (long long)bid * G + threadIdx.x / LPR; j < sp.n; j += total) {
     const int beg = sp.colptr[j], end = sp.colptr[j + 1];
-    if (sp.n_long_rows > 0 && end - beg > sp.long_thresh) continue;  // hub row: k_spmm_long
+    if (sp.n_long_rows > 0 && end - beg > sp.long_thresh) continue;  // hub row: spmm_long_rows
     for (int chb = 0; chb < r; chb += LPR * VEC) {
       // all lanes of the group run the loop: the (index, value) pairs of the row are fetched LPR at a time and
       // handed round with shuffles, eight row gathers in flight per lane (see k_spmm_fast)
@@ -761,62 +761,6 @@ k_fast_lr_ws(DevLowRank lr, int r, double* __restrict__ W, const double* __restr
 // segmented reduction, ls_partials and ls_commit launches disappear.  Slots not attached to a row — A_g
 // itself and the low-rank matrices ("extra" slots) — are handled by the single-block scalar kernel.
 // ================================================================================================
-template <int LPR, int VEC>
-__global__ void __launch_bounds__(SDPLR_NT)
-k_rowdots_ls(int n, int m, DevFast ff, const double* __restrict__ R, const double* __restrict__ D,
-             const double* __restrict__ P, int r, const double* __restrict__ lam,
-             const double* __restrict__ pv_raw, double* __restrict__ A_RD, double* __restrict__ A_DD,
-             double* __restrict__ partials, const DevCtrl* __restrict__ c, int check_done) {
-  __shared__ double sh[9 * (SDPLR_NT / 64)];
-  if (check_done && c->done) return;
-  constexpr int G = SDPLR_NT / LPR;
-  const int lane = threadIdx.x % LPR;
-  const long long total = (long long)gridDim.x * G;
-  const double sigma = c->sigma;
-  double acc[9];
-#pragma unroll
-  for (int k = 0; k < 9; k++) acc[k] = 0.0;
-  for (long long j = (long long)blockIdx.x * G + threadIdx.x / LPR; j < n; j += total) {
-    double rd = 0.0, dd = 0.0;
-    for (int ch = lane * VEC; ch < r; ch += LPR * VEC) {
-      const vecd<VEC> x = ldrow<VEC>(R + j * r + ch), d = ldrow<VEC>(D + j * r + ch), pp = ldrow<VEC>(P + j * r + ch);
-#pragma unroll
-      for (int k = 0; k < VEC; k++) {
-        rd += x.v[k] * d.v[k];
-        dd += d.v[k] * d.v[k];
-        acc[8] += pp.v[k] * d.v[k];
-      }
-    }
-    rd = group_sum<LPR>(rd);
-    dd = group_sum<LPR>(dd);
-    if (lane == 0)
-      for (int e = ff.drow_ptr[j]; e < ff.drow_ptr[j + 1]; e++) {
-        const int k = ff.drow_gid[e];
-        const double v = ff.drow_val[e];
-        const double q1 = v * (rd + rd), q2 = v * dd;
-        A_RD[k] = q1;
-        A_DD[k] = q2;
-        if (k < m) {
-          const double l = lam[k], nq0 = pv_raw[k];
-          acc[0] += l * nq0;
-          acc[1] += nq0 * nq0;
-          acc[2] += l * q1;
-          acc[3] += nq0 * q1;
-          acc[4] += (l - sigma * nq0) * q2;
-          acc[5] += q1 * q1;
-          acc[6] += q1 * q2;
-          acc[7] += q2 * q2;
-        }
-      }
-  }
-  block_sum<9>(acc, sh);
-  if (threadIdx.x == 0) {
-#pragma unroll
-    for (int k = 0; k < 8; k++) slot_partials(partials, SLOT_LS + k)[blockIdx.x] = acc[k];
-    slot_partials(partials, SLOT_PD)[blockIdx.x] = acc[8];
-  }
-}
-
 // The step of the structured fast path: R += α·D (src/sdplr.jl:219), P += α·W, then g! (src/coreop.jl:305-317)
 // as G = 2·(y_g·P + d(y)∘R + Σ_c WS[c]·B[c]) with the ‖G‖² partials of norm(Gt) (src/sdplr.jl:225).
 // COMMIT (singleton form): also the commit of the row-attached constraints and their y; the extra slots were
@@ -1073,7 +1017,7 @@ k_fast_step2(int n, int m, DevFast ff, double* __restrict__ R, double* __restric
 // W = A_g·D with everything row-local of the line-search head riding along (singleton fast path):
 // while row j's neighbours are being gathered, R_j, D_j, P_j stream in, giving ⟨R_j,D_j⟩, ‖D_j‖², the
 // partials of ⟨P,D⟩ and ⟨D,W⟩, the 𝒜 values of the row's singleton constraints and their share of the
-// line-search sums (k_rowdots_ls + k_spmm in one sweep; the gather latency hides the extra streams).
+// line-search sums (row dots, line-search sums and the SpMM in one sweep; the gather latency hides the extra streams).
 template <int LPR, int VEC>
 __global__ void __launch_bounds__(SDPLR_NT)
 k_spmm_fast(DevSparse sg, int m, DevFast ff, const double* __restrict__ R, const double* __restrict__ D,
@@ -1581,13 +1525,6 @@ spmm_long_rows(DevSparse sp, const double* __restrict__ X, double* Y, int r, dou
     nrm = block_sum1(nrm, sh);
     if (threadIdx.x == 0) slot_partials(partials, slot)[pbase + bid] = nrm;
   }
-}
-template <int LPR, int VEC>
-__global__ void __launch_bounds__(SDPLR_NT)
-k_spmm_long(DevSparse sp, const double* __restrict__ X, double* __restrict__ Y, int r, double scale,
-            DevLowRank lr, const double* __restrict__ WS, int slot, int pbase, double* __restrict__ partials,
-            const DevCtrl* __restrict__ c, int check_done, const double* __restrict__ Xdot) {
-  spmm_long_rows<LPR, VEC>(sp, X, Y, r, scale, lr, WS, slot, pbase, partials, c, check_done, Xdot, blockIdx.x, gridDim.x);
 }
 // Both in one grid: the first nb_long blocks take the hub rows (the longest work items start first), the rest
 // the short rows — the two row sets are disjoint, and as two launches the hub rows (a few hundred rows, tens of
