@@ -75,6 +75,7 @@ struct sdplr_hip_solver {
   bool use_tile = false;
   bool no_updfuse = false;   // SDPLR_HIP_NO_UPDFUSE: lbfgs_update! as a kernel of its own on the singleton fast path
   int gram_nb = 1;           // number of Gram partials the latest enqueued producer writes (k_lbfgs_update / fused step)
+  bool force_graph = false;  // SDPLR_HIP_FORCE_GRAPH: hipGraph batches on small instances too (the tests' default)
   bool no_lrfuse = false;    // SDPLR_HIP_NO_LRFUSE: low-rank projections by k_lr_project even on the tile path
   bool dot_descent = false;  // SDPLR_HIP_DOT_DESCENT: in-loop ⟨dir, G⟩ by reduction (k_descent) instead of the Gram form
   int tile_lpr = 0;          // the lists are padded to multiples of this sub-wave width
@@ -652,6 +653,7 @@ int32_t sdplr_hip_finalize(S* s) {
   s->dot_descent = getenv("SDPLR_HIP_DOT_DESCENT") != nullptr;
   if (const char* e = getenv("SDPLR_HIP_GRAPH_ITERS")) s->graph_iters = std::max(1, std::min(atoi(e), 64));
   s->no_lrfuse = getenv("SDPLR_HIP_NO_LRFUSE") != nullptr;
+  s->force_graph = getenv("SDPLR_HIP_FORCE_GRAPH") != nullptr;
   s->no_updfuse = getenv("SDPLR_HIP_NO_UPDFUSE") != nullptr;
   if (s->have_sparse && getenv("SDPLR_HIP_NO_FAST") == nullptr) {
     std::vector<int> general;
@@ -1458,7 +1460,7 @@ int run_lanczos(S* s, int64_t q, const double* v0, double* alpha, double* beta, 
   if (const char* e = getenv("SDPLR_HIP_LZ_REPS")) reps = std::max(1, std::min(atoi(e), 64));
   if (s->lz_graph && s->lz_graph_reps != reps) { (void)hipGraphExecDestroy(s->lz_graph); s->lz_graph = nullptr; }
   const int64_t rounds = (q + 1 + 2) / 3;   // q steps + the closing k_lz_spmv of step q+1
-  bool use_graph = !s->prof_on && !s->graph_disabled && getenv("SDPLR_HIP_NO_GRAPH") == nullptr;
+  bool use_graph = !s->prof_on && !s->graph_disabled && getenv("SDPLR_HIP_NO_GRAPH") == nullptr && (n >= (1 << 14) || s->force_graph);
   if (use_graph && !s->lz_graph && api_lock) {
     api_lock->unlock();
     {
@@ -1739,7 +1741,10 @@ int32_t sdplr_hip_inner_loop(S* s, double normC, double normb, int32_t grel, int
     else enq_iteration(s, use_armijo);
   };
   if (fastp) enq_fast_refresh_P(s);
-  bool use_graph = !s->prof_on && !s->graph_disabled && max_local_iters >= 4 && getenv("SDPLR_HIP_NO_GRAPH") == nullptr;
+  // hipGraph batches pay for their capture (milliseconds, and exclusive of every other handle's HIP calls) only
+  // on instances whose solve is long: small factors (config 5's n = 800 batch: 64 solves 1.3 → 0.95 s) stay eager
+  bool use_graph = !s->prof_on && !s->graph_disabled && max_local_iters >= 4 && getenv("SDPLR_HIP_NO_GRAPH") == nullptr &&
+                   (s->N >= (1LL << 17) || s->force_graph);
   if (use_graph && !s->graph_exec[ar]) {
     // Capture is fragile on ROCm 7.2 when OTHER host threads issue HIP calls meanwhile (observed: 8 handles
     // driven by 8 threads → "operation failed due to a previous error during capture", any capture mode).
