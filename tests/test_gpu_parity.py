@@ -180,6 +180,23 @@ def test_inner_loop_trajectory(hip_abi, oracle_abi, family):
         s_.close()
 
 
+@pytest.mark.parametrize("family", ["maxcut", "minimum_bisection", "lovasz_theta", "mu_conductance_0.05", "ineq_0.05"])
+def test_iteration_paths_are_run_to_run_deterministic(hip_abi, family):
+    """No float atomics on global memory, LDS adds in issue order on lane-private addresses, fixed-order block and
+    grid reductions: three runs of the same 20 iterations give bit-identical R, G and ℒ on every iteration path
+    (singleton / rank-1 / non-singleton fast paths, generic path, Armijo)."""
+    data, C, As, bs = make_data(family, 5, 120, 0.08)
+    normC, normb = data.normC(), float(np.linalg.norm(data.b))
+    seen = set()
+    for rep in range(3):
+        g, _ = make_solver(hip_abi, data, 16, seed=2)
+        st = g.fg(normC, normb)
+        out = g.inner_loop(normC, normb, True, True, data.has_inequalities, 0.0, -1e300, 20, 0.0, *st)
+        seen.add((g.Rt.tobytes(), g.Gt.tobytes(), out[0]))
+        g.close()
+    assert len(seen) == 1
+
+
 @pytest.mark.parametrize("family", ["maxcut", "minimum_bisection", "lovasz_theta"])
 def test_inner_loop_time_budget_exit_leaves_a_consistent_state(hip_abi, oracle_abi, family):
     """The host's time budget (src/sdplr.jl:299) stops the loop between two batches, i.e. after a whole number
