@@ -572,7 +572,8 @@ int32_t sdplr_hip_finalize(S* s) {
   auto plan_long = [&](const std::vector<int>& ptr, DevSparse& dst) -> int {
     std::vector<int> deg(n);
     for (int64_t j = 0; j < n; j++) deg[j] = ptr[j + 1] - ptr[j];
-    const int thresh = 64;   // ≈ 3× the mean degree of the G(n,p) configurations: none of their rows qualify
+    int thresh = 64;   // ≈ 3× the mean degree of the G(n,p) configurations: none of their rows qualify
+    if (const char* e = getenv("SDPLR_HIP_HUB_THRESH")) thresh = std::max(8, atoi(e));
     std::vector<int> rows;
     for (int64_t j = 0; j < n; j++)
       if (deg[j] > thresh) rows.push_back((int)j);
