@@ -1411,7 +1411,8 @@ void enq_lz_step(S* s, double* uprev, double* u, double* t) {
   {
     ProfScope ps(s, "lz_spmv");
     static const int lz_lpr = getenv("SDPLR_HIP_LZ_LPR") ? atoi(getenv("SDPLR_HIP_LZ_LPR")) : 8;
-    const int nbv = blocks_for(s->n, SDPLR_NT / lz_lpr, 768);  // more blocks only lengthen the consumer-side reductions
+    static const int lz_nb = getenv("SDPLR_HIP_LZ_NB") ? atoi(getenv("SDPLR_HIP_LZ_NB")) : 768;
+    const int nbv = blocks_for(s->n, SDPLR_NT / lz_lpr, lz_nb);  // more blocks only lengthen the consumer-side reductions
     s->nb_lzv = nbv;
     if (lz_lpr == 4) k_lz_spmv<4><<<nbv, SDPLR_NT, 0, s->stream>>>(s->sp, s->ctrl, u, t, s->lr, s->y, s->lr_btx_part, s->nb_n, s->lr_coef, s->lz_beta, s->partials);
     else if (lz_lpr == 16) k_lz_spmv<16><<<nbv, SDPLR_NT, 0, s->stream>>>(s->sp, s->ctrl, u, t, s->lr, s->y, s->lr_btx_part, s->nb_n, s->lr_coef, s->lz_beta, s->partials);
