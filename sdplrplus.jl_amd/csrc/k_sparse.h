@@ -895,11 +895,19 @@ k_fast_step2(int n, int m, DevFast ff, double* __restrict__ R, double* __restric
         const long long j = j0 + i0 + u;
         for (int ch = ch0; ch < r; ch += LPR * VEC) {
           vecd<VEC> x = xx[u], pp = pq[u], d = dd[u], w = ww[u];
-          if (HMU == 0 && ch != ch0) {   // (the fused form is launched for single-chunk rows only, r ≤ LPR·VEC)
+          const unsigned offc = off[u] + (unsigned)(ch - ch0) * 8u;   // this chunk (ranks beyond LPR·VEC: several per row)
+          if (ch != ch0) {
             x = ldrow<VEC>(R + j * r + ch);
             pp = ldrow<VEC>(P + j * r + ch);
             d = ldrow<VEC>(D + j * r + ch);
             w = ldrow<VEC>(W + j * r + ch);
+            if (HMU > 0) {
+#pragma unroll
+              for (int l = 0; l < HMU; l++) {
+                sv[u][l] = ldrow_nt<VEC>(rowat(slp[l], offc));
+                yv[u][l] = ldrow_nt<VEC>(rowat(ylp[l], offc));
+              }
+            }
           }
           vecd<VEC> g;
 #pragma unroll
@@ -920,9 +928,9 @@ k_fast_step2(int n, int m, DevFast ff, double* __restrict__ R, double* __restric
             red[0] += g.v[q] * g.v[q];
           }
           if (HMU > 0) {
-            strow<VEC>(rowat(R, off[u]), x);
-            strow<VEC>(rowat(P, off[u]), pp);
-            strow<VEC>(rowat(Gout, off[u]), g);
+            strow<VEC>(rowat(R, offc), x);
+            strow<VEC>(rowat(P, offc), pp);
+            strow<VEC>(rowat(Gout, offc), g);
           } else {
             strow<VEC>(R + j * r + ch, x);
             strow<VEC>(P + j * r + ch, pp);
@@ -937,7 +945,7 @@ k_fast_step2(int n, int m, DevFast ff, double* __restrict__ R, double* __restric
               if (l == jslot) go = yv[u][l];
 #pragma unroll
             for (int q = 0; q < VEC; q++) go.v[q] = gs * go.v[q];
-            if (gold_in_G) strow<VEC>(rowat(Yj, off[u]), go);
+            if (gold_in_G) strow<VEC>(rowat(Yj, offc), go);
           }
           if (HMU > 0 && upd) {
             vecd<VEC> sn, yn;
@@ -953,8 +961,8 @@ k_fast_step2(int n, int m, DevFast ff, double* __restrict__ R, double* __restric
             }
             // dir *= α (:142) is not stored here: nothing reads the scaled direction before lbfgs_dir!
             // overwrites it, and the host copies s_j into dirt when the loop is left (sdplr_hip_inner_loop)
-            strow<VEC>(rowat(Sj, off[u]), sn);   // copy!(s_j, dir)  (:143)
-            strow<VEC>(rowat(Yj, off[u]), yn);
+            strow<VEC>(rowat(Sj, offc), sn);   // copy!(s_j, dir)  (:143)
+            strow<VEC>(rowat(Yj, offc), yn);
 #pragma unroll
             for (int l = 0; l < HMU; l++)
               if (l < h) {
@@ -977,7 +985,7 @@ k_fast_step2(int n, int m, DevFast ff, double* __restrict__ R, double* __restric
                 (void)__hip_atomic_fetch_add(ac + (4 * HMU + l) * SDPLR_NT, q4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
               }
           }
-          if (HMU > 0) break;
+          if (HMU > 0 && LPR < 64) break;   // a row is one chunk unless the sub-wave group is a whole wave (r > 64·VEC)
         }
       }
     }

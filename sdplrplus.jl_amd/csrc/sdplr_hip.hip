@@ -362,9 +362,9 @@ int build_tiles(S* s) {
   return SDPLR_OK;
 }
 
-// lbfgs_update! rides k_fast_step2 (singleton fast path) for h ≤ 4, single-chunk rows and 32-bit row offsets
+// lbfgs_update! rides k_fast_step2 (structured fast paths) for h ≤ 4 and 32-bit row offsets
 bool step_fuses_update(const S* s) {
-  return s->h >= 1 && s->h <= 4 && s->r <= (int64_t)s->LPR * s->VEC && s->n * s->r * 8 < (1LL << 32) && !s->no_updfuse;
+  return s->h >= 1 && s->h <= 4 && s->n * s->r * 8 < (1LL << 32) && !s->no_updfuse;
 }
 
 int alloc_factors(S* s) {
