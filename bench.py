@@ -12,33 +12,90 @@ h = 4, σ = σ₀ = 2 fixed, no early exit (gtol = 0, fprec = −∞), all state
 N > 1: independent replicas of the instance (graph seed + rank), one process per GPU, no data-path
 collective; RCCL only gathers the objectives at the end.  value = N·K / max-over-ranks time.
 Rank 0 prints ONE JSON line.
+
+`--gpus N` with N > 1 and no WORLD_SIZE in the environment makes THIS process a launcher: before it has
+imported torch or loaded the HIP library (it never touches the GPU) it starts
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 … bench.py --gpus N …`
+as a child, relays rank 0's JSON line and exits with the child's code.  WORLD_SIZE ≠ N is an error.
 """
 import argparse
 import json
 import os
+import socket
+import statistics
+import subprocess
 import sys
 import time
-
-import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import sdplrplus_jl_amd as sj  # noqa: E402
-from sdplrplus_jl_amd import problems  # noqa: E402
-
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured streaming)
 N_NODES, P_EDGE, RANK_R, GRAPH_SEED, R_SEED = 100_000, 2e-4, 32, 20240610, 0
+PARITY_ITERS = 5
+
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--selftest-cpu", action="store_true",
+                    help="launcher/collective self-test WITHOUT a GPU: gloo + the CPU checker on a small instance; "
+                         "exercises spawn, rendezvous, barrier, max-over-ranks and the gather — not a measurement")
+    return ap.parse_args(argv)
+
+
+def free_port() -> int:
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_children(args) -> int:
+    """The parent of an N-rank run: one fresh process per GPU through torch.distributed.run.  Nothing in this
+    process has imported torch or loaded libsdplr_hip.so, so no GPU state exists here to fork or exec over."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()),
+           os.path.abspath(__file__), "--gpus", str(args.gpus), "--steps", str(args.steps),
+           "--warmup", str(args.warmup)]
+    if args.no_cpu_baseline:
+        cmd.append("--no-cpu-baseline")
+    if args.selftest_cpu:
+        cmd.append("--selftest-cpu")
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: what RCCL needs on this driver
+    env.setdefault("OMP_NUM_THREADS", "1")
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for out in proc.stdout:                 # relay rank 0's JSON line (the only thing ranks write to stdout)
+        out = out.rstrip("\n")
+        if out.startswith("{") and '"metric"' in out:
+            line = out
+        elif out:
+            print(out, file=sys.stderr, flush=True)
+    rc = proc.wait()
+    if rc != 0:
+        print(f"bench.py: the {args.gpus}-rank run exited with code {rc}", file=sys.stderr)
+        return rc
+    if line is None:
+        print("bench.py: rank 0 printed no result line", file=sys.stderr)
+        return 1
+    print(line, flush=True)
+    return 0
 
 
 def algorithmic_bytes(d, h):
     """Compulsory bytes per launch of each kernel family and per inner iteration:
-    each distinct input read once, each output written once; 8-B values, 4-B indices."""
+    each distinct input read once, each output written once; 8-B values, 4-B indices.  A fused kernel is
+    charged the fused dataflow's own compulsory bytes (never more than the sum of the operators it fuses)."""
     n, m, r, nnzT, nnzS, nnzAgg = d["n"], d["m"], d["r"], d["nnzT"], d["nnzS"], d["nnzAgg"]
     N = 8 * n * r
     A_sparse = 4 * (n + 1) + 4 * nnzT + 12 * nnzAgg + 8 * (m + 1)
     per_kernel = {
-        "lbfgs_dir": (2 * h + 1) * N + 2 * N,
+        "lbfgs_dir": (2 * h + 1) * N + 2 * N,                        # G, s_*, y_* in; dirt, y_next out
+        "lbfgs_dir_noynext": (2 * h + 1) * N + N,                    # in-loop form when lbfgs_update! is fused: y_next not parked
         "lbfgs_update": 5 * N,
         "sddmm_linesearch": 2 * N + 4 * (n + 1) + 4 * nnzT,          # R, D rows + pattern (both 𝒜 passes fused)
         "segreduce": 2 * (8 * nnzT + 12 * nnzAgg + 8 * (m + 1)),
@@ -48,7 +105,10 @@ def algorithmic_bytes(d, h):
         "spmm": 2 * N + 4 * (n + 1) + 12 * nnzS,
         # structured fast path: W = A_g·D with the row dots riding along; the fused step
         "spmm_W": 4 * N + 4 * (n + 1) + 12 * nnzS,    # D rows (once), R, P read; W written; A_g pattern+values
-        "fast_step": 7 * N,                            # R, D, P, W read; R, P, G written (+ 5N when lbfgs_update! is fused in)
+        "fast_step": 7 * N,                            # R, D, P, W read; R, P, G written
+        # … with lbfgs_update! fused in: R, D, P, W, G_old in; R, P, G, s_j, y_j out (the other history pairs the
+        # Gram form re-reads are this design's choice, not compulsory)
+        "fast_step_upd": 10 * N,
     }
     b_iter = ((2 * h + 1) * N + 2 * N      # lbfgs_dir!
               + 2 * N                      # dot(dirt, Gt)
@@ -63,14 +123,6 @@ def algorithmic_bytes(d, h):
     return per_kernel, b_iter
 
 
-def build_instance(abi, graph_seed):
-    A = problems.gnp_graph(N_NODES, P_EDGE, graph_seed)
-    data = problems.maxcut_data(A)
-    cfg = sj.BurerMonteiroConfig(seed=R_SEED, printlevel=0)
-    var = sj.build_solver(abi, data, RANK_R, cfg)
-    return data, var
-
-
 def run_fixed(var, normC, normb, state, iters):
     """`iters` inner iterations at fixed σ with every exit test disabled except the iteration budget."""
     out = var.inner_loop(normC, normb, True, True, False, 0.0, -1e300, iters, 0.0, *state)
@@ -79,61 +131,114 @@ def run_fixed(var, normC, normb, state, iters):
     return out[:3]
 
 
-def cpu_baseline(data, budget_s=20.0):
-    """The oracle (CPU restatement, single thread — the reference's own protocol, exps/test.jl:46)
-    on the same instance: fg!, 2 warm-up iterations, then as many inner iterations as fit the budget."""
-    from oracle import oracle
+def first_iterations(sj, abi, data, r, n_iters):
+    """fg! + `n_iters` inner iterations from (R₀ seed R_SEED, λ = 0, σ₀): the state the parity field compares.
+    → (solver, [ℒ, ‖grad‖, ‖pv‖, obj])."""
+    import numpy as np
     cfg = sj.BurerMonteiroConfig(seed=R_SEED, printlevel=0)
-    o = sj.build_solver(oracle.abi(), data, RANK_R, cfg)
+    var = sj.build_solver(abi, data, r, cfg)
     normC, normb = data.normC(), float(np.linalg.norm(data.b))
-    st = o.fg(normC, normb)
-    t0 = time.perf_counter()
-    st = run_fixed(o, normC, normb, st, 2)
-    per = (time.perf_counter() - t0) / 2
-    k = int(max(3, min(200, budget_s / max(per, 1e-6))))
-    t0 = time.perf_counter()
-    run_fixed(o, normC, normb, st, k)
-    dt = time.perf_counter() - t0
-    o.close()
-    return {"value": k / dt, "unit": "iterations/s", "cores": 1, "kind": "port",
-            "sample": f"same MaxCut G(1e5,2e-4) r=32 instance, {k} inner iterations after fg! + 2 warm-up iterations"}
+    st = run_fixed(var, normC, normb, var.fg(normC, normb), n_iters)
+    return var, [st[0], st[1], st[2], var.obj]
+
+
+def cpu_baseline(sj, data, r, gpu_first, repeats=5, iters=20):
+    """The oracle (CPU restatement, kind "port") on the same instance, same host, same run: ONE thread (the
+    reference's own protocol, exps/test.jl:46) and all cores (OpenMP in its dense sweeps, SDDMM and SpMM) beside
+    it, each the median of `repeats` samples of `iters` inner iterations after fg! + the PARITY_ITERS iterations
+    whose (ℒ, ‖grad‖, obj) are compared with the GPU's — the parity evidence of this very run."""
+    import numpy as np
+    from oracle import oracle
+    one_abi, omp_abi, how, set_threads = oracle.timing_abis()
+    normC, normb = data.normC(), float(np.linalg.norm(data.b))
+    ncores = os.cpu_count() or 1
+    if hasattr(os, "sched_getaffinity"):
+        ncores = len(os.sched_getaffinity(0))
+
+    def timed(abi, threads):
+        set_threads(threads)
+        var, first = first_iterations(sj, abi, data, r, PARITY_ITERS)
+        st = first[:3]
+        rates = []
+        for _ in range(repeats):
+            t0 = time.perf_counter()
+            st = run_fixed(var, normC, normb, st, iters)
+            rates.append(iters / (time.perf_counter() - t0))
+        var.close()
+        return statistics.median(rates), first
+
+    v_all, _ = timed(omp_abi, ncores)
+    v_one, first = timed(one_abi, 1)
+    relerr = lambda a, b: abs(a - b) / max(abs(b), 1e-300)
+    parity = {"iters": PARITY_ITERS, "rel_L": relerr(gpu_first[0], first[0]), "rel_grad": relerr(gpu_first[1], first[1]),
+              "rel_pv": relerr(gpu_first[2], first[2]), "rel_obj": relerr(gpu_first[3], first[3]),
+              "tolerance": 1e-8, "against": "oracle (CPU restatement), same R0/λ0/σ0, fg! + 5 inner iterations"}
+    parity["ok"] = bool(max(parity["rel_L"], parity["rel_grad"], parity["rel_obj"]) < 1e-8)
+    sample = (f"same MaxCut G(1e5,2e-4) r={r} instance; median of {repeats} samples of {iters} inner iterations "
+              f"after fg! + {PARITY_ITERS} iterations")
+    base = {"value": v_one, "unit": "iterations/s", "cores": 1, "kind": "port", "sample": sample, "build": how,
+            "all_cores": {"value": v_all, "unit": "iterations/s", "cores": ncores, "kind": "port",
+                          "threads": "OpenMP over the dense n·r sweeps, the SDDMM and the SpMM of the oracle"}}
+    return base, parity
 
 
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
+    args = parse_args()
+    env_world = os.environ.get("WORLD_SIZE")
+    if args.gpus < 1:
+        print("bench.py: --gpus must be ≥ 1", file=sys.stderr)
+        return 2
+    if env_world is None and args.gpus > 1:
+        return launch_children(args)            # the parent never imports torch / the HIP library
+    if env_world is not None and int(env_world) != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={env_world}: launch with --nproc-per-node {args.gpus}",
+              file=sys.stderr)
+        return 2
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    world = int(env_world or "1")
     K, W = max(args.steps, 1), max(args.warmup, 1)
 
+    import numpy as np
+    import sdplrplus_jl_amd as sj
+    from sdplrplus_jl_amd import problems
+    selftest = args.selftest_cpu
     dist = None
     if world > 1 or os.environ.get("SDPLR_BENCH_FORCE_DIST"):
         # torch first: its wheel bundles a HIP runtime with the same SONAME as /opt/rocm's, and whichever is
         # loaded first serves both torch and libsdplr_hip.so — one runtime per process either way
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    abi = sj.load_hip()  # no fallback: raises if the HIP library is missing
-    if abi.set_device(local_rank) != 0:
-        raise RuntimeError((abi.last_error(None) or b"set_device failed").decode())
+        if selftest:
+            dist.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if selftest:
+        from oracle import oracle
+        abi = oracle.abi()
+        n_nodes, p_edge, rank_r = 300, 0.05, 8
+    else:
+        abi = sj.load_hip()  # no fallback: raises if the HIP library is missing
+        if abi.set_device(local_rank) != 0:
+            raise RuntimeError((abi.last_error(None) or b"set_device failed").decode())
+        n_nodes, p_edge, rank_r = N_NODES, P_EDGE, RANK_R
 
     def barrier():
         abi.device_synchronize()
         if dist is not None:
-            import torch
-            torch.cuda.synchronize()
+            if not selftest:
+                import torch
+                torch.cuda.synchronize()
             dist.barrier()
 
-    data, var = build_instance(abi, GRAPH_SEED + rank)
-    dims = var.dims()
+    data = problems.maxcut_data(problems.gnp_graph(n_nodes, p_edge, GRAPH_SEED + rank))
     normC, normb = data.normC(), float(np.linalg.norm(data.b))
+
+    # the first PARITY_ITERS iterations from R₀, kept for the comparison with the oracle's (cpu_baseline)
+    var, gpu_first = first_iterations(sj, abi, data, rank_r, PARITY_ITERS)
+    dims = var.dims()
     h = var.h
     per_kernel_bytes, b_iter = algorithmic_bytes(dims, h)
 
@@ -142,7 +247,7 @@ def main():
     # solver state, so it is repeated for ~0.4 s to get those transitions out of the way.
     state = var.fg(normC, normb)
     t_pw = time.perf_counter()
-    while time.perf_counter() - t_pw < float(os.environ.get("SDPLR_BENCH_PREWARM_S", "0.4")):
+    while not selftest and time.perf_counter() - t_pw < float(os.environ.get("SDPLR_BENCH_PREWARM_S", "0.4")):
         state = var.fg(normC, normb)
     state = run_fixed(var, normC, normb, state, W)      # warm-up steps (untimed); captures the hipGraph
 
@@ -163,13 +268,18 @@ def main():
     prof_all = var.profile()
     var.profile_enable(False)
     if prof_all.get("fast_step", (0, 0.0))[0] and not prof_all.get("lbfgs_update", (0, 0.0))[0]:
-        # lbfgs_update! rides the step kernel (k_fast_step2<…,4>): that launch is charged both operators' bytes
-        per_kernel_bytes["fast_step"] += per_kernel_bytes["lbfgs_update"]
-    dominant = max(per_kernel_bytes, key=lambda k: prof_all.get(k, (0, 0.0))[1])
+        # lbfgs_update! rides the step kernel (k_fast_step2<…,4>): charged the fused dataflow's compulsory bytes,
+        # and the in-loop direction kernel no longer parks y_next
+        per_kernel_bytes["fast_step"] = per_kernel_bytes["fast_step_upd"]
+        per_kernel_bytes["lbfgs_dir"] = per_kernel_bytes["lbfgs_dir_noynext"]
+    candidates = [k for k in per_kernel_bytes if k in prof_all]
+    dominant = max(candidates, key=lambda k: prof_all[k][1]) if candidates else "fast_step"
     launches, dom_ms = prof_all.get(dominant, (0, 0.0))
+    stats = var.stats() if hasattr(var, "stats") else {}
 
-    dt_max, objs = reduce_over_ranks(dist, dt, obj, "cuda" if dist is not None else None)
+    dt_max, objs = reduce_over_ranks(dist, dt, obj, None if (dist is None or selftest) else "cuda")
 
+    rc = 0
     if rank == 0:
         its = world * K / dt_max
         avg_s = dom_ms / max(launches, 1) / 1e3
@@ -192,6 +302,8 @@ def main():
                        "nnzS": dims["nnzS"], "numlbfgsvecs": h, "graph_seed": GRAPH_SEED},
             "hbm_GBps_per_gpu_algorithmic": b_iter * (K / dt_max) / 1e9,
             "bytes_per_iteration_algorithmic": b_iter,
+            "bytes_per_iteration_note": "SURVEY §8d: the reference's UNFUSED operator sequence (27N + sparse); "
+                                        "the fused kernels below are charged their own compulsory bytes",
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved,
                          "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                          "traffic": load_traffic(dominant),
@@ -201,14 +313,23 @@ def main():
                                    "unit": "GB/s", "frac": b_iter * (K / dt_max) / 1e9 / HBM_PEAK_GBPS},
             "kernels_eager_profile": kern,
             "objectives": objs,
+            "library_stats": stats,
         }
-        if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(data)
+        if selftest:
+            line["selftest"] = True
+            line["config"]["workload"] = (f"SELF-TEST (no GPU): MaxCut G({n_nodes},{p_edge}) r={rank_r} on the CPU "
+                                          "checker over gloo — exercises the launcher and the collectives only")
+        elif world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"], line["parity"] = cpu_baseline(sj, data, rank_r, gpu_first)
+            if not line["parity"]["ok"]:
+                print(f"bench.py: PARITY FAILED against the oracle: {line['parity']}", file=sys.stderr)
+                rc = 3
         print(json.dumps(line), flush=True)
     var.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    return rc
 
 
 def reduce_over_ranks(dist, dt, obj, device):
@@ -238,4 +359,4 @@ def load_traffic(kernel):
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

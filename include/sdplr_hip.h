@@ -50,6 +50,10 @@ typedef struct sdplr_hip_solver sdplr_hip_solver; /* opaque handle ("HIPAux" + d
 #define SDPLR_F_DIRT 2        /* dirt     src/sdplr.jl:174                                    */
 #define SDPLR_F_LBFGS_S 100   /* + j, j = 0..h-1: lbfgshis.vecs[j+1].s   src/lbfgs.jl:9       */
 #define SDPLR_F_LBFGS_Y 200   /* + j, j = 0..h-1: lbfgshis.vecs[j+1].y   src/lbfgs.jl:11      */
+#define SDPLR_F_SCRATCH 300   /* + k, k = 0,1: two factor-shaped scratch arrays (allocated on first use) for
+                                 operator calls on arrays that are not solver state: the Ut / Vt / x / y
+                                 arguments of 𝒜!(out, aux, Ut[, Vt]) and 𝒜t!(y, x, aux, var) when a caller
+                                 hands in its own matrices (src/coreop.jl:36,54,260)                   */
 
 /* ---- vector slots (src/structs.jl:197-222) ---------------------------------------------------- */
 #define SDPLR_V_LAMBDA 0      /* λ              m                                            */
@@ -66,6 +70,7 @@ typedef struct sdplr_hip_solver sdplr_hip_solver; /* opaque handle ("HIPAux" + d
 #define SDPLR_V_UVT 11        /* aux.UVt        nnzT (src/structs.jl:288)                    */
 #define SDPLR_V_TRIU_S_NZVAL 12 /* aux.triu_sparse_S.nzval  nnzT                             */
 #define SDPLR_V_S_NZVAL 13    /* aux.sparse_S.nzval         nnzS                             */
+#define SDPLR_V_SCRATCH 14    /* m+1: scratch output of 𝒜! for callers' own `out` vectors     */
 
 /* ---- scalar slots ------------------------------------------------------------------------- */
 #define SDPLR_S_SIGMA 0        /* var.σ[]   src/structs.jl:204                                 */
@@ -143,6 +148,10 @@ int32_t sdplr_hip_At_left(sdplr_hip_solver* s, int32_t y_slot, int32_t x_slot);
 /* 𝒜t!(y, aux, x, var)  src/coreop.jl:281-300: y = S·x + Σ coeff·B·D·Bᵀ·x; x, y are n×k
  * column-major HOST arrays (the Lanczos path keeps its vectors on the device, see below).      */
 int32_t sdplr_hip_At_right(sdplr_hip_solver* s, const double* x_host, double* y_host, int64_t k);
+/* The same product on DEVICE vectors (x_dev, y_dev: n×k column-major in this GPU's memory, e.g. a ROCArray /
+ * torch tensor; must not alias): nothing crosses PCIe.  Runs on the handle's stream and returns when y is
+ * complete.  What an eigensolver living on the device calls (SDP_S_eigval's operator, src/coreop.jl:363-366). */
+int32_t sdplr_hip_At_right_device(sdplr_hip_solver* s, const double* x_dev, double* y_dev, int64_t k);
 
 /* ---- Lagrangian value / gradient ----------------------------------------------------------- */
 /* f!(data, var, aux)  src/coreop.jl:11-31 */
@@ -216,6 +225,14 @@ int32_t sdplr_hip_approx_mineigval_lanczos(sdplr_hip_solver* s, int64_t q, const
  * q = 2⌈√max(iter,100)·ln n⌉ :402)                                                             */
 int32_t sdplr_hip_dual_obj(sdplr_hip_solver* s, double trace_bound, int64_t iter,
                            const double* v0, double* dual_value, double* mineig);
+
+/* ---- library counters ------------------------------------------------------------------------------
+ * out[0] hipGraph captures that succeeded, out[1] captures that FAILED (this handle then launches eagerly for
+ * good — visible here, never silent), out[2] captures skipped because the process-wide capture lock was busy
+ * (that call ran eagerly; the next one tries again), out[3] inner-loop batches replayed from a graph,
+ * out[4] inner-loop batches launched eagerly, out[5] Lanczos graph replays, out[6] Lanczos rounds launched
+ * eagerly, out[7] inner iterations run.  Writes min(cap, 8) entries, *n_written says how many.            */
+int32_t sdplr_hip_get_stats(const sdplr_hip_solver* s, int64_t* out, int32_t cap, int32_t* n_written);
 
 /* ---- per-kernel device timing (hipEvent pairs on the handle's stream) ------------------------ */
 int32_t sdplr_hip_profile_enable(sdplr_hip_solver* s, int32_t on); /* also resets the counters */

@@ -15,11 +15,45 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB = os.path.join(HERE, "libsdplr_oracle.so")
 
 
+LIB_OMP = os.path.join(HERE, "libsdplr_oracle_omp.so")
+
+
 def build(force: bool = False) -> str:
     src = os.path.join(HERE, "sdplr_oracle.c")
-    if force or not os.path.exists(LIB) or os.path.getmtime(LIB) < os.path.getmtime(src):
-        subprocess.check_call(["make", "-C", HERE, "-s"])
+    stale = lambda lib: not os.path.exists(lib) or os.path.getmtime(lib) < os.path.getmtime(src)
+    if force or stale(LIB) or stale(LIB_OMP):
+        subprocess.check_call(["make", "-C", HERE, "-s"] + (["-B"] if force else []))
     return LIB
+
+
+def timing_abis(scratch: str = None):
+    """The two builds bench.py's cpu_baseline times: (one-thread ABI, all-cores OpenMP ABI, how they were
+    built, set_threads(k) for the OpenMP build).  When a C compiler is present on the box that runs the bench, both are rebuilt there with
+    -march=native into a scratch directory; otherwise the prebuilt generic-x86-64 libraries that
+    travelled with the snapshot are used and the returned note says so."""
+    import shutil
+    import tempfile
+    import sdplrplus_jl_amd as sj
+    note = "prebuilt, -O3 generic x86-64 (no compiler on this box)"
+    one, omp = LIB, LIB_OMP
+    if shutil.which(os.environ.get("CC", "gcc")) and shutil.which("make"):
+        out = scratch or tempfile.mkdtemp(prefix="sdplr_oracle_native_")
+        try:
+            subprocess.check_call(["make", "-C", HERE, "-s", "-B", "native", f"OUT={out}"],
+                                  stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            one, omp = os.path.join(out, "libsdplr_oracle_1t.so"), os.path.join(out, "libsdplr_oracle_omp.so")
+            note = "built on this box, gcc -O3 -march=native"
+        except (subprocess.CalledProcessError, OSError):
+            pass
+    if not os.path.exists(omp):
+        build()
+    one_abi, omp_abi = sj.CABI(one, "sdplr_oracle_"), sj.CABI(omp, "sdplr_oracle_")
+    gomp = C.CDLL("libgomp.so.1")          # already mapped as a dependency of the OpenMP build: same handle
+    gomp.omp_set_num_threads.argtypes = [C.c_int]
+
+    def set_threads(k: int):
+        gomp.omp_set_num_threads(int(k))
+    return one_abi, omp_abi, note, set_threads
 
 
 class _Layout(C.Structure):

@@ -1,7 +1,7 @@
 /*
  * sdplr_oracle.c — TEST INFRASTRUCTURE, NOT PRODUCT.  See sdplr_oracle.h for scope and pinning.
  *
- * Plain C99, single-threaded, FP64, no BLAS: a CPU restatement of the reference's numeric hot path,
+ * Plain C99, single-threaded (see the note on the inert OpenMP pragmas at ddot), FP64, no BLAS: a CPU restatement of the reference's numeric hot path,
  * function by function, each citing the reference file:line it follows.  Deliberately written as
  * the obvious loops (the reference's own structure), not as an optimised implementation.
  */
@@ -26,6 +26,7 @@
 #define F_DIRT 2
 #define F_LBFGS_S 100
 #define F_LBFGS_Y 200
+#define F_SCRATCH 300
 
 #define V_LAMBDA 0
 #define V_LAMBDA_UB 1
@@ -41,6 +42,7 @@
 #define V_UVT 11
 #define V_TRIU_S_NZVAL 12
 #define V_S_NZVAL 13
+#define V_SCRATCH 14
 
 #define S_SIGMA 0
 #define S_OBJ 1
@@ -76,6 +78,8 @@ struct sdplr_oracle_solver {
   double *rho, *a;
   int64_t latest; /* 1-based, as in the reference */
   char err[256];
+  double* scratchF[2]; /* F_SCRATCH + k, allocated on first use */
+  double* scratchV;    /* V_SCRATCH, m+1 */
 };
 typedef struct sdplr_oracle_solver S;
 
@@ -195,6 +199,9 @@ static void free_factors(S* s) {
   }
   free(s->hs);
   free(s->hy);
+  free(s->scratchF[0]);
+  free(s->scratchF[1]);
+  s->scratchF[0] = s->scratchF[1] = NULL;
   s->Rt = s->Gt = s->dirt = NULL;
   s->hs = s->hy = NULL;
 }
@@ -255,7 +262,7 @@ int32_t sdplr_oracle_destroy(S* s) {
   for (int64_t t = 0; t < s->n_lr; t++) { free(s->lr[t].B); free(s->lr[t].D); }
   free(s->lr);
   free(s->lambda); free(s->lambda_ub); free(s->b); free(s->y); free(s->pv_raw); free(s->pv_lb);
-  free(s->pv); free(s->A_RD); free(s->A_DD); free(s->rho); free(s->a);
+  free(s->pv); free(s->A_RD); free(s->A_DD); free(s->rho); free(s->a); free(s->scratchV);
   free(s);
   return OK;
 }
@@ -286,6 +293,10 @@ static double* factor_ptr(S* s, int32_t slot) {
   if (slot == F_DIRT) return s->dirt;
   if (slot >= F_LBFGS_S && slot < F_LBFGS_S + s->h) return s->hs[slot - F_LBFGS_S];
   if (slot >= F_LBFGS_Y && slot < F_LBFGS_Y + s->h) return s->hy[slot - F_LBFGS_Y];
+  if (slot == F_SCRATCH || slot == F_SCRATCH + 1) {
+    if (!s->scratchF[slot - F_SCRATCH]) s->scratchF[slot - F_SCRATCH] = dalloc(s->n * s->r);
+    return s->scratchF[slot - F_SCRATCH];
+  }
   return NULL;
 }
 static double* vec_ptr(S* s, int32_t which, int64_t* len) {
@@ -305,6 +316,10 @@ static double* vec_ptr(S* s, int32_t which, int64_t* len) {
     case V_UVT: *len = s->nnzT; return s->UVt;
     case V_TRIU_S_NZVAL: *len = s->nnzT; return s->triu_nzval;
     case V_S_NZVAL: *len = s->nnzS; return s->nzval;
+    case V_SCRATCH:
+      *len = m + 1;
+      if (!s->scratchV) s->scratchV = dalloc(m + 1);
+      return s->scratchV;
     default: *len = 0; return NULL;
   }
 }
@@ -371,16 +386,33 @@ int32_t sdplr_oracle_get_dims(const S* s, int64_t* n, int64_t* m, int64_t* r, in
 }
 
 /* ---- BLAS-1 as plain loops ------------------------------------------------------------------ */
+/* The `#pragma omp` lines below are inert in the checker build (libsdplr_oracle.so is compiled WITHOUT
+ * -fopenmp: one thread, the reference's own protocol, exps/test.jl:46).  They only take effect in the
+ * separate all-cores timing build (make omp → libsdplr_oracle_omp.so) that bench.py's cpu_baseline
+ * reports beside the one-thread number; tests/test_oracle_omp.py checks that build
+ * against this one. */
 static double ddot(int64_t N, const double* x, const double* y) {
   double acc = 0.0;
+#pragma omp parallel for reduction(+ : acc) schedule(static) if (N > 65536)
   for (int64_t i = 0; i < N; i++) acc += x[i] * y[i];
   return acc;
 }
 static void daxpy(int64_t N, double a, const double* x, double* y) {
+#pragma omp parallel for schedule(static) if (N > 65536)
   for (int64_t i = 0; i < N; i++) y[i] += a * x[i];
 }
 static void dscal(int64_t N, double a, double* x) {
+#pragma omp parallel for schedule(static) if (N > 65536)
   for (int64_t i = 0; i < N; i++) x[i] *= a;
+}
+/* copyto! of a factor-shaped array (a memcpy in the one-thread build) */
+static void dcopy(int64_t N, const double* x, double* y) {
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static) if (N > 65536)
+  for (int64_t i = 0; i < N; i++) y[i] = x[i];
+#else
+  memcpy(y, x, (size_t)N * sizeof(double));
+#endif
 }
 static double dnrm2(int64_t N, const double* x) { return sqrt(ddot(N, x, x)); }
 
@@ -404,6 +436,7 @@ static double mydot2(const double* Ut, const double* Vt, int64_t r, int64_t row,
 /* 𝒜_sparse_formUUt!  src/coreop.jl:174-186 */
 static void A_sparse_formUUt(S* s, const double* Ut) {
   memset(s->UVt, 0, (size_t)s->nnzT * sizeof(double));
+#pragma omp parallel for schedule(dynamic, 512)
   for (int64_t col = 0; col < s->n; col++)
     for (int64_t nzi = s->triu_colptr[col]; nzi < s->triu_colptr[col + 1]; nzi++) {
       int64_t row = s->triu_rowval[nzi];
@@ -413,6 +446,7 @@ static void A_sparse_formUUt(S* s, const double* Ut) {
 /* 𝒜_sparse_formUVt!  src/coreop.jl:188-203 */
 static void A_sparse_formUVt(S* s, const double* Ut, const double* Vt) {
   memset(s->UVt, 0, (size_t)s->nnzT * sizeof(double));
+#pragma omp parallel for schedule(dynamic, 512)
   for (int64_t col = 0; col < s->n; col++)
     for (int64_t nzi = s->triu_colptr[col]; nzi < s->triu_colptr[col + 1]; nzi++) {
       int64_t row = s->triu_rowval[nzi];
@@ -422,6 +456,7 @@ static void A_sparse_formUVt(S* s, const double* Ut, const double* Vt) {
 /* the `UUt' * SparseMatrixCSC(nnzT, n_sparse, matptr, nzind, nzval_two)` product and scatter,
  * src/coreop.jl:80-90 / :102-112 */
 static void A_sparse_reduce(S* s, double* out) {
+#pragma omp parallel for schedule(dynamic, 1024)
   for (int64_t k = 0; k < s->n_sparse; k++) {
     double v = 0.0;
     for (int64_t e = s->matptr[k]; e < s->matptr[k + 1]; e++) v += s->UVt[s->nzind[e]] * s->nzval_two[e];
@@ -465,7 +500,9 @@ int32_t sdplr_oracle_A(S* s, int32_t u_slot, int32_t v_slot, int32_t out_vec) {
   double* U = factor_ptr(s, u_slot);
   double* V = v_slot >= 0 ? factor_ptr(s, v_slot) : NULL;
   if (!U || (v_slot >= 0 && !V)) return fail(s, ERR_INVALID, "A: bad factor slot");
-  double* out = out_vec == V_PV_RAW ? s->pv_raw : out_vec == V_A_RD ? s->A_RD : out_vec == V_A_DD ? s->A_DD : NULL;
+  int64_t olen;
+  double* out = out_vec == V_PV_RAW ? s->pv_raw : out_vec == V_A_RD ? s->A_RD : out_vec == V_A_DD ? s->A_DD :
+                out_vec == V_SCRATCH ? vec_ptr(s, V_SCRATCH, &olen) : NULL;
   if (!out) return fail(s, ERR_INVALID, "A: bad output vector");
   A_op(s, out, U, V);
   return OK;
@@ -482,6 +519,7 @@ static void At_preprocess(S* s) {
     double v = s->y[s->gids[k]];
     for (int64_t e = s->matptr[k]; e < s->matptr[k + 1]; e++) s->triu_nzval[s->nzind[e]] += s->nzval_one[e] * v;
   }
+#pragma omp parallel for schedule(static)
   for (int64_t i = 0; i < s->nnzS; i++) s->nzval[i] = s->triu_nzval[s->mapped[i]];
 }
 int32_t sdplr_oracle_At_preprocess(S* s) {
@@ -495,6 +533,7 @@ static void At_left(S* s, double* y, const double* x) {
   int64_t n = s->n, r = s->r;
   memset(y, 0, (size_t)(n * r) * sizeof(double));
   if (s->n_sparse > 0)
+#pragma omp parallel for schedule(dynamic, 512)
     for (int64_t j = 0; j < n; j++)
       for (int64_t p = s->colptr[j]; p < s->colptr[j + 1]; p++) {
         double v = s->nzval[p];
@@ -553,6 +592,16 @@ int32_t sdplr_oracle_At_right(S* s, const double* x, double* y, int64_t k) {
   NEED_FINAL(s);
   if (!x || !y || k < 1) return fail(s, ERR_INVALID, "At_right: bad args");
   At_right(s, y, x, k);
+  return OK;
+}
+int32_t sdplr_oracle_At_right_device(S* s, const double* x, double* y, int64_t k) {
+  return sdplr_oracle_At_right(s, x, y, k); /* the oracle's "device" memory is host memory */
+}
+int32_t sdplr_oracle_get_stats(const S* s, int64_t* out, int32_t cap, int32_t* n_written) {
+  if (!s || !out || cap < 0) return ERR_INVALID;
+  int32_t k = cap < 8 ? cap : 8;
+  for (int32_t i = 0; i < k; i++) out[i] = 0;
+  if (n_written) *n_written = k;
   return OK;
 }
 
@@ -656,7 +705,7 @@ int32_t sdplr_oracle_lbfgs_clear(S* s) {
 static void lbfgs_dir(S* s, int negate) {
   int64_t N = s->n * s->r, m = s->h, lst = s->latest;
   double *dir = s->dirt, *grad = s->Gt;
-  memcpy(dir, grad, (size_t)N * sizeof(double));
+  dcopy(N, grad, dir);
   if (m == 0) return;
   int64_t j = lst;
   for (int64_t it = 0; it < m; it++) {
@@ -676,7 +725,7 @@ static void lbfgs_dir(S* s, int negate) {
   }
   if (negate) dscal(N, -1.0, dir);
   j = s->latest % m + 1;
-  memcpy(s->hy[j - 1], grad, (size_t)N * sizeof(double));
+  dcopy(N, grad, s->hy[j - 1]);
   dscal(N, -1.0, s->hy[j - 1]);
 }
 int32_t sdplr_oracle_lbfgs_dir(S* s, int32_t negate, double* descent) {
@@ -690,7 +739,7 @@ int32_t sdplr_oracle_descent_fallback(S* s) {
   NEED_FINAL(s);
   int64_t N = s->n * s->r;
   dscal(N, -1.0, s->Gt);
-  memcpy(s->dirt, s->Gt, (size_t)N * sizeof(double));
+  dcopy(N, s->Gt, s->dirt);
   return OK;
 }
 /* lbfgs_update! src/lbfgs.jl:129-149 */
@@ -699,7 +748,7 @@ static void lbfgs_update(S* s, double stepsize) {
   int64_t N = s->n * s->r;
   int64_t j = s->latest % s->h + 1;
   dscal(N, stepsize, s->dirt);
-  memcpy(s->hs[j - 1], s->dirt, (size_t)N * sizeof(double));
+  dcopy(N, s->dirt, s->hs[j - 1]);
   daxpy(N, 1.0, s->Gt, s->hy[j - 1]);
   s->rho[j - 1] = 1 / ddot(N, s->hy[j - 1], s->hs[j - 1]);
   s->latest = j;
@@ -900,7 +949,7 @@ int32_t sdplr_oracle_inner_loop(S* s, double normC, double normb, int32_t grel, 
     double descent = ddot(N, s->dirt, s->Gt);         /* :201 */
     if (isnan(descent) || descent >= 0) {             /* :202-205 */
       dscal(N, -1.0, s->Gt);
-      memcpy(s->dirt, s->Gt, (size_t)N * sizeof(double));
+      dcopy(N, s->Gt, s->dirt);
     }
     double lastval = L;                               /* :207 */
     int rc = use_armijo ? linesearch_armijo(s, 1.0, &alpha, &L) : linesearch(s, 1.0, &alpha, &L);

@@ -66,6 +66,10 @@ int32_t sdplr_oracle_At_preprocess(sdplr_oracle_solver* s);
 int32_t sdplr_oracle_At_left(sdplr_oracle_solver* s, int32_t y_slot, int32_t x_slot);
 int32_t sdplr_oracle_At_right(sdplr_oracle_solver* s, const double* x_host, double* y_host,
                               int64_t k);
+int32_t sdplr_oracle_At_right_device(sdplr_oracle_solver* s, const double* x_dev, double* y_dev,
+                                     int64_t k); /* the oracle's "device" is host memory */
+int32_t sdplr_oracle_get_stats(const sdplr_oracle_solver* s, int64_t* out, int32_t cap,
+                               int32_t* n_written); /* all zero: no graphs here */
 int32_t sdplr_oracle_f(sdplr_oracle_solver* s, double* lagrangian);
 int32_t sdplr_oracle_g(sdplr_oracle_solver* s);
 int32_t sdplr_oracle_fg(sdplr_oracle_solver* s, double normC, double normb,

@@ -22,9 +22,11 @@ ERR_STATE = -4
 ERR_NO_DEVICE = -5
 ERR_ALLOC = -6
 
-F_RT, F_GT, F_DIRT, F_LBFGS_S, F_LBFGS_Y = 0, 1, 2, 100, 200
+F_RT, F_GT, F_DIRT, F_LBFGS_S, F_LBFGS_Y, F_SCRATCH = 0, 1, 2, 100, 200, 300
 (V_LAMBDA, V_LAMBDA_UB, V_B, V_Y, V_PV_RAW, V_PV_LB, V_PV, V_A_RD, V_A_DD, V_LBFGS_RHO, V_LBFGS_A,
- V_UVT, V_TRIU_S_NZVAL, V_S_NZVAL) = range(14)
+ V_UVT, V_TRIU_S_NZVAL, V_S_NZVAL, V_SCRATCH) = range(15)
+STAT_NAMES = ("graph_captures", "graph_capture_failures", "graph_capture_skipped", "graph_batches",
+              "eager_batches", "lanczos_graph_replays", "lanczos_eager_rounds", "inner_iterations")
 S_SIGMA, S_OBJ, S_LBFGS_LATEST = 0, 1, 2
 
 _i32, _i64, _f64, _vp = C.c_int32, C.c_int64, C.c_double, C.c_void_p
@@ -56,6 +58,8 @@ SIGNATURES = {
     "At_preprocess": [_vp],
     "At_left": [_vp, _i32, _i32],
     "At_right": [_vp, _pf64, _pf64, _i64],
+    "At_right_device": [_vp, _vp, _vp, _i64],
+    "get_stats": [_vp, _pi64, _i32, _pi32],
     "f": [_vp, _pf64],
     "g": [_vp],
     "fg": [_vp, _f64, _f64, _i32, _i32, _pf64, _pf64, _pf64],
@@ -227,7 +231,7 @@ class DeviceSolver:
         m = self.m
         return {V_LAMBDA: m, V_LAMBDA_UB: m, V_B: m, V_Y: m + 1, V_PV_RAW: m + 1, V_PV_LB: m,
                 V_PV: m, V_A_RD: m + 1, V_A_DD: m + 1, V_LBFGS_RHO: self.h, V_LBFGS_A: self.h,
-                V_UVT: d["nnzT"], V_TRIU_S_NZVAL: d["nnzT"], V_S_NZVAL: d["nnzS"]}[which]
+                V_UVT: d["nnzT"], V_TRIU_S_NZVAL: d["nnzT"], V_S_NZVAL: d["nnzS"], V_SCRATCH: m + 1}[which]
 
     def set_vec(self, which: int, v):
         v = _f64c(v)
@@ -283,6 +287,25 @@ class DeviceSolver:
         yf = np.empty((self.n, k), dtype=np.float64, order="F")
         self._ck(self.abi.At_right(self._h, xf.ctypes.data_as(_pf64), yf.ctypes.data_as(_pf64), k))
         return yf.reshape(x.shape)
+
+    def At_right_device(self, x_ptr: int, y_ptr: int, k: int = 1):
+        """𝒜t!(y, aux, x, var) on device vectors given as raw device addresses (e.g. ``tensor.data_ptr()``)."""
+        self._ck(self.abi.At_right_device(self._h, _vp(x_ptr), _vp(y_ptr), int(k)))
+
+    def A_of(self, Ut: np.ndarray, Vt: Optional[np.ndarray] = None) -> np.ndarray:
+        """𝒜!(out, aux, Ut[, Vt]) on the caller's own matrices (not solver state), through the scratch slots."""
+        self.set_factor(F_SCRATCH, Ut)
+        if Vt is not None:
+            self.set_factor(F_SCRATCH + 1, Vt)
+        self.A(F_SCRATCH, F_SCRATCH + 1 if Vt is not None else -1, V_SCRATCH)
+        return self.get_vec(V_SCRATCH)
+
+    def stats(self) -> dict:
+        """Library counters (include/sdplr_hip.h, sdplr_hip_get_stats)."""
+        out = (C.c_int64 * 8)()
+        k = C.c_int32(0)
+        self._ck(self.abi.get_stats(self._h, out, 8, C.byref(k)))
+        return {STAT_NAMES[i]: int(out[i]) for i in range(k.value)}
 
     def f(self) -> float:
         """f!(data, var, aux)  src/coreop.jl:11-31."""

@@ -1128,7 +1128,7 @@ k_spmm_fast(DevSparse sg, int m, DevFast ff, const double* __restrict__ R, const
 
 // ---- column-sweep form of k_spmm_fast --------------------------------------------------------------------
 // A sub-wave group owns a tile of K consecutive rows.  The tile's nonzeros are stored sorted by COLUMN
-// (entry = local row << 27 | column, value), so every group walks its list from column 0 to column n−1, and
+// (entry = local row << SDPLR_TILE_COLBITS | column, value), so every group walks its list from column 0 to column n−1, and
 // since the lists are equally long on average all the groups resident on the chip read the same narrow band
 // of D at the same time: the band lives in the XCD's 4 MiB L2 instead of each row gather going out to the
 // Infinity Cache (a uniformly random gather keeps only 4 MiB / |D| of its rows in L2).  The K partial rows
@@ -1144,7 +1144,7 @@ struct DevTile {
   int K, n_tiles;        // K = most rows in any tile
   const int* row0;       // [n_tiles + 1] first row of each tile
   const int* ptr;        // [n_tiles + 1]
-  const int* ent;        // local row << 27 | column
+  const int* ent;        // local row << SDPLR_TILE_COLBITS (24) | column
   const double* val;
 };
 

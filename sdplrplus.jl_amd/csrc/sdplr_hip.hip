@@ -29,11 +29,20 @@ namespace {
 std::string g_err;
 // ROCm 7.2: while one host thread records a hipGraph, HIP calls made by OTHER threads fail ("operation
 // failed due to a previous error during capture", any capture mode).  Every entry point therefore holds
-// this lock shared; a capture takes it exclusively.
-std::shared_mutex g_api_rw;
+// this lock shared; a capture takes it exclusively — but only if it gets it within a bounded wait
+// (SDPLR_HIP_CAPTURE_WAIT_MS, default 50): other handles' inner loops hold the lock shared for up to their whole
+// time budget, and glibc's rwlock prefers readers, so an unbounded wait could starve.  A capture that cannot
+// get the lock is skipped: that call launches eagerly (same kernels, same results) and the next call tries again.
+using ApiMutex = std::shared_timed_mutex;
+using ApiLock = std::shared_lock<ApiMutex>;
+ApiMutex g_api_rw;
 struct ApiShared {
-  std::shared_lock<std::shared_mutex> l{g_api_rw};
+  ApiLock l{g_api_rw};
 };
+int capture_wait_ms() {
+  static const int ms = getenv("SDPLR_HIP_CAPTURE_WAIT_MS") ? std::max(0, atoi(getenv("SDPLR_HIP_CAPTURE_WAIT_MS"))) : 50;
+  return ms;
+}
 
 struct LowRankHost {
   int64_t gid, s;
@@ -114,6 +123,13 @@ struct sdplr_hip_solver {
 
   // Gram bookkeeping (see k_dense.h)
   bool gram_dirty = false, sg_stale = false, ynext_pending = false;
+
+  // scratch arrays for operator calls on the caller's own matrices / vectors (SDPLR_F_SCRATCH, SDPLR_V_SCRATCH)
+  double* scratchF[2] = {nullptr, nullptr};
+  double* scratchV = nullptr;
+  // counters (sdplr_hip_get_stats)
+  int64_t st_captures = 0, st_capture_failed = 0, st_capture_skipped = 0, st_graph_batches = 0,
+          st_eager_batches = 0, st_lz_graph = 0, st_lz_eager = 0, st_iters = 0;
 
   // profiling
   bool prof_on = false;
@@ -252,7 +268,19 @@ int blocks_for(long long work, int per_block, int cap) {
   return (int)b;
 }
 
+// release one tracked allocation
+void dfree(S* s, void* p) {
+  if (!p) return;
+  (void)hipFree(p);
+  s->allocs.erase(std::remove(s->allocs.begin(), s->allocs.end(), p), s->allocs.end());
+}
+
 double* factor_ptr(S* s, int32_t slot) {
+  if (slot == SDPLR_F_SCRATCH || slot == SDPLR_F_SCRATCH + 1) {
+    double*& p = s->scratchF[slot - SDPLR_F_SCRATCH];
+    if (!p && dzero(s, &p, (size_t)s->N) != SDPLR_OK) return nullptr;
+    return p;
+  }
   if (slot == SDPLR_F_RT) return aslot(s->arena, AS_R);
   if (slot == SDPLR_F_GT) return aslot(s->arena, AS_G);
   if (slot == SDPLR_F_DIRT) return aslot(s->arena, AS_D);
@@ -262,7 +290,7 @@ double* factor_ptr(S* s, int32_t slot) {
 }
 void note_factor_written(S* s, int32_t slot) {
   if (slot == SDPLR_F_GT) s->sg_stale = true;
-  if (slot >= SDPLR_F_LBFGS_S) s->gram_dirty = true;
+  if (slot >= SDPLR_F_LBFGS_S && slot < SDPLR_F_SCRATCH) s->gram_dirty = true;
 }
 
 // sub-wave shape for a given rank: VEC doubles per lane, LPR lanes per row (power of two ≤ 64)
@@ -802,6 +830,8 @@ int32_t sdplr_hip_reset_rank(S* s, int64_t new_r) {
   s->arena.base = nullptr;
   for (int k = 0; k < 2; k++)
     if (s->graph_exec[k]) { (void)hipGraphExecDestroy(s->graph_exec[k]); s->graph_exec[k] = nullptr; }
+  // everything sized by the rank is released before it is re-allocated (the graphs above hold their pointers)
+  for (double** p : {&s->lr_part, &s->lr_W, &s->lr_WS, &s->scratchF[0], &s->scratchF[1]}) { dfree(s, *p); *p = nullptr; }
   s->r = new_r;
   int rc = s->fast ? build_tiles(s) : SDPLR_OK;
   if (rc) return rc;
@@ -866,6 +896,10 @@ double* vec_ptr(S* s, int32_t which, int64_t* len, bool* in_ctrl) {
     case SDPLR_V_UVT: *len = s->nnzT; return s->sp.UVt0;
     case SDPLR_V_TRIU_S_NZVAL: *len = s->nnzT; return s->sp.triu_nzval;
     case SDPLR_V_S_NZVAL: *len = s->nnzS; return s->sp.nzval;
+    case SDPLR_V_SCRATCH:
+      *len = m + 1;
+      if (!s->scratchV && dzero(s, &s->scratchV, (size_t)m + 1) != SDPLR_OK) *len = -1;
+      return s->scratchV;
     default: *len = -1; return nullptr;
   }
 }
@@ -1405,6 +1439,20 @@ int run_lanczos_classic(S* s, int64_t q, const double* v0, double* alpha, double
   return SDPLR_OK;
 }
 
+// A hipGraph capture failed (not: was skipped): the handle launches eagerly from now on.  Never silent — counted
+// (sdplr_hip_get_stats out[1]), kept in last_error, and printed once per process.
+void note_capture_failure(S* s, const char* what) {
+  const hipError_t e = hipGetLastError();
+  s->graph_disabled = true;
+  s->st_capture_failed++;
+  s->err = std::string("hipGraph capture failed (") + what + "): " + hipGetErrorString(e) + " — eager launches from now on";
+  static bool said = false;
+  if (!said) {
+    said = true;
+    fprintf(stderr, "[sdplr_hip] warning: %s\n", s->err.c_str());
+  }
+}
+
 // one Lanczos step = k_lz_spmv (+ hub rows) + k_lz_step on the buffer triple (uprev, u, t)
 void enq_lz_step(S* s, double* uprev, double* u, double* t) {
   const int* stop = &s->ctrl->lz_done;
@@ -1427,7 +1475,7 @@ void enq_lz_step(S* s, double* uprev, double* u, double* t) {
 
 // approx_mineigval_lanczos's recurrence, src/coreop.jl:461-500 (see k_sparse.h "Lanczos recurrence")
 int run_lanczos(S* s, int64_t q, const double* v0, double* alpha, double* beta, int64_t* steps,
-                std::shared_lock<std::shared_mutex>* api_lock) {
+                ApiLock* api_lock) {
   const int64_t n = s->n;
   if (s->lr.ST > SDPLR_LRMAX || getenv("SDPLR_HIP_CLASSIC_LANCZOS") != nullptr)
     return run_lanczos_classic(s, q, v0, alpha, beta, steps);
@@ -1466,29 +1514,35 @@ int run_lanczos(S* s, int64_t q, const double* v0, double* alpha, double* beta, 
   if (use_graph && !s->lz_graph && api_lock) {
     api_lock->unlock();
     {
-      std::unique_lock<std::shared_mutex> excl(g_api_rw);
-      hipGraph_t graph = nullptr;
-      bool ok = hipStreamBeginCapture(s->stream, hipStreamCaptureModeRelaxed) == hipSuccess;
-      if (ok) {
-        for (int t = 0; t < reps; t++) three();
-        ok = hipStreamEndCapture(s->stream, &graph) == hipSuccess && graph != nullptr;
-      }
-      if (ok) ok = hipGraphInstantiate(&s->lz_graph, graph, nullptr, nullptr, 0) == hipSuccess;
-      s->lz_graph_reps = reps;
-      if (graph) (void)hipGraphDestroy(graph);
-      if (!ok) {
-        (void)hipGetLastError();
-        s->lz_graph = nullptr;
-        s->graph_disabled = true;
+      std::unique_lock<ApiMutex> excl(g_api_rw, std::chrono::milliseconds(capture_wait_ms()));
+      if (!excl.owns_lock()) {
+        s->st_capture_skipped++;   // busy: this call launches eagerly, the next one tries again
+      } else {
+        hipGraph_t graph = nullptr;
+        bool ok = hipStreamBeginCapture(s->stream, hipStreamCaptureModeRelaxed) == hipSuccess;
+        if (ok) {
+          for (int t = 0; t < reps; t++) three();
+          ok = hipStreamEndCapture(s->stream, &graph) == hipSuccess && graph != nullptr;
+        }
+        if (ok) ok = hipGraphInstantiate(&s->lz_graph, graph, nullptr, nullptr, 0) == hipSuccess;
+        s->lz_graph_reps = reps;
+        if (graph) (void)hipGraphDestroy(graph);
+        if (ok) {
+          s->st_captures++;
+        } else {
+          note_capture_failure(s, "Lanczos");
+          s->lz_graph = nullptr;
+        }
       }
     }
     api_lock->lock();
   }
   if (!s->lz_graph) use_graph = false;
   if (use_graph) {
-    for (int64_t k = 0; k < rounds; k += reps) HIPCK(s, hipGraphLaunch(s->lz_graph, s->stream));
+    for (int64_t k = 0; k < rounds; k += reps) { HIPCK(s, hipGraphLaunch(s->lz_graph, s->stream)); s->st_lz_graph++; }
   } else {
     for (int64_t k = 0; k < rounds; k++) three();
+    s->st_lz_eager += rounds;
   }
   HIPCK(s, hipGetLastError());
   HIPCK(s, hipMemcpyAsync(alpha, s->lz_alpha, q * sizeof(double), hipMemcpyDeviceToHost, s->stream));
@@ -1512,6 +1566,10 @@ int32_t sdplr_hip_A(S* s, int32_t u_slot, int32_t v_slot, int32_t out_vec) {
   double* V = v_slot >= 0 ? factor_ptr(s, v_slot) : nullptr;
   if (!U || (v_slot >= 0 && !V)) return fail(s, SDPLR_ERR_INVALID_ARG, "A: bad factor slot");
   double* out = out_vec == SDPLR_V_PV_RAW ? s->pv_raw : out_vec == SDPLR_V_A_RD ? s->A_RD : out_vec == SDPLR_V_A_DD ? s->A_DD : nullptr;
+  if (out_vec == SDPLR_V_SCRATCH) {
+    int64_t L; bool in_ctrl;
+    out = vec_ptr(s, SDPLR_V_SCRATCH, &L, &in_ctrl);
+  }
   if (!out) return fail(s, SDPLR_ERR_INVALID_ARG, "A: bad output vector");
   enq_A(s, U, V, V ? 1 : 0, out, nullptr, 0);
   return sync_check(s);
@@ -1543,6 +1601,31 @@ int32_t sdplr_hip_At_right(S* s, const double* x, double* yh, int64_t k) {
     HIPCK(s, hipStreamSynchronize(s->stream));
   }
   return sync_check(s);
+}
+
+int32_t sdplr_hip_At_right_device(S* s, const double* x, double* yd, int64_t k) {
+  ApiShared api_guard;
+  NEED_FINAL(s);
+  if (!x || !yd || k < 1 || x == yd) return fail(s, SDPLR_ERR_INVALID_ARG, "At_right_device: bad args");
+  hipPointerAttribute_t ax{}, ay{};
+  if (hipPointerGetAttributes(&ax, x) != hipSuccess || hipPointerGetAttributes(&ay, yd) != hipSuccess ||
+      ax.type != hipMemoryTypeDevice || ay.type != hipMemoryTypeDevice) {
+    (void)hipGetLastError();
+    return fail(s, SDPLR_ERR_INVALID_ARG, "At_right_device: x and y must be device pointers");
+  }
+  const int64_t n = s->n;
+  for (int64_t c = 0; c < k; c++) enq_spmv(s, x + c * n, yd + c * n, -1, nullptr);
+  return sync_check(s);
+}
+
+int32_t sdplr_hip_get_stats(const S* s, int64_t* out, int32_t cap, int32_t* n_written) {
+  if (!s || !out || cap < 0) return SDPLR_ERR_INVALID_ARG;
+  const int64_t v[8] = {s->st_captures, s->st_capture_failed, s->st_capture_skipped, s->st_graph_batches,
+                        s->st_eager_batches, s->st_lz_graph, s->st_lz_eager, s->st_iters};
+  const int32_t k = std::min<int32_t>(cap, 8);
+  for (int32_t i = 0; i < k; i++) out[i] = v[i];
+  if (n_written) *n_written = k;
+  return SDPLR_OK;
 }
 
 int32_t sdplr_hip_f(S* s, double* L) {
@@ -1715,7 +1798,7 @@ int32_t sdplr_hip_inner_loop(S* s, double normC, double normb, int32_t grel, int
                              double cur_gtol, double fprec_eps, int64_t max_local_iters, double time_budget_s,
                              double* Lio, double* gnio, double* pnio, double* last_alpha, int64_t* iters,
                              int32_t* exit_reason) {
-  std::shared_lock<std::shared_mutex> api_lock(g_api_rw);
+  ApiLock api_lock(g_api_rw);
   NEED_FINAL(s);
   if (!Lio || !gnio || !pnio || max_local_iters < 1) return fail(s, SDPLR_ERR_INVALID_ARG, "inner_loop: bad args");
   ensure_gram(s);
@@ -1728,7 +1811,6 @@ int32_t sdplr_hip_inner_loop(S* s, double normC, double normb, int32_t grel, int
   c->grel = grel; c->prel = prel;
   c->L = *Lio; c->gnorm = *gnio; c->pvnorm = *pnio; c->alpha = 0.0; c->alpha_max = 1.0;
   if ((rc = push(s))) return rc;
-  const auto t0 = std::chrono::steady_clock::now();
   // Iterations are enqueued in batches — a captured hipGraph of `graph_iters` passes of the while
   // body, or eager launches when per-kernel event timing is on.  The device decides every exit;
   // once `done` is set the remaining kernels of a batch fall through.  The control block is
@@ -1750,28 +1832,37 @@ int32_t sdplr_hip_inner_loop(S* s, double normC, double normb, int32_t grel, int
   if (use_graph && !s->graph_exec[ar]) {
     // Capture is fragile on ROCm 7.2 when OTHER host threads issue HIP calls meanwhile (observed: 8 handles
     // driven by 8 threads → "operation failed due to a previous error during capture", any capture mode).
-    // So: one capture at a time, and a failed capture is not an error — this handle falls back to eager
-    // launches for good.
+    // So: one capture at a time, under the process-wide lock taken exclusively — with a bounded wait (other
+    // handles may sit in their own inner loops for seconds): no lock in time ⇒ this call runs eagerly and the
+    // next call tries again.  A capture that FAILS is not an error either, but it is recorded
+    // (note_capture_failure) and this handle launches eagerly for good.
     api_lock.unlock();
     {
-    std::unique_lock<std::shared_mutex> excl(g_api_rw);
-    hipGraph_t graph = nullptr;
-    bool ok = hipStreamBeginCapture(s->stream, hipStreamCaptureModeRelaxed) == hipSuccess;
-    if (ok) {
-      for (int i = 0; i < s->graph_iters; i++) enq_iter();
-      ok = hipStreamEndCapture(s->stream, &graph) == hipSuccess && graph != nullptr;
-    }
-    if (ok) ok = hipGraphInstantiate(&s->graph_exec[ar], graph, nullptr, nullptr, 0) == hipSuccess;
-    if (graph) (void)hipGraphDestroy(graph);
-    if (!ok) {
-      (void)hipGetLastError();
-      s->graph_exec[ar] = nullptr;
-      s->graph_disabled = true;
-    }
+      std::unique_lock<ApiMutex> excl(g_api_rw, std::chrono::milliseconds(capture_wait_ms()));
+      if (!excl.owns_lock()) {
+        s->st_capture_skipped++;
+      } else {
+        hipGraph_t graph = nullptr;
+        bool ok = hipStreamBeginCapture(s->stream, hipStreamCaptureModeRelaxed) == hipSuccess;
+        if (ok) {
+          for (int i = 0; i < s->graph_iters; i++) enq_iter();
+          ok = hipStreamEndCapture(s->stream, &graph) == hipSuccess && graph != nullptr;
+        }
+        if (ok) ok = hipGraphInstantiate(&s->graph_exec[ar], graph, nullptr, nullptr, 0) == hipSuccess;
+        if (graph) (void)hipGraphDestroy(graph);
+        if (ok) {
+          s->st_captures++;
+        } else {
+          note_capture_failure(s, "inner loop");
+          s->graph_exec[ar] = nullptr;
+        }
+      }
     }
     api_lock.lock();
   }
-  if (s->graph_disabled) use_graph = false;
+  if (!s->graph_exec[ar]) use_graph = false;
+  // the time budget starts here: after any wait for the capture lock
+  const auto t0 = std::chrono::steady_clock::now();
   const int64_t eager_batch = std::min<int64_t>(max_local_iters + 1, 8);
   const bool dbg = getenv("SDPLR_HIP_DEBUG") != nullptr;
   double t_enq = 0.0, t_wait = 0.0;
@@ -1782,9 +1873,11 @@ int32_t sdplr_hip_inner_loop(S* s, double normC, double normb, int32_t grel, int
     n_batches++;
     if (use_graph) {
       HIPCK(s, hipGraphLaunch(s->graph_exec[ar], s->stream));
+      s->st_graph_batches++;
     } else {
       for (int64_t i = 0; i < eager_batch; i++) enq_iter();
       HIPCK(s, hipGetLastError());
+      s->st_eager_batches++;
     }
     HIPCK(s, hipMemcpyAsync(s->snap[slot], s->ctrl, sizeof(DevCtrl), hipMemcpyDeviceToHost, s->stream));
     HIPCK(s, hipEventRecord(s->snap_ev[slot], s->stream));
@@ -1854,6 +1947,7 @@ int32_t sdplr_hip_inner_loop(S* s, double normC, double normb, int32_t grel, int
     (void)push(s);
     return fail(s, SDPLR_ERR_NOT_DESCENT, "Error: cubic[1] should be less than 0.");
   }
+  s->st_iters += c->iters;
   *Lio = c->L; *gnio = c->gnorm; *pnio = c->pvnorm;
   if (last_alpha) *last_alpha = c->alpha;
   if (iters) *iters = c->iters;
@@ -1887,8 +1981,7 @@ int32_t sdplr_hip_tridiag_mineig(const double* alpha, const double* beta, int64_
   *out = 0.5 * (lo + hi) - 1;                                   // cancel the shift (:513)
   return SDPLR_OK;
 }
-static int32_t approx_mineig_impl(S* s, int64_t q, const double* v0, double* mineig,
-                                  std::shared_lock<std::shared_mutex>* api_lock) {
+static int32_t approx_mineig_impl(S* s, int64_t q, const double* v0, double* mineig, ApiLock* api_lock) {
   std::vector<double> al(q), be(q);
   int64_t steps = 0;
   int rc = run_lanczos(s, q, v0, al.data(), be.data(), &steps, api_lock);

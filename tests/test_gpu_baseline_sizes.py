@@ -1,0 +1,203 @@
+"""GPU parity at the BASELINE.json sizes (run on the MI355X box with -m gpu): the HIP library against the CPU oracle
+on the north-star inputs themselves — same R₀, λ₀ = 0, σ₀ — through the C ABI.
+
+north_star: "Results match the … CPU reference on the same inputs within a stated FP64 tolerance (1e-8 on ‖grad‖ and
+primal objective)".  Here: fg! + 5 native inner iterations (src/sdplr.jl:190-278) on both libraries; ℒ, ‖grad‖, ‖pv‖,
+obj to 1e-8 relative and R to 1e-8 (max-norm, relative), at full grids (nb_step = 512, nb_tile = 1024 blocks — the
+class of bug a small instance cannot see); the first 10 of the 232 Lanczos steps of the dual bound
+(src/coreop.jl:481-500) to 1e-9; config 5 (64 MaxCut instances, 8 in flight) on the route it takes by default."""
+import os
+
+import numpy as np
+import pytest
+
+import sdplrplus_jl_amd as sj
+from sdplrplus_jl_amd import batch, cabi, problems
+from helpers import make_solver
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-8          # BASELINE.json north_star tolerance on ‖grad‖ and the primal objective
+ITERS = 5
+
+
+def rel(a, b):
+    a, b = np.asarray(a, dtype=float), np.asarray(b, dtype=float)
+    return float(np.max(np.abs(a - b)) / (1.0 + np.max(np.abs(b))))
+
+
+def _instance(which):
+    if which == "maxcut_n1e5":          # BASELINE.json configs[1]: the north-star instance of bench.py
+        return problems.maxcut_data(problems.gnp_graph(100_000, 2e-4, 20240610)), 0
+    if which == "lovasz_chunglu_5e4":   # configs[2] stand-in: Chung–Lu power law, n ≈ 5e4, |E| ≈ 2.5e5
+        return problems.lovasz_theta_data(problems.chung_lu_graph(50_000, 10.0, 2.5, 3)), 1
+    if which == "minbis_n1e5":          # configs[3]
+        return problems.minimum_bisection_data(problems.gnp_graph(100_000, 2e-4, 4)), 2
+    raise KeyError(which)
+
+
+@pytest.mark.parametrize("which", ["maxcut_n1e5", "lovasz_chunglu_5e4", "minbis_n1e5"])
+def test_first_iterations_match_oracle_at_baseline_size(hip_abi, oracle_abi, which):
+    data, seed = _instance(which)
+    r = 32
+    normC, normb = data.normC(), float(np.linalg.norm(data.b))
+    out = {}
+    for name, abi in (("hip", hip_abi), ("oracle", oracle_abi)):
+        s, _ = make_solver(abi, data, r, seed=seed)
+        st = s.fg(normC, normb)
+        res = s.inner_loop(normC, normb, True, True, False, 0.0, -1e300, ITERS, 0.0, *st)
+        assert res[4] == ITERS and res[5] == 2
+        out[name] = dict(fg=st, L=res[0], gnorm=res[1], pvnorm=res[2], alpha=res[3], obj=s.obj, R=s.Rt, G=s.Gt,
+                         pv=s.primal_vio_raw, y=s.y)
+        if name == "hip":
+            # the Lanczos recurrence on the S this state defines, q = 2⌈√100·ln n⌉ (src/coreop.jl:402)
+            v0 = np.random.Generator(np.random.PCG64(5)).standard_normal(data.n)
+            out["v0"] = v0
+        q = int(2 * np.ceil(np.sqrt(100.0) * np.log(data.n)))
+        s.dual_obj(float(data.n), 0, out["v0"])                 # copy2y + 𝒜t_preprocess! (:384-385) + Lanczos
+        al, be, k = s.lanczos(q, out["v0"])
+        assert k == q
+        out[name].update(lz_alpha=al, lz_beta=be, q=q)
+        s.close()
+    h, o = out["hip"], out["oracle"]
+    assert np.allclose(h["fg"], o["fg"], rtol=1e-11)
+    for key in ("L", "gnorm", "pvnorm", "obj"):
+        assert abs(h[key] - o[key]) <= TOL * max(abs(o[key]), 1e-300), (which, key, h[key], o[key])
+    assert abs(h["alpha"] - o["alpha"]) <= 1e-7 * max(1.0, abs(o["alpha"]))
+    assert rel(h["R"], o["R"]) < TOL and rel(h["G"], o["G"]) < 10 * TOL
+    assert rel(h["pv"], o["pv"]) < TOL and rel(h["y"], o["y"]) < TOL
+    # plain Lanczos loses orthogonality after tens of steps: only the first steps are comparable
+    assert np.allclose(h["lz_alpha"][:10], o["lz_alpha"][:10], rtol=1e-9, atol=1e-12 * abs(o["lz_alpha"][0]))
+    assert np.allclose(h["lz_beta"][:10], o["lz_beta"][:10], rtol=1e-9)
+
+
+def _batch_instances():
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "gset_G1_G9.npz"))
+    graphs = [problems.graph_from_edges(int(z[f"G{k}_n"]), z[f"G{k}"]) for k in range(1, 10)]
+    graphs += [problems.gnp_graph(800, 0.06, seed) for seed in range(10, 65)]
+    return graphs
+
+
+def test_config5_full_batch_on_its_default_route(hip_abi, oracle_abi, monkeypatch):
+    """BASELINE.json configs[4] on one GPU: all 64 MaxCut instances of the batch (Gset G1–G9 as in
+    exps/batch_test.txt:1-9 — rank 10, ptol = objtol = 0.01 — plus 55 seeded G(800, 0.06)), 8 in flight, WITHOUT
+    SDPLR_HIP_FORCE_GRAPH: n·r = 8000 < 2¹⁷, so this is the eager route the batch really takes.  Every objective,
+    dual bound and iteration count must equal a serial run of the same instance bit for bit, and G1–G9 must land
+    within the objtol window of the oracle's solve of the same seed."""
+    monkeypatch.delenv("SDPLR_HIP_FORCE_GRAPH", raising=False)
+    graphs = _batch_instances()
+    assert len(graphs) == 64 and graphs[0].shape == (800, 800) and graphs[0].nnz == 38352
+    kw = dict(make_data=problems.maxcut_data, ptol=0.01, objtol=0.01, seed=0, prior_trace_bound=800.0)
+    conc = batch.gather(batch.solve_local(graphs, 0, 1, 10, concurrency=8, **kw), 64)
+    ser = batch.gather(batch.solve_local(graphs, 0, 1, 10, concurrency=1, **kw), 64)
+    assert conc.shape == ser.shape == (64, batch.N_FIELDS)
+    assert np.array_equal(conc[:, :4], ser[:, :4])            # index, obj, max_dual_value, iterations
+    assert np.all(conc[:, 2] <= conc[:, 1] + 1e-6 * np.abs(conc[:, 1]))     # weak duality
+    # best known cuts of G1–G9 are 11 624 … 12 083-ish SDP bounds: −obj lies in between ±1 %
+    assert np.all((-conc[:9, 1] >= 11400 * 0.99) & (-conc[:9, 1] <= 12100 * 1.01))
+    ora = batch.gather(batch.solve_local(graphs[:9], 0, 1, 10, abi=oracle_abi, concurrency=1, **kw), 9)
+    # both stop with a relative duality gap ≤ objtol = 1e-2 around the same SDP value
+    assert np.all(np.abs(conc[:9, 1] - ora[:, 1]) <= 1e-2 * np.abs(ora[:, 1]))
+    assert np.all(np.abs(conc[:9, 2] - ora[:, 2]) <= 2e-2 * np.abs(ora[:, 2]))
+
+
+def test_production_scale_grids_n3e5(hip_abi, monkeypatch):
+    """n = 3·10⁵, r = 32 MaxCut: more than 1024·16 tiles' worth of rows (the tile kernel's grid-stride loop), 24-bit
+    column packing with n > 2¹⁸, full step / update grids.  Five iterations on the default route and on the routes
+    with the tile kernel / fused update / singleton fusion switched off, each checked against a scipy recomputation
+    of the state (𝒜, G = 2(C + Diag y)R, W = A_g·D through P = A_g·R) and against the default route to 1e-9."""
+    n, r = 300_000, 32
+    A = problems.gnp_graph(n, 20.0 / n, 77)
+    data = problems.maxcut_data(A)
+    normC, normb = data.normC(), float(np.linalg.norm(data.b))
+
+    def run():
+        g, _ = make_solver(hip_abi, data, r, seed=3)
+        st = g.fg(normC, normb)
+        res = g.inner_loop(normC, normb, True, True, False, 0.0, -1e300, 5, 0.0, *st)
+        out = (res, g.Rt, g.Gt, g.primal_vio_raw, g.y, g.dirt)
+        g.close()
+        return out
+
+    base = run()
+    res, R, G, pv, y, D = base
+    assert res[4] == 5
+    C = data.C
+    assert np.max(np.abs(pv[:-1] - (np.einsum("ij,ij->i", R, R) - 1.0))) < 1e-9
+    CR = C @ R
+    assert abs(pv[-1] - float(np.sum(CR * R))) < 1e-10 * abs(pv[-1])
+    Gref = 2 * (CR + y[:-1, None] * R)
+    assert np.max(np.abs(G - Gref)) < 1e-10 * np.max(np.abs(Gref))
+    assert res[1] == pytest.approx(np.linalg.norm(Gref) / normC, rel=1e-10)
+    for toggle in ("SDPLR_HIP_NO_TILE", "SDPLR_HIP_NO_UPDFUSE", "SDPLR_HIP_NO_FAST2"):
+        monkeypatch.setenv(toggle, "1")
+        alt = run()
+        monkeypatch.delenv(toggle)
+        assert np.allclose(alt[0][:3], res[:3], rtol=1e-9), toggle
+        assert rel(alt[1], R) < 1e-9 and rel(alt[2], G) < 1e-8 and rel(alt[5], D) < 1e-7, toggle
+
+
+def test_row_offsets_just_below_2_pow_32(hip_abi):
+    """8·n·r = 4.26e9 < 2³² = 4.29e9 (n = 2²⁰, r = 508): the largest factor the 32-bit row byte offsets of the tile /
+    fused step kernels serve (beyond it the library must — and does — take the 64-bit row kernels).  r = 508 also
+    means whole-wave groups with four chunks per row, the last one ragged.  Checked with scipy identities after fg!
+    and after 3 inner iterations."""
+    n, r = 1 << 20, 508
+    assert 8 * n * r < 2 ** 32 < 8 * n * (r + 4)
+    A = problems.gnp_graph(n, 8.0 / n, 5)
+    data = problems.maxcut_data(A)
+    g, _ = make_solver(hip_abi, data, r, seed=4)
+    normC, normb = data.normC(), float(np.linalg.norm(data.b))
+    st = g.fg(normC, normb)
+    res = g.inner_loop(normC, normb, True, True, False, 0.0, -1e300, 3, 0.0, *st)
+    assert res[4] == 3 and res[0] < st[0]
+    R = g.Rt
+    pv = g.primal_vio_raw
+    assert np.max(np.abs(pv[:-1] - (np.einsum("ij,ij->i", R, R) - 1.0))) < 1e-8
+    CR = data.C @ R
+    assert abs(pv[-1] - float(np.sum(CR * R))) < 1e-10 * abs(pv[-1])
+    y = g.y
+    G = g.Gt
+    CR += y[:-1, None] * R
+    CR *= 2.0
+    assert np.max(np.abs(G - CR)) < 1e-10 * np.max(np.abs(CR))
+    g.close()
+
+
+def test_scratch_slots_and_device_vectors(hip_abi, oracle_abi):
+    """𝒜!(out, aux, Ut[, Vt]) on the caller's own matrices (SDPLR_F_SCRATCH / SDPLR_V_SCRATCH) leaves the solver state
+    alone; 𝒜t!(y, aux, x, var) on device vectors (sdplr_hip_At_right_device) equals the host-vector form."""
+    import ctypes as C
+    from helpers import make_data, primal_vio_dense
+    data, Cm, As, bs = make_data("minimum_bisection", 3, 40, 0.3)
+    g, _ = make_solver(hip_abi, data, 6, seed=1)
+    normC, normb = data.normC(), float(np.linalg.norm(data.b))
+    st = g.fg(normC, normb)
+    before = (g.Rt, g.Gt, g.primal_vio_raw, g.A_RD, g.A_DD)
+    rng = np.random.Generator(np.random.PCG64(3))
+    U, V = rng.standard_normal((data.n, 6)), rng.standard_normal((data.n, 6))
+    out = g.A_of(U)
+    ref = primal_vio_dense(Cm, As, np.zeros(len(bs)), U)
+    assert np.max(np.abs(out - ref)) < 1e-10 * (1 + np.max(np.abs(ref)))
+    out2 = g.A_of(U, V)
+    X = (U @ V.T + V @ U.T) / 2
+    ref2 = np.array([np.sum(A_.toarray() * X) for A_ in As] + [np.sum(Cm.toarray() * X)])
+    assert np.max(np.abs(out2 - ref2)) < 1e-10 * (1 + np.max(np.abs(ref2)))
+    after = (g.Rt, g.Gt, g.primal_vio_raw, g.A_RD, g.A_DD)
+    assert all(np.array_equal(a, b) for a, b in zip(before, after))
+    # device vectors: raw hipMalloc'ed buffers through the HIP runtime the library itself uses
+    hip = C.CDLL("libamdhip64.so.7")      # the soname libsdplr_hip.so is linked against: the same loaded runtime
+    n, k = data.n, 3
+    x = np.asfortranarray(rng.standard_normal((n, k)))
+    dx, dy = C.c_void_p(), C.c_void_p()
+    assert hip.hipMalloc(C.byref(dx), C.c_size_t(8 * n * k)) == 0 and hip.hipMalloc(C.byref(dy), C.c_size_t(8 * n * k)) == 0
+    assert hip.hipMemcpy(dx, x.ctypes.data_as(C.c_void_p), C.c_size_t(8 * n * k), 1) == 0
+    g.At_right_device(dx.value, dy.value, k)
+    yd = np.empty((n, k), order="F")
+    assert hip.hipMemcpy(yd.ctypes.data_as(C.c_void_p), dy, C.c_size_t(8 * n * k), 2) == 0
+    assert np.array_equal(yd, g.At_right(x))
+    rc = g.abi.At_right_device(g._h, x.ctypes.data_as(C.c_void_p), dy, 1)                    # a host pointer is refused
+    assert rc == cabi.ERR_INVALID_ARG
+    hip.hipFree(dx); hip.hipFree(dy)
+    assert g.stats()["graph_capture_failures"] == 0
+    g.close()

@@ -497,6 +497,11 @@ def test_concurrent_handles_match_serial(hip_abi):
     ("minimum_bisection", ["SDPLR_HIP_NO_TILE"]), ("cutnorm", ["SDPLR_HIP_NO_FAST"]),
     ("lovasz_theta", ["SDPLR_HIP_NO_LRFUSE"]), ("minimum_bisection", ["SDPLR_HIP_NO_FAST", "SDPLR_HIP_NO_LRFUSE"]),
     ("mu_conductance_0.05", ["SDPLR_HIP_NO_FAST"]), ("ineq_0.05", ["SDPLR_HIP_NO_FAST"]),
+    # the eager route (what instances below n·r = 2¹⁷ take by default; the suite forces graphs otherwise) for EVERY family
+    ("minimum_bisection", ["SDPLR_HIP_NO_GRAPH"]), ("lovasz_theta", ["SDPLR_HIP_NO_GRAPH"]),
+    ("cutnorm", ["SDPLR_HIP_NO_GRAPH"]), ("mu_conductance_0.01", ["SDPLR_HIP_NO_GRAPH"]),
+    ("mu_conductance_0.05", ["SDPLR_HIP_NO_GRAPH"]), ("mu_conductance_0.1", ["SDPLR_HIP_NO_GRAPH"]),
+    ("ineq_0.01", ["SDPLR_HIP_NO_GRAPH"]), ("ineq_0.05", ["SDPLR_HIP_NO_GRAPH"]), ("ineq_0.1", ["SDPLR_HIP_NO_GRAPH"]),
 ])
 def test_code_paths_agree(hip_abi, oracle_abi, family, toggles, monkeypatch):
     """The structured fast paths, the hipGraph batches and the eager launches are the same algorithm:
