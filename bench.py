@@ -142,42 +142,72 @@ def first_iterations(sj, abi, data, r, n_iters):
     return var, [st[0], st[1], st[2], var.obj]
 
 
-def cpu_baseline(sj, data, r, gpu_first, repeats=5, iters=20):
+def effective_cpus() -> int:
+    """CPUs this process may really use: the affinity mask capped by the cgroup CPU quota (a GPU box hands a
+    16-CPU share of a much larger host to one GPU; sizing an OpenMP team to the host would oversubscribe it)."""
+    n = os.cpu_count() or 1
+    if hasattr(os, "sched_getaffinity"):
+        n = min(n, len(os.sched_getaffinity(0)))
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as f:
+                parts = f.read().split()
+            if path.endswith("cpu.max"):
+                if parts[0] != "max":
+                    n = min(n, max(1, int(float(parts[0]) / float(parts[1]) + 0.999)))
+            else:
+                quota = int(parts[0])
+                if quota > 0:
+                    with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as g:
+                        n = min(n, max(1, int(quota / int(g.read().split()[0]) + 0.999)))
+        except (OSError, ValueError, IndexError):
+            continue
+    return max(1, min(n, int(os.environ.get("SDPLR_BENCH_MAX_THREADS", "64"))))
+
+
+def cpu_baseline(sj, data, r, gpu_first, repeats=5, sample_s=2.5):
     """The oracle (CPU restatement, kind "port") on the same instance, same host, same run: ONE thread (the
     reference's own protocol, exps/test.jl:46) and all cores (OpenMP in its dense sweeps, SDDMM and SpMM) beside
-    it, each the median of `repeats` samples of `iters` inner iterations after fg! + the PARITY_ITERS iterations
-    whose (ℒ, ‖grad‖, obj) are compared with the GPU's — the parity evidence of this very run."""
+    it, each the median of `repeats` samples of ≈`sample_s` seconds of inner iterations after fg! + the
+    PARITY_ITERS iterations whose (ℒ, ‖grad‖, obj) are compared with the GPU's — the parity evidence of this very
+    run.  Bounded: ≈ 2·(repeats·sample_s) seconds of CPU work plus the set-up."""
     import numpy as np
     from oracle import oracle
     one_abi, omp_abi, how, set_threads = oracle.timing_abis()
     normC, normb = data.normC(), float(np.linalg.norm(data.b))
-    ncores = os.cpu_count() or 1
-    if hasattr(os, "sched_getaffinity"):
-        ncores = len(os.sched_getaffinity(0))
+    ncores = effective_cpus()
 
     def timed(abi, threads):
         set_threads(threads)
+        t0 = time.perf_counter()
         var, first = first_iterations(sj, abi, data, r, PARITY_ITERS)
         st = first[:3]
+        t1 = time.perf_counter()
+        st = run_fixed(var, normC, normb, st, 2)             # sizes the samples
+        per = (time.perf_counter() - t1) / 2
+        iters = int(max(3, min(20, sample_s / max(per, 1e-6))))
         rates = []
         for _ in range(repeats):
-            t0 = time.perf_counter()
+            t1 = time.perf_counter()
             st = run_fixed(var, normC, normb, st, iters)
-            rates.append(iters / (time.perf_counter() - t0))
+            rates.append(iters / (time.perf_counter() - t1))
         var.close()
-        return statistics.median(rates), first
+        print(f"bench.py: cpu_baseline {threads} thread(s): {statistics.median(rates):.2f} it/s "
+              f"({repeats} x {iters} iterations, {time.perf_counter() - t0:.1f} s)", file=sys.stderr, flush=True)
+        return statistics.median(rates), first, iters
 
-    v_all, _ = timed(omp_abi, ncores)
-    v_one, first = timed(one_abi, 1)
+    v_all, _, it_all = timed(omp_abi, ncores)
+    v_one, first, it_one = timed(one_abi, 1)
     relerr = lambda a, b: abs(a - b) / max(abs(b), 1e-300)
     parity = {"iters": PARITY_ITERS, "rel_L": relerr(gpu_first[0], first[0]), "rel_grad": relerr(gpu_first[1], first[1]),
               "rel_pv": relerr(gpu_first[2], first[2]), "rel_obj": relerr(gpu_first[3], first[3]),
               "tolerance": 1e-8, "against": "oracle (CPU restatement), same R0/λ0/σ0, fg! + 5 inner iterations"}
     parity["ok"] = bool(max(parity["rel_L"], parity["rel_grad"], parity["rel_obj"]) < 1e-8)
-    sample = (f"same MaxCut G(1e5,2e-4) r={r} instance; median of {repeats} samples of {iters} inner iterations "
-              f"after fg! + {PARITY_ITERS} iterations")
+    sample = (f"same MaxCut G(1e5,2e-4) r={r} instance; median of {repeats} samples of {it_one} inner iterations "
+              f"after fg! + {PARITY_ITERS} + 2 iterations")
     base = {"value": v_one, "unit": "iterations/s", "cores": 1, "kind": "port", "sample": sample, "build": how,
             "all_cores": {"value": v_all, "unit": "iterations/s", "cores": ncores, "kind": "port",
+                          "sample": f"median of {repeats} samples of {it_all} inner iterations",
                           "threads": "OpenMP over the dense n·r sweeps, the SDDMM and the SpMM of the oracle"}}
     return base, parity
 
