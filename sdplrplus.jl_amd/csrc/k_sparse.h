@@ -1746,3 +1746,300 @@ k_lz_step(int n, DevCtrl* __restrict__ c, const double* __restrict__ uprev, cons
     c->lz_steps = st + 1;                                       // iter += 1 (:482)
   }
 }
+
+// ================================================================================================
+// Lanczos SpMV through LDS-resident bands of x  (k_lz_band + k_lz_step_band; replaces k_lz_spmv + k_lz_step
+// when the band plan exists: 2¹⁴ ≤ n, ≤ 16 bands).
+//
+// k_lz_spmv gathers x[rowval[p]] — 2.1 M random 8-byte reads per step at the north-star size.  x (0.8 MB) sits in
+// every XCD's L2, but each 8-byte read costs a whole L2 request and line fill (profiles/r02_lanczos_pmc.csv:
+// 2.5 M TCC read requests per launch, 88 % hits, the waves 54 % of their cycles in s_waitcnt) — the kernel runs at
+// the L2 REQUEST rate, 18 µs for 31 MB of compulsory bytes.  Here the columns are cut into NB bands of BW ≤ 16 384
+// entries and the rows into NC chunks; block (b, c) stages band b of x into LDS with coalesced loads (NB·NC·BW·8 B
+// ≈ 29 MB of L2 reads per step instead of 2.1 M requests of 128 B), then sweeps the nonzeros of its rows that fall
+// into the band — the random reads hit LDS — and writes a PARTIAL t for its chunk; the recurrence kernel adds the NB
+// partials of a row in band order while it streams u and u_prev anyway.
+//   Layout ("sliced ELL", built once on the host): within a block the rows are sorted by their nonzero count in the
+// band and cut into slots of 64 (one wave, one row per lane); a slot stores its entries lane-fastest and padded to
+// the slot's longest row, so a wave reads 64 consecutive (column u16, value f64) pairs per step of a uniform loop.
+// Values are re-gathered from sparse_S.nzval once per Lanczos run (k_lz_band_fill): S is fixed during the q steps.
+// Sums are formed in a fixed order (row: ascending column inside a band; then bands ascending): deterministic.
+// Hub rows (more than long_thresh nonzeros) are left out of the plan: k_spmv_long writes them to `textra`.
+// ================================================================================================
+struct DevBand {
+  int NB, NC, BW, CH, n_slots, n_groups;   // n_groups counts the real groups; group n_groups is an all-padding dummy
+  const int* blk_slot;            // [NB·NC + 1] slots of block b·NC + c
+  const int* slot_g;              // [n_slots + 1] first group of each slot
+  // one GROUP = 4 entries of each of a slot's 64 rows (lane-fastest); padding entries are (column 0, value 0)
+  const uint4* cw;                // [groups·64] {c0 | c1 << 16, c2 | c3 << 16, row local to the chunk (0xFFFF ⇒ none), 0}
+  double2* vA;                    // [groups·64] values of entries 0, 1   (refreshed by k_lz_band_fill)
+  double2* vB;                    // [groups·64] values of entries 2, 3
+  const int4* pos;                // [groups·64] positions in sparse_S.nzval; −1 ⇒ padding
+  double* tpart;                  // [NB][n] band partials of t = S·u
+  double* textra;                 // [n] hub rows of t (k_spmv_long), zero elsewhere
+};
+
+__global__ void __launch_bounds__(SDPLR_NT)
+k_lz_band_fill(DevBand bd, const double* __restrict__ nzval) {
+  const long long total = (long long)(bd.n_groups + 1) * 64;
+  const long long stride = (long long)gridDim.x * SDPLR_NT;
+  for (long long e = (long long)blockIdx.x * SDPLR_NT + threadIdx.x; e < total; e += stride) {
+    const int4 p = bd.pos[e];
+    double2 a, b;
+    a.x = p.x >= 0 ? nzval[p.x] : 0.0;
+    a.y = p.y >= 0 ? nzval[p.y] : 0.0;
+    b.x = p.z >= 0 ? nzval[p.z] : 0.0;
+    b.y = p.w >= 0 ? nzval[p.w] : 0.0;
+    bd.vA[e] = a;
+    bd.vB[e] = b;
+  }
+}
+
+#define SDPLR_LZB_NT 1024
+#define SDPLR_LZB_MAXS 4      /* slots per wave: CH ≤ 4096 rows = 64 slots over 16 waves */
+#define SDPLR_LZB_G0 3        /* groups of a wave's FIRST slot requested up front (the block's 16 longest slots) */
+// K1: partial t for (band, chunk) + the block's share of u·t; the grid's last block closes the previous step exactly
+// as k_lz_spmv's block 0 does and publishes the low-rank coefficients (coef_out[c] = y[gid]·D_c·⟨B_c,u⟩,
+// coef_out[ST + c] = ⟨B_c,u⟩).
+// Everything a sweeping block reads from global memory is requested in ONE round trip before anything is waited for,
+// in as few wave instructions as the layout allows (a CU's texture path issues one wave-load per ≈ 8-16 cycles
+// whatever its width: the first version — staging loop, then slot after slot, one 2-byte and one 8-byte load per
+// entry — sat 8.5 of its 12 µs in the request phase): the band of x (≤ 8 × 16 B per thread), per slot three 16-byte
+// loads per lane for four entries (packed columns + row, two value pairs), the chunk's rows of u for the dot.  Slots
+// past the block's end and groups past a slot's end are redirected to the all-padding dummy group, so nothing in the
+// sweep is conditional.
+__global__ void __launch_bounds__(SDPLR_LZB_NT)
+k_lz_band(DevBand bd, int n, DevCtrl* __restrict__ c, const double* __restrict__ u, DevLowRank lr,
+          const double* __restrict__ yvec, const double* __restrict__ btx_part, int nb_prev,
+          double* __restrict__ coef_out, double* __restrict__ beta_out, double* __restrict__ partials) {
+  extern __shared__ double lzb_lds[];   // xs[BW] | ys[CH]
+  __shared__ double shw[SDPLR_LZB_NT / 64];
+  constexpr int MAXS = SDPLR_LZB_MAXS, G0 = SDPLR_LZB_G0, NW = SDPLR_LZB_NT / 64;
+  constexpr int NG = G0 + MAXS - 1;     // groups requested up front per lane
+  double* xs = lzb_lds;
+  double* ys = lzb_lds + bd.BW;
+  const int dn = c->lz_done;
+  if (blockIdx.x == gridDim.x - 1) {
+    // The grid's LAST block only closes the previous step (one wave; its partials — nb_prev ≤ 1024 each — are fetched
+    // 16 per lane in one round trip, unconditionally: the arrays are SDPLR_MAXNB wide).  A block of its own, so that
+    // neither its registers nor its round trip sit on a sweeping block's path.
+    if (threadIdx.x >= 64) return;
+    const int lane = threadIdx.x;
+    double nn = 0.0;
+    {
+      const double* pn = slot_partials(partials, SLOT_LZ_N);
+      double v[16];
+#pragma unroll
+      for (int q = 0; q < 16; q++) v[q] = pn[lane + 64 * q];
+#pragma unroll
+      for (int q = 0; q < 16; q++) nn += (lane + 64 * q < nb_prev) ? v[q] : 0.0;
+      for (int i = lane + 1024; i < nb_prev; i += 64) nn += pn[i];
+      nn = wave_sum(nn);
+    }
+    double bsum[SDPLR_LRMAX];
+#pragma unroll
+    for (int cc = 0; cc < SDPLR_LRMAX; cc++) {
+      bsum[cc] = 0.0;
+      if (cc < lr.ST) {
+        const double* pb = btx_part + (long long)cc * nb_prev;
+        double v[16], sidx = 0.0;
+#pragma unroll
+        for (int q = 0; q < 16; q++) v[q] = pb[min(lane + 64 * q, nb_prev - 1)];
+#pragma unroll
+        for (int q = 0; q < 16; q++) sidx += (lane + 64 * q < nb_prev) ? v[q] : 0.0;
+        for (int i = lane + 1024; i < nb_prev; i += 64) sidx += pb[i];
+        bsum[cc] = wave_sum(sidx);
+      }
+    }
+    if (!dn && lane == 0) {   // close the previous step (see "Lanczos recurrence" above)
+#pragma unroll
+      for (int cc = 0; cc < SDPLR_LRMAX; cc++)
+        if (cc < lr.ST) {
+          coef_out[cc] = yvec[lr.col_gid[cc]] * lr.Dcat[cc] * bsum[cc];
+          coef_out[lr.ST + cc] = bsum[cc];
+        }
+      const double g = sqrt(nn);
+      const long long st = c->lz_steps;
+      if (st > 0) {
+        beta_out[st - 1] = g;                                                      // beta[i] = ‖Av‖  (:492)
+        if (fabs(g) < sqrt((double)n) * 2.220446049250313e-16) c->lz_done = 1;     // (:494-496)
+      }
+      if (st >= c->lz_qmax) c->lz_done = 1;
+      c->lz_gamma_prev = c->lz_gamma_cur;
+      c->lz_gamma_cur = g;
+      c->lz_beta_prev = (st > 0) ? g : 0.0;
+    }
+    return;
+  }
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int b = blockIdx.x / bd.NC, ch = blockIdx.x % bd.NC;
+  const int col0 = b * bd.BW, ncol = max(0, min(bd.BW, n - col0));
+  const int row0 = ch * bd.CH, nrow = max(0, min(bd.CH, n - row0));
+  const int s0 = bd.blk_slot[blockIdx.x], s1 = bd.blk_slot[blockIdx.x + 1];
+  // ---- requests -------------------------------------------------------------------------------------------------
+  // group index of up-front request j: j < G0 → groups 0..G0−1 of the wave's first slot, then group 0 of slots 1..
+  int gfirst[MAXS], gend[MAXS];
+#pragma unroll
+  for (int q = 0; q < MAXS; q++) {
+    const int sl = s0 + wave + NW * q;
+    const int slc = min(sl, max(bd.n_slots - 1, 0));
+    const int g0 = bd.slot_g[slc], g1 = bd.slot_g[slc + 1];
+    const bool ok = sl < s1;
+    gfirst[q] = ok ? g0 : bd.n_groups;      // (bd.n_groups = the dummy group)
+    gend[q] = ok ? g1 : bd.n_groups;
+  }
+  uint4 cw[NG];
+  double2 va[NG], vb[NG];
+#pragma unroll
+  for (int j = 0; j < NG; j++) {
+    const int q = j < G0 ? 0 : j - G0 + 1;
+    const int g = gfirst[q] + (j < G0 ? j : 0);
+    const long long e = (long long)(g < gend[q] ? g : bd.n_groups) * 64 + lane;
+    cw[j] = bd.cw[e];
+    va[j] = bd.vA[e];
+    vb[j] = bd.vB[e];
+  }
+  constexpr int XT = 16384 / 2 / SDPLR_LZB_NT;    // double2 per thread for the widest band
+  const int npair = ncol >> 1;
+  double2 xr[XT];
+  const double2* u2 = reinterpret_cast<const double2*>(u + col0);   // col0 is a multiple of 64
+#pragma unroll
+  for (int k = 0; k < XT; k++) xr[k] = u2[min(tid + SDPLR_LZB_NT * k, max(npair - 1, 0))];   // (vectors are padded by 64)
+  double ur[MAXS];   // the chunk's rows of u (CH ≤ 4096 = MAXS·1024)
+#pragma unroll
+  for (int k = 0; k < MAXS; k++) ur[k] = u[min(row0 + tid + SDPLR_LZB_NT * k, n - 1)];
+  if (dn) return;
+  // ---- the band of x into LDS --------------------------------------------------------------------------------------
+#pragma unroll
+  for (int k = 0; k < XT; k++) {
+    const int i = tid + SDPLR_LZB_NT * k;
+    if (i < npair) reinterpret_cast<double2*>(xs)[i] = xr[k];
+  }
+  if ((ncol & 1) && tid == 0) xs[ncol - 1] = u[col0 + ncol - 1];
+  for (int i = tid; i < nrow; i += SDPLR_LZB_NT) ys[i] = 0.0;
+  __syncthreads();
+  // ---- the sweep: one row per lane and slot; a row's products are added in ascending column order ------------------
+  auto fold = [&](double acc, const uint4& w, const double2& a, const double2& bb) {
+    acc += a.x * xs[w.x & 0xFFFFu];
+    acc += a.y * xs[w.x >> 16];
+    acc += bb.x * xs[w.y & 0xFFFFu];
+    acc += bb.y * xs[w.y >> 16];
+    return acc;
+  };
+#pragma unroll
+  for (int q = 0; q < MAXS; q++) {
+    double acc = 0.0;
+    const int j0 = q == 0 ? 0 : G0 + q - 1, nj = q == 0 ? G0 : 1;
+#pragma unroll
+    for (int j = 0; j < nj; j++) acc = fold(acc, cw[j0 + j], va[j0 + j], vb[j0 + j]);
+    for (int g = gfirst[q] + nj; g < gend[q]; g++) {      // rows longer than the up-front groups (rare)
+      const long long e = (long long)g * 64 + lane;
+      acc = fold(acc, bd.cw[e], bd.vA[e], bd.vB[e]);
+    }
+    const unsigned lrow = cw[j0].z;
+    if (lrow != 0xFFFFu) ys[lrow] = acc;
+  }
+  __syncthreads();
+  double dot = 0.0;
+  double* tp = bd.tpart + (long long)b * n + row0;
+#pragma unroll
+  for (int k = 0; k < MAXS; k++) {
+    const int i = tid + SDPLR_LZB_NT * k;
+    if (i < nrow) {
+      const double t = ys[i];
+      tp[i] = t;
+      dot += ur[k] * t;
+    }
+  }
+  dot = wave_sum(dot);
+  if (lane == 0) shw[wave] = dot;
+  __syncthreads();
+  if (tid == 0) {
+    double tsum = 0.0;
+#pragma unroll
+    for (int w = 0; w < NW; w++) tsum += shw[w];
+    slot_partials(partials, SLOT_LZ_A)[blockIdx.x] = tsum;
+  }
+}
+
+// K2: t_k = Σ_b tpart[b][k] (+ hub rows + low-rank), α_i, r_i and the partials for the next step (see k_lz_step).
+// The grid covers n in one trip (n ≤ 2¹⁸ whenever the band plan exists), and a thread's row — its ≤ 16 band
+// partials, u, u_prev — is requested together with the flags and the partials of u·t, before the reduction's
+// barriers: one memory round trip, not two.
+#define SDPLR_LZB_NBMAX 16
+__global__ void __launch_bounds__(SDPLR_NT)
+k_lz_step_band(int n, DevCtrl* __restrict__ c, DevBand bd, int has_long, const double* __restrict__ uprev,
+               const double* __restrict__ u, double* __restrict__ t, DevLowRank lr,
+               const double* __restrict__ coef, double* __restrict__ btx_part, int nb_a,
+               double* __restrict__ alpha_out, double* __restrict__ partials) {
+  __shared__ double sh[8];
+  const int dn = c->lz_done;
+  const double gi = c->lz_gamma_cur, gp = c->lz_gamma_prev, be = c->lz_beta_prev;
+  const int stride = gridDim.x * SDPLR_NT;
+  const int k0 = blockIdx.x * SDPLR_NT + threadIdx.x;
+  const int kc = min(k0, n - 1);           // clamped: every load of the first trip is unconditional
+  double tpv[SDPLR_LZB_NBMAX];
+#pragma unroll
+  for (int b = 0; b < SDPLR_LZB_NBMAX; b++) tpv[b] = bd.tpart[(long long)min(b, bd.NB - 1) * n + kc];
+  const double te0v = bd.textra[kc];
+  const double te0 = has_long ? te0v : 0.0;
+  const double u0 = u[kc], up0 = uprev[kc];
+  double cf[SDPLR_LRMAX], lrdot = 0.0;
+#pragma unroll
+  for (int cc = 0; cc < SDPLR_LRMAX; cc++) {
+    cf[cc] = 0.0;
+    if (cc < lr.ST) {
+      cf[cc] = coef[cc];
+      lrdot += cf[cc] * coef[lr.ST + cc];     // coef_c·⟨B_c,u⟩: the low-rank part of u·(S·u)
+    }
+  }
+  double pa = 0.0;
+  for (int i = threadIdx.x; i < nb_a; i += SDPLR_NT) pa += slot_partials(partials, SLOT_LZ_A)[i];
+  if (dn) return;
+  const double al = (block_sum1(pa, sh) + lrdot) / (gi * gi);  // v'·Av (:484)
+  double nrm = 0.0;
+  double bt[SDPLR_LRMAX];
+#pragma unroll
+  for (int cc = 0; cc < SDPLR_LRMAX; cc++) bt[cc] = 0.0;
+  for (int k = k0; k < n; k += stride) {
+    double tv = 0.0, uk, upk;
+    if (k == k0) {
+#pragma unroll
+      for (int b = 0; b < SDPLR_LZB_NBMAX; b++) tv += (b < bd.NB) ? tpv[b] : 0.0;
+      tv += te0;
+      uk = u0;
+      upk = up0;
+    } else {
+      for (int b = 0; b < bd.NB; b++) tv += bd.tpart[(long long)b * n + k];
+      if (has_long) tv += bd.textra[k];
+      uk = u[k];
+      upk = uprev[k];
+    }
+#pragma unroll
+    for (int cc = 0; cc < SDPLR_LRMAX; cc++)
+      if (cc < lr.ST) tv += cf[cc] * lr.Bcat[(long long)cc * n + k];
+    const double vi = uk / gi, avk = tv / gi, vp = upk / gp;
+    const double r = avk - (al * vi + be * vp);                 // (:486-490)
+    t[k] = r;
+    nrm += r * r;
+#pragma unroll
+    for (int cc = 0; cc < SDPLR_LRMAX; cc++)
+      if (cc < lr.ST) bt[cc] += lr.Bcat[(long long)cc * n + k] * r;
+  }
+  __syncthreads();
+  nrm = block_sum1(nrm, sh);
+  if (threadIdx.x == 0) slot_partials(partials, SLOT_LZ_N)[blockIdx.x] = nrm;
+#pragma unroll
+  for (int cc = 0; cc < SDPLR_LRMAX; cc++)
+    if (cc < lr.ST) {
+      __syncthreads();
+      const double v = block_sum1(bt[cc], sh);
+      if (threadIdx.x == 0) btx_part[(long long)cc * gridDim.x + blockIdx.x] = v;
+    }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    const long long st = c->lz_steps;
+    alpha_out[st] = al;
+    c->lz_steps = st + 1;                                       // iter += 1 (:482)
+  }
+}

@@ -80,6 +80,8 @@ struct sdplr_hip_solver {
   DevSparse sp_fast{};       // sp with the segmented-reduction plan restricted to the diagonal-only matrices
   DevSparse spg{};           // the general matrix A_g alone, as a symmetric CSR with fixed values
   DevTile tile{};            // the same matrix as column-sorted K-row tiles (k_spmm_tile)
+  DevBand band{};            // full pattern as LDS-band slices for the Lanczos SpMV (k_lz_band)
+  bool use_band = false;
   int nb_tile = 0, nb_step = 1;
   bool use_tile = false;
   bool no_updfuse = false;   // SDPLR_HIP_NO_UPDFUSE: lbfgs_update! as a kernel of its own on the singleton fast path
@@ -390,6 +392,105 @@ int build_tiles(S* s) {
   return SDPLR_OK;
 }
 
+// The band plan of the Lanczos SpMV (k_sparse.h, DevBand) from the host copy of the full pattern (CSC of the
+// symmetric S: column j lists row j's neighbours).  NB bands of BW ≤ 16 384 columns (x band in LDS: ≤ 128 KB),
+// NC row chunks of CH ≤ 4096 rows (partial t of the chunk in LDS: ≤ 32 KB), one 1024-thread block per (band,
+// chunk), about one block per CU.  Hub rows are left to k_spmv_long.
+int build_band(S* s) {
+  s->use_band = false;
+  const int64_t n = s->n;
+  // (SDPLR_HIP_LZBAND_MIN_N / _BW / _CH: test knobs — small instances with several narrow bands and chunks)
+  int64_t min_n = 1 << 14;
+  if (const char* e = getenv("SDPLR_HIP_LZBAND_MIN_N")) min_n = std::max(1, atoi(e));
+  if (!s->have_sparse || s->nnzS == 0 || n < min_n || getenv("SDPLR_HIP_NO_LZBAND") != nullptr) return SDPLR_OK;
+  int BWMAX = 16384, CHMAX = 4096;
+  if (const char* e = getenv("SDPLR_HIP_LZBAND_BW")) BWMAX = std::max(64, std::min(atoi(e), 16384)) / 64 * 64;
+  if (const char* e = getenv("SDPLR_HIP_LZBAND_CH")) CHMAX = std::max(1, std::min(atoi(e), 4096));
+  const int NB = (int)((n + BWMAX - 1) / BWMAX);
+  if (NB > 16) return SDPLR_OK;
+  const int BW = (int)(((n + NB - 1) / NB + 63) / 64 * 64);
+  int NC = std::max<int>((int)((n + CHMAX - 1) / CHMAX), 256 / NB);
+  if (const char* e = getenv("SDPLR_HIP_LZBAND_NC")) NC = std::max(NC, atoi(e));
+  if ((int64_t)NB * NC > 1024) return SDPLR_OK;
+  const int CH = (int)((n + NC - 1) / NC);
+  const std::vector<int>&cp = s->h_fcp, &rv = s->h_frv;
+  const int thresh = s->sp.long_thresh;
+  auto is_hub = [&](int64_t j) { return s->sp.n_long_rows > 0 && cp[j + 1] - cp[j] > thresh; };
+  // entries of row j that fall into band b, in ascending column order: counted, then filled
+  std::vector<int> cnt((size_t)NB * n, 0);
+  for (int64_t j = 0; j < n; j++) {
+    if (is_hub(j)) continue;
+    for (int p = cp[j]; p < cp[j + 1]; p++) cnt[(size_t)(rv[p] / BW) * n + j]++;
+  }
+  std::vector<int> blk_slot(1, 0), slot_g(1, 0);
+  std::vector<uint4> cw;
+  std::vector<int4> pos;
+  std::vector<int> rows;
+  auto push_group = [&](const int* first, const int* rowsp, int nl, int k0, int64_t r0, int b) {
+    for (int l = 0; l < 64; l++) {
+      unsigned cc[4] = {0, 0, 0, 0};
+      int pp[4] = {-1, -1, -1, -1};
+      unsigned lrow = 0xFFFFu;
+      if (l < nl) {
+        const int j = rowsp[l];
+        lrow = (unsigned)(j - r0);
+        for (int k = 0; k < 4; k++)
+          if (k0 + k < cnt[(size_t)b * n + j]) {
+            const int p = first[l] + k0 + k;
+            cc[k] = (unsigned)(rv[p] - b * BW);
+            pp[k] = p;
+          }
+      }
+      cw.push_back(make_uint4(cc[0] | (cc[1] << 16), cc[2] | (cc[3] << 16), lrow, 0u));
+      pos.push_back(make_int4(pp[0], pp[1], pp[2], pp[3]));
+    }
+  };
+  for (int b = 0; b < NB; b++)
+    for (int c = 0; c < NC; c++) {
+      const int64_t r0 = (int64_t)c * CH, r1 = std::min<int64_t>(r0 + CH, n);
+      rows.clear();
+      for (int64_t j = r0; j < r1; j++)
+        if (cnt[(size_t)b * n + j] > 0) rows.push_back((int)j);
+      std::stable_sort(rows.begin(), rows.end(), [&](int a, int bb) { return cnt[(size_t)b * n + a] > cnt[(size_t)b * n + bb]; });
+      for (size_t q0 = 0; q0 < rows.size(); q0 += 64) {
+        const int nl = (int)std::min<size_t>(64, rows.size() - q0);
+        const int len = cnt[(size_t)b * n + rows[q0]];
+        int first[64];   // first entry of each lane's row inside band b (a scan of the short row)
+        for (int l = 0; l < nl; l++) {
+          const int j = rows[q0 + l];
+          int p = cp[j];
+          while (rv[p] / BW != b) p++;
+          first[l] = p;
+        }
+        for (int k0 = 0; k0 < len; k0 += 4) push_group(first, rows.data() + q0, nl, k0, r0, b);
+        slot_g.push_back((int)(cw.size() / 64));
+      }
+      blk_slot.push_back((int)slot_g.size() - 1);
+    }
+  const size_t n_groups = cw.size() / 64;
+  if ((n_groups + 1) * 64 >= (size_t)1 << 31) return SDPLR_OK;
+  push_group(nullptr, nullptr, 0, 0, 0, 0);   // the all-padding dummy group
+  DevBand& bd = s->band;
+  bd = DevBand{};
+  bd.NB = NB; bd.NC = NC; bd.BW = BW; bd.CH = CH; bd.n_slots = (int)slot_g.size() - 1; bd.n_groups = (int)n_groups;
+  int rc;
+  if ((rc = upload(s, &bd.blk_slot, blk_slot))) return rc;
+  if ((rc = upload(s, &bd.slot_g, slot_g))) return rc;
+  if ((rc = upload(s, &bd.cw, cw))) return rc;
+  if ((rc = upload(s, &bd.pos, pos))) return rc;
+  if ((rc = dalloc(s, &bd.vA, cw.size()))) return rc;
+  if ((rc = dalloc(s, &bd.vB, cw.size()))) return rc;
+  HIPCK(s, hipMemsetAsync(bd.vA, 0, cw.size() * sizeof(double2), s->stream));
+  HIPCK(s, hipMemsetAsync(bd.vB, 0, cw.size() * sizeof(double2), s->stream));
+  if ((rc = dzero(s, &bd.tpart, (size_t)NB * n))) return rc;
+  if ((rc = dzero(s, &bd.textra, (size_t)n))) return rc;
+  // more than 64 KB of dynamic LDS has to be asked for
+  HIPCK(s, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lz_band), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)((size_t)(BW + CH) * sizeof(double))));
+  s->use_band = true;
+  return SDPLR_OK;
+}
+
 // lbfgs_update! rides k_fast_step2 (structured fast paths) for h ≤ 4 and 32-bit row offsets
 bool step_fuses_update(const S* s) {
   return s->h >= 1 && s->h <= 4 && s->n * s->r * 8 < (1LL << 32) && !s->no_updfuse;
@@ -610,6 +711,7 @@ int32_t sdplr_hip_finalize(S* s) {
     return upload(s, &dst.long_rows, rows);
   };
   if ((rc = plan_long(s->h_fcp, sp))) return rc;
+  if ((rc = build_band(s))) return rc;
   if ((rc = dzero(s, &sp.nzval, s->nnzS))) return rc;
   if ((rc = dzero(s, &sp.triu_nzval, s->nnzT))) return rc;
   if ((rc = dzero(s, &sp.UVt0, s->nnzT))) return rc;
@@ -657,11 +759,11 @@ int32_t sdplr_hip_finalize(S* s) {
   }
   if ((rc = dzero(s, &s->partials, (size_t)SDPLR_NSLOT * SDPLR_MAXNB))) return rc;
   for (int k = 0; k < 3; k++)
-    if ((rc = dzero(s, &s->lz_buf[k], n))) return rc;
+    if ((rc = dzero(s, &s->lz_buf[k], n + 64))) return rc;   // (k_lz_band reads a clamped 16-byte pair at a ragged band end)
   if ((rc = dzero(s, &s->lz_v0, n))) return rc;
   s->nb_lr = 256;   // (alloc_factors raises it to 1024 for large factors: n·r ≥ 4M)
   if ((rc = dzero(s, &s->lr_btx_part, (size_t)std::max(lr.ST, 1) * SDPLR_MAXNB))) return rc;
-  if ((rc = dzero(s, &s->lr_coef, std::max(lr.ST, 1)))) return rc;
+  if ((rc = dzero(s, &s->lr_coef, 2 * (size_t)std::max(lr.ST, 1)))) return rc;
   {
     DevCtrl* d = nullptr;
     if ((rc = dalloc(s, &d, 1))) return rc;
@@ -1456,6 +1558,22 @@ void note_capture_failure(S* s, const char* what) {
 // one Lanczos step = k_lz_spmv (+ hub rows) + k_lz_step on the buffer triple (uprev, u, t)
 void enq_lz_step(S* s, double* uprev, double* u, double* t) {
   const int* stop = &s->ctrl->lz_done;
+  if (s->use_band) {   // LDS-band form (k_sparse.h, DevBand): partial t per (band, chunk), summed by the recurrence kernel
+    const DevBand& bd = s->band;
+    const int nbk = bd.NB * bd.NC, nbl = s->sp.n_long_rows > 0 ? std::min(s->sp.n_long_rows, 256) : 0;
+    {
+      ProfScope ps(s, "lz_spmv");
+      // (+ 1: the grid's last block closes the previous step and does nothing else)
+      k_lz_band<<<nbk + 1, SDPLR_LZB_NT, (size_t)(bd.BW + bd.CH) * sizeof(double), s->stream>>>(bd, (int)s->n, s->ctrl, u, s->lr, s->y, s->lr_btx_part, s->nb_n, s->lr_coef, s->lz_beta, s->partials);
+      if (nbl > 0) {
+        DevLowRank none{};
+        k_spmv_long<<<nbl, SDPLR_NT, 0, s->stream>>>(s->sp, u, bd.textra, none, s->lr_coef, SLOT_LZ_A, nbk, s->partials, stop);
+      }
+    }
+    ProfScope ps(s, "lz_step");
+    k_lz_step_band<<<s->nb_n, SDPLR_NT, 0, s->stream>>>((int)s->n, s->ctrl, bd, nbl > 0 ? 1 : 0, uprev, u, t, s->lr, s->lr_coef, s->lr_btx_part, nbk + nbl, s->lz_alpha, s->partials);
+    return;
+  }
   {
     ProfScope ps(s, "lz_spmv");
     static const int lz_lpr = getenv("SDPLR_HIP_LZ_LPR") ? atoi(getenv("SDPLR_HIP_LZ_LPR")) : 8;
@@ -1488,6 +1606,10 @@ int run_lanczos(S* s, int64_t q, const double* v0, double* alpha, double* beta, 
   c->lz_done = 0; c->lz_steps = 0; c->lz_beta_prev = 0.0; c->lz_gamma_cur = 1.0; c->lz_gamma_prev = 1.0; c->lz_qmax = q;
   if ((rc = push(s))) return rc;
   double *b0 = s->lz_buf[0], *b1 = s->lz_buf[1], *b2 = s->lz_buf[2];
+  if (s->use_band) {   // S is fixed for the q steps: the band layout's values are gathered once per run
+    ProfScope ps(s, "lanczos_init");
+    k_lz_band_fill<<<blocks_for((long long)(s->band.n_groups + 1) * 64, SDPLR_NT, 2048), SDPLR_NT, 0, s->stream>>>(s->band, s->sp.nzval);
+  }
   HIPCK(s, hipMemcpyAsync(b1, v0, n * sizeof(double), hipMemcpyHostToDevice, s->stream));   // u_1 = v0
   HIPCK(s, hipMemsetAsync(b0, 0, n * sizeof(double), s->stream));                            // u_0 = 0
   HIPCK(s, hipMemsetAsync(s->lz_alpha, 0, q * sizeof(double), s->stream));

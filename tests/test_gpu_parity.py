@@ -697,3 +697,51 @@ def test_unusual_structures(hip_abi, oracle_abi, kind, r):
 def test_eigval_and_dimacs_on_gpu(hip_abi):
     from test_oracle_endtoend import _check_eigval_and_dimacs
     _check_eigval_and_dimacs(hip_abi)
+
+
+@pytest.mark.parametrize("family,bw,ch,hub", [("maxcut", 64, 16, None), ("minimum_bisection", 64, 7, None),
+                                              ("lovasz_theta", 128, 32, 8), ("mu_conductance_0.05", 64, 1000, None),
+                                              ("maxcut", 16384, 4096, 8)])
+def test_lanczos_band_form_matches_gather_form_and_oracle(hip_abi, oracle_abi, monkeypatch, family, bw, ch, hub):
+    """The Lanczos SpMV through LDS-resident bands of x (k_lz_band + k_lz_step_band) against the gather form
+    (k_lz_spmv + k_lz_step) and the oracle: small instances with the plan forced on (several narrow bands, several
+    row chunks, ragged last band / chunk, rows without entries in a band, a rank-one term, hub rows left to
+    k_spmv_long), on the S of a seeded y.  Coefficients to 1e-9 over the well-conditioned first steps, the Ritz
+    value of the whole run to 1e-6 of ‖S‖."""
+    data, C, As, bs = make_data(family, 7, 150, 0.08)
+    n = data.n
+    v0 = np.random.Generator(np.random.PCG64(12)).standard_normal(n)
+    if hub is not None:
+        monkeypatch.setenv("SDPLR_HIP_HUB_THRESH", str(hub))
+    runs = {}
+    for name in ("band", "gather", "oracle"):
+        if name == "band":
+            monkeypatch.setenv("SDPLR_HIP_LZBAND_MIN_N", "1")
+            monkeypatch.setenv("SDPLR_HIP_LZBAND_BW", str(bw))
+            monkeypatch.setenv("SDPLR_HIP_LZBAND_CH", str(ch))
+        else:
+            monkeypatch.setenv("SDPLR_HIP_NO_LZBAND", "1")
+        s_, _ = make_solver(oracle_abi if name == "oracle" else hip_abi, data, 4, seed=3)
+        # the same S on all three: a seeded y (an iterated state differs between the libraries in the 7th digit on
+        # the ill-conditioned families, which is about the solver, not about the SpMV)
+        s_.y = np.random.Generator(np.random.PCG64(44)).standard_normal(data.m + 1)
+        s_.At_preprocess()
+        ev = s_.approx_mineigval_lanczos(60, v0)
+        dual = ev
+        al, be, k = s_.lanczos(60, v0)
+        runs[name] = (dual, ev, al, be, k, s_.tridiag_mineig(al, be))
+        s_.close()
+    for other in ("gather", "oracle"):
+        a, b = runs["band"], runs[other]
+        assert a[4] == b[4] == 60
+        scale = np.max(np.abs(b[2]))
+        # comparable steps: while ε·Π(‖S‖/β_j) < 1e-10 (see test_first_iterations_match_oracle_at_baseline_size)
+        amp, K = np.finfo(float).eps, 0
+        while K < 10 and amp < 1e-10:
+            K += 1
+            amp *= scale / b[3][K - 1]
+        assert np.allclose(a[2][:K], b[2][:K], rtol=1e-9, atol=1e-12 * scale), (K, a[2][:K], b[2][:K])
+        assert np.allclose(a[3][:K], b[3][:K], rtol=1e-9, atol=1e-12 * scale)
+        # the Ritz value of the whole (unorthogonalised) run: agreement on the scale of ‖S‖, looser where the run
+        # has long lost orthogonality (the μ-conductance S has λ_max/λ_min ≈ 1e7)
+        assert abs(a[5] - b[5]) <= 1e-6 * scale and abs(a[1] - b[1]) <= 1e-6 * scale and a[1] == a[5]
