@@ -226,6 +226,23 @@ int32_t sdplr_hip_approx_mineigval_lanczos(sdplr_hip_solver* s, int64_t q, const
 int32_t sdplr_hip_dual_obj(sdplr_hip_solver* s, double trace_bound, int64_t iter,
                            const double* v0, double* dual_value, double* mineig);
 
+/* ---- high-precision eigen path / DIMACS ----------------------------------------------------------------------
+ * SDP_S_eigval(var, aux, nevs, preprocessed; which, ncv, tol, maxiter)  src/coreop.jl:351-374: the nev smallest
+ * (which = 0, :SA) or largest (which = 1, :LA) eigenvalues of the S left by the last 𝒜t_preprocess!.  The reference
+ * hands x ↦ S·x + x to GenericArpack.symeigs (implicitly restarted Lanczos) and subtracts the shift; here thick-restart
+ * Lanczos with full re-orthogonalisation runs ON THE DEVICE: the ≤ ncv basis vectors stay in HBM, the operator is the
+ * device SpMV of 𝒜t!(y, aux, x, var), and only the ncv×ncv projected matrix crosses PCIe, once per restart cycle.
+ * Convergence test: ARPACK's, |β·y_last| ≤ tol·max(eps^⅔, |θ + 1|) on the shifted operator; tol ≤ 0 ⇒ machine
+ * precision; ncv ≤ 0 ⇒ min(100, n) (:439); maxiter counts restart cycles.  v0 (HOST, length n) or NULL for a fixed
+ * internal start vector.  evals[nev] ascending for :SA, descending for :LA; *n_converged < nev ⇒ the cycle budget ran
+ * out (the values returned are the current Ritz values).                                                        */
+int32_t sdplr_hip_S_eigval(sdplr_hip_solver* s, int64_t nev, int32_t which, int64_t ncv, double tol,
+                           int64_t maxiter, const double* v0, double* evals, int64_t* n_matvec,
+                           int64_t* n_converged);
+/* dot(A, B) of two factor slots on the device: err6 of DIMACS_errors is dot(Rt, Rt·S) (src/coreop.jl:449) =
+ * At_left(SDPLR_F_SCRATCH, SDPLR_F_RT) then factor_dot(SDPLR_F_RT, SDPLR_F_SCRATCH).                            */
+int32_t sdplr_hip_factor_dot(sdplr_hip_solver* s, int32_t slot_a, int32_t slot_b, double* out);
+
 /* ---- library counters ------------------------------------------------------------------------------
  * out[0] hipGraph captures that succeeded, out[1] captures that FAILED (this handle then launches eagerly for
  * good — visible here, never silent), out[2] captures skipped because the process-wide capture lock was busy

@@ -597,6 +597,71 @@ int32_t sdplr_oracle_At_right(S* s, const double* x, double* y, int64_t k) {
 int32_t sdplr_oracle_At_right_device(S* s, const double* x, double* y, int64_t k) {
   return sdplr_oracle_At_right(s, x, y, k); /* the oracle's "device" memory is host memory */
 }
+/* SDP_S_eigval src/coreop.jl:351-374.  The reference's eigensolver (GenericArpack.symeigs) is third-party code
+ * outside the tree: PARITY UNPINNED there.  The checker computes what that solver converges to: the exact spectrum
+ * of the dense S (𝒜t! right applied to the identity, then cyclic Jacobi) — small n only. */
+int32_t sdplr_oracle_S_eigval(S* s, int64_t nev, int32_t which, int64_t ncv, double tol, int64_t maxiter,
+                              const double* v0, double* evals, int64_t* n_matvec, int64_t* n_converged) {
+  NEED_FINAL(s);
+  (void)ncv; (void)tol; (void)maxiter; (void)v0;
+  int64_t n = s->n;
+  if (!evals || nev < 1 || nev > n) return fail(s, ERR_INVALID, "S_eigval: bad args");
+  if (n > 1500) return fail(s, ERR_INVALID, "S_eigval: the dense checker handles n <= 1500");
+  double* A = dalloc(n * n);
+  double* e = dalloc(n);
+  for (int64_t j = 0; j < n; j++) {
+    memset(e, 0, (size_t)n * sizeof(double));
+    e[j] = 1.0;
+    At_right(s, A + j * n, e, 1);
+  }
+  for (int64_t i = 0; i < n; i++)
+    for (int64_t j = i + 1; j < n; j++) A[i * n + j] = A[j * n + i] = 0.5 * (A[i * n + j] + A[j * n + i]);
+  for (int sweep = 0; sweep < 100; sweep++) {
+    double off = 0.0, tot = 0.0;
+    for (int64_t i = 0; i < n; i++)
+      for (int64_t j = 0; j < n; j++) { tot += A[i * n + j] * A[i * n + j]; if (i != j) off += A[i * n + j] * A[i * n + j]; }
+    if (off <= 1e-30 * tot) break;
+    for (int64_t p = 0; p < n - 1; p++)
+      for (int64_t q = p + 1; q < n; q++) {
+        double apq = A[p * n + q];
+        if (apq == 0.0) continue;
+        double theta = (A[q * n + q] - A[p * n + p]) / (2.0 * apq);
+        double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+        double c = 1.0 / sqrt(t * t + 1.0), sn = t * c;
+        for (int64_t k = 0; k < n; k++) {
+          double akp = A[k * n + p], akq = A[k * n + q];
+          A[k * n + p] = c * akp - sn * akq;
+          A[k * n + q] = sn * akp + c * akq;
+        }
+        for (int64_t k = 0; k < n; k++) {
+          double apk = A[p * n + k], aqk = A[q * n + k];
+          A[p * n + k] = c * apk - sn * aqk;
+          A[q * n + k] = sn * apk + c * aqk;
+        }
+      }
+  }
+  for (int64_t i = 0; i < n; i++) e[i] = A[i * n + i];
+  for (int64_t i = 1; i < n; i++) { /* insertion sort, ascending */
+    double v = e[i];
+    int64_t j = i - 1;
+    while (j >= 0 && e[j] > v) { e[j + 1] = e[j]; j--; }
+    e[j + 1] = v;
+  }
+  for (int64_t i = 0; i < nev; i++) evals[i] = which == 0 ? e[i] : e[n - 1 - i];
+  if (n_matvec) *n_matvec = n;
+  if (n_converged) *n_converged = nev;
+  free(A);
+  free(e);
+  return OK;
+}
+/* dot(A, B) of two factor slots (err6 = dot(Rt, Rt·S), src/coreop.jl:449) */
+int32_t sdplr_oracle_factor_dot(S* s, int32_t slot_a, int32_t slot_b, double* out) {
+  NEED_FINAL(s);
+  double *a = factor_ptr(s, slot_a), *b = factor_ptr(s, slot_b);
+  if (!a || !b || !out) return fail(s, ERR_INVALID, "factor_dot: bad args");
+  *out = ddot(s->n * s->r, a, b);
+  return OK;
+}
 int32_t sdplr_oracle_get_stats(const S* s, int64_t* out, int32_t cap, int32_t* n_written) {
   if (!s || !out || cap < 0) return ERR_INVALID;
   int32_t k = cap < 8 ? cap : 8;

@@ -68,6 +68,10 @@ int32_t sdplr_oracle_At_right(sdplr_oracle_solver* s, const double* x_host, doub
                               int64_t k);
 int32_t sdplr_oracle_At_right_device(sdplr_oracle_solver* s, const double* x_dev, double* y_dev,
                                      int64_t k); /* the oracle's "device" is host memory */
+int32_t sdplr_oracle_S_eigval(sdplr_oracle_solver* s, int64_t nev, int32_t which, int64_t ncv, double tol,
+                              int64_t maxiter, const double* v0, double* evals, int64_t* n_matvec,
+                              int64_t* n_converged); /* exact dense spectrum (n <= 1500); PARITY UNPINNED vs symeigs */
+int32_t sdplr_oracle_factor_dot(sdplr_oracle_solver* s, int32_t slot_a, int32_t slot_b, double* out);
 int32_t sdplr_oracle_get_stats(const sdplr_oracle_solver* s, int64_t* out, int32_t cap,
                                int32_t* n_written); /* all zero: no graphs here */
 int32_t sdplr_oracle_f(sdplr_oracle_solver* s, double* lagrangian);

@@ -1,10 +1,12 @@
 #!/usr/bin/env python3
-"""BASELINE.json configs[4]: a batch of 64 MaxCut instances — Gset G1–G9 (the reference's batch,
-exps/batch_test.txt: rank 10, ptol = objtol = 0.01) + 55 seeded G(800, 0.06) graphs — sharded
-round-robin over the ranks, 8 in flight per GPU, objectives gathered with one RCCL all_gather.
+"""BASELINE.json configs[4]: a batch of MaxCut instances — by default Gset G1–G9 (the reference's batch,
+exps/batch_test.txt: rank 10, ptol = objtol = 0.01) + 55 seeded G(800, 0.06) graphs, or any manifest written by
+scripts/gen_batch_test.py (--batch file.json) — sharded round-robin over the ranks, 8 in flight per GPU,
+objectives gathered with one RCCL all_gather.  This is the reference's `parallel --jobs 9 < batch_test.txt`
+(exps/README.md:17-21) with GPUs in place of CPU jobs.
 
-    python scripts/run_batch.py                       # 1 GPU
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 scripts/run_batch.py
+    python scripts/run_batch.py [--batch scripts/batch_test.json]   # 1 GPU
+    python scripts/run_batch.py --gpus 8                            # launches its own 8 ranks (torch.distributed.run)
 """
 import json
 import os
@@ -15,19 +17,49 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-import sdplrplus_jl_amd as sj  # noqa: E402
-from sdplrplus_jl_amd import batch, problems  # noqa: E402
+from sdplrplus_jl_amd import problems  # noqa: E402  (no GPU work at import: the launcher branch runs first)
 
 
-def instances():
+def load_graph(name):
+    if name.startswith("gnp:"):
+        _, n, p, seed = name.split(":")
+        return problems.gnp_graph(int(n), float(p), int(seed))
     z = np.load(os.path.join(ROOT, "tests", "golden", "gset_G1_G9.npz"))
-    gs = [problems.graph_from_edges(int(z[f"G{k}_n"]), z[f"G{k}"]) for k in range(1, 10)]
-    gs += [problems.gnp_graph(800, 0.06, seed) for seed in range(10, 65)]
-    return gs
+    return problems.graph_from_edges(int(z[f"{name}_n"]), z[name])
+
+
+def manifest(path):
+    if path:
+        with open(path) as f:
+            return json.load(f)
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import gen_batch_test
+    return gen_batch_test.build(gen_batch_test.default_graphs(55), "MaxCut", 0, 0.01, 10)[1]
 
 
 def main():
+    import argparse
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", default=None, help="manifest written by scripts/gen_batch_test.py")
+    ap.add_argument("--gpus", type=int, default=1)
+    args = ap.parse_args()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # launcher: before this process touches torch or the HIP library (see bench.py)
+        import socket
+        import subprocess
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), "--gpus", str(args.gpus)]
+        if args.batch:
+            cmd += ["--batch", args.batch]
+        sys.exit(subprocess.call(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))))
+    import sdplrplus_jl_amd as sj
+    from sdplrplus_jl_amd import batch
     rank, local_rank, world = (int(os.environ.get(k, d)) for k, d in (("RANK", 0), ("LOCAL_RANK", 0), ("WORLD_SIZE", 1)))
+    if world != args.gpus:
+        sys.exit(f"run_batch.py: --gpus {args.gpus} but WORLD_SIZE={world}")
     dist, device = None, None
     if world > 1:   # torch before the HIP library: one HIP runtime per process (same SONAME in the torch wheel)
         import torch
@@ -37,11 +69,17 @@ def main():
         dist.init_process_group("nccl", device_id=device)
     abi = sj.load_hip()
     assert abi.set_device(local_rank) == 0
-    graphs = instances()
+    entries = manifest(args.batch)
+    builders = {"MaxCut": problems.maxcut_data, "MinimumBisection": problems.minimum_bisection_data,
+                "LovaszTheta": problems.lovasz_theta_data}
+    e0 = entries[0]
+    assert all(e["problem"] == e0["problem"] and e["rank"] == e0["rank"] and e["ptol"] == e0["ptol"] for e in entries)
+    graphs = [load_graph(e["graph"]) for e in entries]
     t0 = time.perf_counter()
     conc = int(os.environ.get("SDPLR_BATCH_CONCURRENCY", "8"))
-    local = batch.solve_local(graphs, rank, world, 10, concurrency=conc, make_data=problems.maxcut_data,
-                              ptol=0.01, objtol=0.01, seed=0, prior_trace_bound=800.0)
+    tb = 1.0 if e0["problem"] == "LovaszTheta" else float(max(g.shape[0] for g in graphs))     # exps/test.jl:166-176
+    local = batch.solve_local(graphs, rank, world, e0["rank"], concurrency=conc, make_data=builders[e0["problem"]],
+                              ptol=e0["ptol"], objtol=e0["objtol"], seed=e0["seed"], prior_trace_bound=tb)
     res = batch.gather(local, len(graphs), dist, device)
     dt = time.perf_counter() - t0
     if rank == 0:

@@ -26,25 +26,7 @@ def load_graph(name):
     return problems.graph_from_edges(int(z[f"{name}_n"]), z[name])
 
 
-def eval_cut(L, x):                      # exps/test.jl:67-69
-    return 0.25 * float(x @ (L @ x))
-
-
-def maxcut_rounding(A, R, rng):          # exps/test.jl:71-81: best of 100 random hyperplanes
-    L = problems._laplacian(A, 1.0)
-    return max(eval_cut(L, np.sign(R @ rng.standard_normal(R.shape[1]))) for _ in range(100))
-
-
-def minimumbisection_rounding(A, R, rng):  # exps/test.jl:83-98: sort the projection, split in halves
-    L = problems._laplacian(A, 1.0)
-    n = R.shape[0]
-    best = np.inf
-    for _ in range(100):
-        perm = np.argsort(R @ rng.standard_normal(R.shape[1]))
-        part = np.zeros(n)
-        part[perm] = np.where((np.arange(1, n + 1) * 2) <= n, 1.0, -1.0)
-        best = min(best, eval_cut(L, part))
-    return best
+from sdplrplus_jl_amd.rounding import maxcut_rounding, minimumbisection_rounding  # noqa: E402  (exps/test.jl:67-105)
 
 
 PROBLEMS = {  # name → (builder, rounding callback, trace bound as a function of n)   exps/test.jl:166-176

@@ -8,7 +8,7 @@ Layout: ``csrc/`` hand-written HIP kernels + the C ABI of include/sdplr_hip.h (b
 ``lib/libsdplr_hip.so``), ``cabi.py`` ctypes binding / ``DeviceSolver``, ``preprocess.py`` one-time
 host layout, ``problems.py`` SDP builders, ``sdplr.py`` host control flow, ``build.py`` hipcc recipe.
 """
-from . import batch, cabi, io, preprocess, problems, structs  # noqa: F401
+from . import batch, cabi, io, preprocess, problems, rounding, structs  # noqa: F401
 from .cabi import CABI, DeviceSolver, SdplrError, load_hip, hip_library_path  # noqa: F401
 from .preprocess import AggregatedLayout, preprocess_sparsecons  # noqa: F401
 from .sdplr import DIMACS_errors, SDP_S_eigval, _sdplr, build_solver, initial_point, sdplr  # noqa: F401

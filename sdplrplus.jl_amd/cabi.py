@@ -60,6 +60,8 @@ SIGNATURES = {
     "At_right": [_vp, _pf64, _pf64, _i64],
     "At_right_device": [_vp, _vp, _vp, _i64],
     "get_stats": [_vp, _pi64, _i32, _pi32],
+    "S_eigval": [_vp, _i64, _i32, _i64, _f64, _i64, _pf64, _pf64, _pi64, _pi64],
+    "factor_dot": [_vp, _i32, _i32, _pf64],
     "f": [_vp, _pf64],
     "g": [_vp],
     "fg": [_vp, _f64, _f64, _i32, _i32, _pf64, _pf64, _pf64],
@@ -299,6 +301,23 @@ class DeviceSolver:
             self.set_factor(F_SCRATCH + 1, Vt)
         self.A(F_SCRATCH, F_SCRATCH + 1 if Vt is not None else -1, V_SCRATCH)
         return self.get_vec(V_SCRATCH)
+
+    def S_eigval(self, nev: int = 1, which: str = "SA", ncv: int = 0, tol: float = 0.0, maxiter: int = 1000,
+                 v0: Optional[np.ndarray] = None):
+        """SDP_S_eigval's solver (src/coreop.jl:361-372) on the S left by the last 𝒜t_preprocess!, on the device
+        → (eigenvalues[nev], matvecs, converged count)."""
+        out = np.zeros(int(nev))
+        mv, nc = C.c_int64(0), C.c_int64(0)
+        v0c = _f64c(v0) if v0 is not None else None
+        self._ck(self.abi.S_eigval(self._h, int(nev), {"SA": 0, "LA": 1}[which], int(ncv), float(tol), int(maxiter),
+                                   _pd(v0c) if v0c is not None else None, _pd(out), C.byref(mv), C.byref(nc)))
+        return out, int(mv.value), int(nc.value)
+
+    def factor_dot(self, slot_a: int, slot_b: int) -> float:
+        """dot of two factor slots on the device (err6 of DIMACS_errors, src/coreop.jl:449)."""
+        v = C.c_double()
+        self._ck(self.abi.factor_dot(self._h, slot_a, slot_b, C.byref(v)))
+        return float(v.value)
 
     def stats(self) -> dict:
         """Library counters (include/sdplr_hip.h, sdplr_hip_get_stats)."""

@@ -23,6 +23,7 @@
 #include "k_dense.h"
 #include "k_scalar.h"
 #include "k_sparse.h"
+#include "k_eig.h"
 
 namespace {
 
@@ -2133,6 +2134,179 @@ int32_t sdplr_hip_dual_obj(S* s, double trace_bound, int64_t iter, const double*
   const double dv = -s->hc->descent + trace_bound * std::min(ev, 0.0);  // :412
   if (dual_value) *dual_value = dv;
   if (mineig) *mineig = ev;
+  return sync_check(s);
+}
+
+// ---- high-precision eigen path ---------------------------------------------------------------------------
+}  // extern "C"
+namespace {
+// eigen-decomposition of a small dense symmetric matrix (cyclic Jacobi): A (m×m, row-major) is destroyed,
+// w gets the eigenvalues ascending, Z (m×m) the eigenvectors as ROWS (Z[i] ↔ w[i])
+void jacobi_eigh(std::vector<double>& A, int m, std::vector<double>& w, std::vector<double>& Z) {
+  std::vector<double> Vv((size_t)m * m, 0.0);
+  for (int i = 0; i < m; i++) Vv[(size_t)i * m + i] = 1.0;
+  for (int sweep = 0; sweep < 60; sweep++) {
+    double off = 0.0, diag = 0.0;
+    for (int i = 0; i < m; i++)
+      for (int j = 0; j < m; j++) (i == j ? diag : off) += A[(size_t)i * m + j] * A[(size_t)i * m + j];
+    if (off <= 1e-30 * (diag + off) || off == 0.0) break;
+    for (int p = 0; p < m - 1; p++)
+      for (int q = p + 1; q < m; q++) {
+        const double apq = A[(size_t)p * m + q];
+        if (apq == 0.0) continue;
+        const double app = A[(size_t)p * m + p], aqq = A[(size_t)q * m + q];
+        const double theta = (aqq - app) / (2.0 * apq);
+        const double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
+        const double c = 1.0 / std::sqrt(t * t + 1.0), sn = t * c;
+        for (int k = 0; k < m; k++) {   // A ← A·J
+          const double akp = A[(size_t)k * m + p], akq = A[(size_t)k * m + q];
+          A[(size_t)k * m + p] = c * akp - sn * akq;
+          A[(size_t)k * m + q] = sn * akp + c * akq;
+        }
+        for (int k = 0; k < m; k++) {   // A ← Jᵀ·A
+          const double apk = A[(size_t)p * m + k], aqk = A[(size_t)q * m + k];
+          A[(size_t)p * m + k] = c * apk - sn * aqk;
+          A[(size_t)q * m + k] = sn * apk + c * aqk;
+        }
+        for (int k = 0; k < m; k++) {   // eigenvectors as columns of Vv
+          const double vkp = Vv[(size_t)k * m + p], vkq = Vv[(size_t)k * m + q];
+          Vv[(size_t)k * m + p] = c * vkp - sn * vkq;
+          Vv[(size_t)k * m + q] = sn * vkp + c * vkq;
+        }
+      }
+  }
+  std::vector<int> order(m);
+  for (int i = 0; i < m; i++) order[i] = i;
+  std::sort(order.begin(), order.end(), [&](int a, int b) { return A[(size_t)a * m + a] < A[(size_t)b * m + b]; });
+  w.resize(m);
+  Z.assign((size_t)m * m, 0.0);
+  for (int i = 0; i < m; i++) {
+    w[i] = A[(size_t)order[i] * m + order[i]];
+    for (int k = 0; k < m; k++) Z[(size_t)i * m + k] = Vv[(size_t)k * m + order[i]];
+  }
+}
+}  // namespace
+extern "C" {
+
+// SDP_S_eigval, src/coreop.jl:351-374 — see include/sdplr_hip.h
+int32_t sdplr_hip_S_eigval(S* s, int64_t nev, int32_t which, int64_t ncv_in, double tol, int64_t maxiter,
+                           const double* v0, double* evals, int64_t* n_matvec, int64_t* n_converged) {
+  ApiShared api_guard;
+  NEED_FINAL(s);
+  const int64_t n = s->n;
+  if (!evals || nev < 1 || nev > n || (which != 0 && which != 1) || maxiter < 1)
+    return fail(s, SDPLR_ERR_INVALID_ARG, "S_eigval: bad args");
+  int m = (int)std::min<int64_t>(n, std::max<int64_t>(ncv_in > 0 ? ncv_in : 100, std::min<int64_t>(n, 2 * nev + 1)));
+  if (m > 256) m = 256;
+  if (nev > m) return fail(s, SDPLR_ERR_INVALID_ARG, "S_eigval: nev exceeds the basis size");
+  const double eps = std::numeric_limits<double>::epsilon();
+  if (!(tol > 0)) tol = eps;                       // ARPACK: tol = 0 ⇒ machine precision
+  const long long ldv = (n + 31) / 32 * 32;
+  const int nb = blocks_for(n, SDPLR_NT, 256);
+  // scratch of this call: two bases [m + 1][ldv], the column of T being formed, β's, the rotation matrix
+  double *V = nullptr, *V2 = nullptr, *part = nullptr, *h = nullptr, *Tdev = nullptr, *bdev = nullptr, *Ydev = nullptr;
+  auto cleanup = [&]() { for (double* p : {V, V2, part, h, Tdev, bdev, Ydev}) dfree(s, p); };
+  int rc;
+#define EIG_ALLOC(ptr, cnt) if ((rc = dzero(s, &ptr, (size_t)(cnt)))) { cleanup(); return rc; }
+  EIG_ALLOC(V, (size_t)(m + 1) * ldv) EIG_ALLOC(V2, (size_t)(m + 1) * ldv) EIG_ALLOC(part, (size_t)(m + 1) * nb)
+  EIG_ALLOC(h, m + 1) EIG_ALLOC(Tdev, (size_t)m * m) EIG_ALLOC(bdev, m) EIG_ALLOC(Ydev, (size_t)m * m)
+#undef EIG_ALLOC
+  {  // start vector: the caller's v0 (the reference lets ARPACK draw one), or a fixed pseudo-random one
+    std::vector<double> st(n);
+    if (v0) std::copy(v0, v0 + n, st.begin());
+    else { unsigned long long z = 0x9E3779B97F4A7C15ull; for (int64_t i = 0; i < n; i++) { z = z * 6364136223846793005ull + 1442695040888963407ull; st[i] = (double)(z >> 11) / 9007199254740992.0 - 0.5; } }
+    hipError_t e = hipMemcpyAsync(V2, st.data(), n * sizeof(double), hipMemcpyHostToDevice, s->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
+    if (e != hipSuccess) { cleanup(); return fail(s, SDPLR_ERR_HIP, std::string("S_eigval: ") + hipGetErrorString(e)); }
+    k_sumsq<<<nb, SDPLR_NT, 0, s->stream>>>(V2, n, SLOT_V0, s->partials);
+    k_eig_scale<<<nb, SDPLR_NT, 0, s->stream>>>(V2, (int)n, SLOT_V0, nb, s->partials, bdev, 0.0, V);
+  }
+  std::vector<double> T((size_t)m * m, 0.0), theta, Y, beta(m), Tcols((size_t)m * m);
+  int k = 0;                 // vectors kept from the previous cycle (V[0..k) Ritz vectors, V[k] the new direction)
+  int64_t matvecs = 0, nconv = 0;
+  double* w = V + (size_t)m * ldv;   // row m of the basis: the vector being orthogonalised
+  for (int64_t cycle = 0; cycle < maxiter; cycle++) {
+    for (int j = k; j < m; j++) {
+      double* vj = V + (size_t)j * ldv;
+      w = V + (size_t)(j + 1) * ldv;
+      enq_spmv(s, vj, w, -1, nullptr);                                     // w = S·v_j  (𝒜t!(y, aux, x, var), :364)
+      double* tcol = Tdev + (size_t)j * m;
+      for (int pass = 0; pass < 2; pass++) {                               // classical Gram–Schmidt, twice
+        k_eig_proj<<<nb, SDPLR_NT, 0, s->stream>>>(V, ldv, j + 1, w, (int)n, part);
+        k_eig_reduce<<<(j + 1 + 3) / 4, SDPLR_NT, 0, s->stream>>>(j + 1, nb, part, h, tcol, pass);
+        k_eig_axpy<<<nb, SDPLR_NT, (size_t)(j + 1) * sizeof(double), s->stream>>>(V, ldv, j + 1, h, w, (int)n);
+      }
+      k_sumsq<<<nb, SDPLR_NT, 0, s->stream>>>(w, n, SLOT_V0, s->partials);
+      k_eig_scale<<<nb, SDPLR_NT, 0, s->stream>>>(w, (int)n, SLOT_V0, nb, s->partials, bdev + j, 1e-300, w);
+      matvecs++;
+    }
+    hipError_t e = hipMemcpyAsync(Tcols.data(), Tdev, (size_t)m * m * sizeof(double), hipMemcpyDeviceToHost, s->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(beta.data(), bdev, m * sizeof(double), hipMemcpyDeviceToHost, s->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
+    if (e == hipSuccess) e = hipGetLastError();
+    if (e != hipSuccess) { cleanup(); return fail(s, SDPLR_ERR_HIP, std::string("S_eigval: ") + hipGetErrorString(e)); }
+    // T = Vᵀ·S·V: columns k..m−1 were projected in this cycle; the leading k×k block is diag(θ) of the last one
+    double tnorm = 0.0;
+    for (int j = k; j < m; j++)
+      for (int i = 0; i <= j; i++) T[(size_t)i * m + j] = T[(size_t)j * m + i] = Tcols[(size_t)j * m + i];
+    for (int i = 0; i < m; i++) tnorm = std::max(tnorm, std::fabs(T[(size_t)i * m + i]));
+    // an invariant subspace (β at round-off level) ends the Krylov space there: exact eigenvalues of the block
+    int meff = m;
+    for (int j = k; j < m - 1; j++)
+      if (beta[j] <= 1e-13 * std::max(tnorm, 1e-300)) { meff = j + 1; break; }
+    std::vector<double> Tw((size_t)meff * meff);
+    for (int i = 0; i < meff; i++)
+      for (int j = 0; j < meff; j++) Tw[(size_t)i * meff + j] = T[(size_t)i * m + j];
+    jacobi_eigh(Tw, meff, theta, Y);
+    const double bres = meff == m ? beta[m - 1] : 0.0;
+    auto idx = [&](int i) { return which == 0 ? i : meff - 1 - i; };       // i-th wanted Ritz pair
+    nconv = 0;
+    for (int i = 0; i < (int)std::min<int64_t>(nev, meff); i++) {
+      const double res = std::fabs(bres * Y[(size_t)idx(i) * meff + (meff - 1)]);
+      // ARPACK's test on the shifted operator S + I the reference hands over (:365-366)
+      if (res <= tol * std::max(std::pow(eps, 2.0 / 3.0), std::fabs(theta[idx(i)] + 1.0))) nconv++;
+      else break;
+    }
+    if (nconv >= nev || meff < m || meff == n || cycle + 1 == maxiter) {
+      for (int i = 0; i < (int)std::min<int64_t>(nev, meff); i++) evals[i] = theta[idx(i)];
+      for (int64_t i = meff; i < nev; i++) evals[i] = std::numeric_limits<double>::quiet_NaN();
+      if (meff < m || meff == n) nconv = std::min<int64_t>(nev, meff);      // exact: the Krylov space closed
+      break;
+    }
+    // thick restart: keep the knew wanted-end Ritz vectors, then continue from the residual direction V[m]
+    const int knew = std::max((int)nev + 1, std::min(m - 1, (int)nev + (m - (int)nev) / 2));
+    std::vector<double> Yk((size_t)knew * m);
+    for (int i = 0; i < knew; i++)
+      for (int l = 0; l < m; l++) Yk[(size_t)i * m + l] = Y[(size_t)idx(i) * m + l];
+    e = hipMemcpyAsync(Ydev, Yk.data(), Yk.size() * sizeof(double), hipMemcpyHostToDevice, s->stream);
+    if (e != hipSuccess) { cleanup(); return fail(s, SDPLR_ERR_HIP, std::string("S_eigval: ") + hipGetErrorString(e)); }
+    k_eig_rotate<<<nb, SDPLR_NT, 0, s->stream>>>(V, ldv, m, Ydev, knew, V2, (int)n);
+    e = hipMemcpyAsync(V2 + (size_t)knew * ldv, V + (size_t)m * ldv, n * sizeof(double), hipMemcpyDeviceToDevice, s->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(s->stream);   // (Yk lives on this frame)
+    if (e != hipSuccess) { cleanup(); return fail(s, SDPLR_ERR_HIP, std::string("S_eigval: ") + hipGetErrorString(e)); }
+    std::swap(V, V2);
+    std::fill(T.begin(), T.end(), 0.0);
+    for (int i = 0; i < knew; i++) T[(size_t)i * m + i] = theta[idx(i)];
+    k = knew;
+  }
+  if (n_matvec) *n_matvec = matvecs;
+  if (n_converged) *n_converged = nconv;
+  rc = sync_check(s);
+  cleanup();
+  return rc;
+}
+
+// dot of two factor-shaped arrays on the device (err6 = dot(Rt, Rt·S), src/coreop.jl:449)
+int32_t sdplr_hip_factor_dot(S* s, int32_t slot_a, int32_t slot_b, double* out) {
+  ApiShared api_guard;
+  NEED_FINAL(s);
+  double *a = factor_ptr(s, slot_a), *b = factor_ptr(s, slot_b);
+  if (!a || !b || !out) return fail(s, SDPLR_ERR_INVALID_ARG, "factor_dot: bad args");
+  k_dot_flat<<<s->nb_dense, SDPLR_NT, 0, s->stream>>>(a, b, s->N, SLOT_DUALYB, s->partials);
+  k_reduce_slot<<<1, SDPLR_NT, 0, s->stream>>>(&s->ctrl->descent, SLOT_DUALYB, s->nb_dense, s->partials);
+  int rc = pull(s);
+  if (rc) return rc;
+  *out = s->hc->descent;
   return sync_check(s);
 }
 

@@ -76,25 +76,20 @@ def _load_point(s: DeviceSolver, data: SDPData, r: int, config: BurerMonteiroCon
 
 def SDP_S_eigval(var: DeviceSolver, nevs: int = 1, preprocessed: bool = False, *, which: str = "SA",
                  ncv: Optional[int] = None, tol: float = 0.0, maxiter: int = 1000000, v0=None) -> np.ndarray:
-    """``SDP_S_eigval`` (src/coreop.jl:351-374): smallest eigenvalues of S through ARPACK on the shifted
-    operator x ↦ S·x + x.  The reference calls GenericArpack.symeigs (a Julia port of ARPACK); here the
-    same implicitly restarted Lanczos runs in scipy's ARPACK binding on the host, with the operator
-    applied on the device (``𝒜t!(y, aux, x, var)``, src/coreop.jl:281-300).  ``preprocessed=False``
-    refreshes S from the current y first (the reference's branch :358-360 calls 𝒜t_preprocess! with
-    swapped arguments and has no method; every caller passes ``true``)."""
-    from scipy.sparse.linalg import LinearOperator, eigsh
+    """``SDP_S_eigval`` (src/coreop.jl:351-374): the ``nevs`` smallest eigenvalues of S.  The reference hands
+    x ↦ S·x + x to GenericArpack.symeigs (implicitly restarted Lanczos) and cancels the shift; here the same kind of
+    solver — thick-restart Lanczos with full re-orthogonalisation — runs on the device behind
+    ``sdplr_hip_S_eigval``: basis vectors and operator (``𝒜t!(y, aux, x, var)``, src/coreop.jl:281-300) stay in HBM.
+    ``preprocessed=False`` refreshes S from the current y first (the reference's branch :358-360 calls
+    𝒜t_preprocess! with swapped arguments and has no method; every caller passes ``true``)."""
     if not preprocessed:
         var.At_preprocess()
     n = var.n
-    op = LinearOperator((n, n), matvec=lambda x: var.At_right(np.asarray(x, dtype=np.float64).ravel()) + x.ravel(),
-                        dtype=np.float64)            # shift the matrix by I (:365-366)
-    if n <= max(nevs + 1, 3):                         # ARPACK needs k < n − 1: tiny problems go dense
-        S = np.column_stack([op.matvec(e) for e in np.eye(n)])
-        return np.sort(np.linalg.eigvalsh((S + S.T) / 2))[:nevs] - 1.0
     ncv = min(ncv if ncv is not None else min(100, n), n)
-    ncv = max(ncv, min(n, 2 * nevs + 1))
-    vals = eigsh(op, k=nevs, which=which, ncv=ncv, tol=tol, maxiter=maxiter, v0=v0, return_eigenvectors=False)
-    return np.sort(np.real(vals)) - 1.0               # cancel the shift (:372)
+    vals, _matvecs, nconv = var.S_eigval(nevs, which, ncv, tol, min(int(maxiter), 100000), v0)
+    if nconv < nevs:
+        print(f"Warning: SDP_S_eigval: {nconv} of {nevs} eigenvalues converged.", file=sys.stderr)
+    return np.sort(vals)
 
 
 def DIMACS_errors(data: SDPData, var: DeviceSolver) -> np.ndarray:
@@ -113,9 +108,8 @@ def DIMACS_errors(data: SDPData, var: DeviceSolver) -> np.ndarray:
     obj = var.obj
     λb = float(λ @ data.b)
     err5 = (obj - λb) / (1.0 + abs(obj) + abs(λb))
-    Rt = var.Rt
-    var.At_left(cabi.F_GT, cabi.F_RT)                  # Rt·S (:449); Gt is recomputed by the next g!
-    err6 = float(np.sum(Rt * var.Gt)) / (1.0 + abs(obj) + abs(λb))
+    var.At_left(cabi.F_SCRATCH, cabi.F_RT)             # Rt·S (:449) into a scratch slot: one device dot, no download
+    err6 = var.factor_dot(cabi.F_RT, cabi.F_SCRATCH) / (1.0 + abs(obj) + abs(λb))
     return np.array([err1, err2, err3, err4, err5, err6])
 
 

@@ -10,6 +10,7 @@ import os
 
 import numpy as np
 import pytest
+import scipy.sparse as sp
 
 import sdplrplus_jl_amd as sj
 from sdplrplus_jl_amd import batch, cabi, problems
@@ -220,3 +221,39 @@ def test_scratch_slots_and_device_vectors(hip_abi, oracle_abi):
     hip.hipFree(dx); hip.hipFree(dy)
     assert g.stats()["graph_capture_failures"] == 0
     g.close()
+
+
+def test_device_eigensolver_against_arpack(hip_abi):
+    """SDP_S_eigval on the device (thick-restart Lanczos, basis in HBM; src/coreop.jl:351-374) against scipy's ARPACK
+    applied to the same S on the host: the two smallest eigenvalues to 1e-8 of ‖S‖ — MaxCut n = 2·10⁴ (sparse S) and
+    MinBisection n = 2·10⁴ (S with a rank-one term, λ_max ≫ |λ_min|); and DIMACS err6 = ⟨Rt, Rt·S⟩ as one device dot."""
+    from scipy.sparse.linalg import LinearOperator, eigsh
+    for builder, seed in ((problems.maxcut_data, 11), (problems.minimum_bisection_data, 12)):
+        A = problems.gnp_graph(20_000, 6e-4, seed)
+        data = builder(A)
+        n, m = data.n, data.m
+        g, _ = make_solver(hip_abi, data, 8, seed=seed)
+        normC, normb = data.normC(), float(np.linalg.norm(data.b))
+        st = g.fg(normC, normb)
+        g.inner_loop(normC, normb, True, True, False, 0.0, -1e300, 30, 0.0, *st)
+        g.dual_obj(float(n), 0, np.ones(n))                      # y = copy2y_λ_sub_pvio!, S current
+        y = g.y
+        S = sp.csr_matrix(data.C) + sp.diags(y[:n])
+        lowrank = y[n] if data.lowrank else 0.0
+        Sop = LinearOperator((n, n), matvec=lambda x: S @ x + lowrank * np.ones(n) * np.sum(x), dtype=np.float64)
+        ref = np.sort(eigsh(Sop, k=2, which="SA", tol=1e-10, ncv=60)[0])
+        scale = max(abs(ref[0]), float(abs(S).sum(axis=1).max()), abs(lowrank) * n)
+        v0 = np.random.Generator(np.random.PCG64(1)).standard_normal(n)
+        ev = sj.SDP_S_eigval(g, 2, True, which="SA", ncv=60, tol=1e-10, v0=v0)
+        assert np.max(np.abs(ev - ref)) <= 1e-8 * scale, (ev, ref)
+        vals, matvecs, nconv = g.S_eigval(2, "SA", 60, 1e-10, 1000, v0)
+        assert nconv == 2 and matvecs >= 60
+        la = g.S_eigval(1, "LA", 40, 1e-8, 1000, v0)[0][0]
+        assert la == pytest.approx(eigsh(Sop, k=1, which="LA", tol=1e-10)[0][0], rel=1e-7)
+        # err6 numerator on the device vs numpy
+        R = g.Rt
+        g.At_left(cabi.F_SCRATCH, cabi.F_RT)
+        xz = g.factor_dot(cabi.F_RT, cabi.F_SCRATCH)
+        ref_xz = float(np.sum(R * (S @ R + lowrank * np.outer(np.ones(n), R.sum(axis=0)))))
+        assert xz == pytest.approx(ref_xz, rel=1e-10, abs=1e-8 * scale)
+        g.close()
