@@ -442,7 +442,11 @@ k_lz_update2(DevCtrl* __restrict__ c, int n, int step, double* __restrict__ Av, 
 // solve the quartic (src/linesearch.jl:44-112), decide the relative-decrease exit (src/sdplr.jl:238-241),
 // commit the extra slots (src/linesearch.jl:118-124, src/coreop.jl:229-236) and prepare the low-rank
 // coefficients WS of the moved point.
-__global__ void __launch_bounds__(SDPLR_NT)
+// The sums come from ≤ 1024 partials each, fetched four per thread in one round trip (unconditional loads: the slot
+// arrays are SDPLR_MAXNB wide); `red2` ≠ null: sums 8 and 9 (the big matrix) were already folded by k_edge_sums.
+#define SDPLR_LSF_NT SDPLR_NT
+#define SDPLR_LSF_EXMAX 16
+__global__ void __launch_bounds__(SDPLR_LSF_NT)
 k_ls_solve_fast(DevCtrl* __restrict__ c, int m, int gid_g, int n_extra, const int* __restrict__ extra,
                 int nb, double* __restrict__ A_RD, double* __restrict__ A_DD,
                 const double* __restrict__ lam, const double* __restrict__ lam_ub,
@@ -450,8 +454,9 @@ k_ls_solve_fast(DevCtrl* __restrict__ c, int m, int gid_g, int n_extra, const in
                 double* __restrict__ y, int lr_ST, int r, const int* __restrict__ lr_col_gid,
                 const double* __restrict__ lr_D, double* __restrict__ lrW, double* __restrict__ lrWS,
                 const double* __restrict__ partials, int check_done,
-                int lr_tail, int lr_n, const int* __restrict__ lr_mat_ptr, const int* __restrict__ lr_mat_gid) {
-  __shared__ double sh[10 * (SDPLR_NT / 64)];
+                int lr_tail, int lr_n, const int* __restrict__ lr_mat_ptr, const int* __restrict__ lr_mat_gid,
+                const double* __restrict__ red2 = nullptr) {
+  __shared__ double sh[10 * (SDPLR_LSF_NT / 64)];
   const int dn = check_done ? c->done : 0;
   // every scalar the serial part needs, requested up front: their latency overlaps the partial sums below
   // instead of forming a chain of dependent global round trips in thread 0
@@ -461,14 +466,47 @@ k_ls_solve_fast(DevCtrl* __restrict__ c, int m, int gid_g, int n_extra, const in
     rd_m = A_RD[m];
     dd_m = A_DD[m];
   }
+  // the extra slots' own data (≤ SDPLR_LSF_EXMAX of them staged; more fall back to global reads), fetched by one thread
+  // each alongside the partials: the serial part below then reads LDS instead of chaining global round trips
+  __shared__ int ex_k[SDPLR_LSF_EXMAX];
+  __shared__ double ex_v[SDPLR_LSF_EXMAX][4];   // λ, λ_ub, primal_vio_raw, lb
+  if ((int)threadIdx.x < n_extra && threadIdx.x < SDPLR_LSF_EXMAX) {
+    const int k = extra[threadIdx.x];
+    ex_k[threadIdx.x] = k;
+    const int kc = min(k, m - (m > 0));
+    ex_v[threadIdx.x][0] = lam[kc];
+    ex_v[threadIdx.x][1] = lam_ub[kc];
+    ex_v[threadIdx.x][2] = pv_raw[k];
+    ex_v[threadIdx.x][3] = lb[kc];
+  }
   double s[10];
+  {
+    constexpr int PT = 4;
+    double v[10][PT];
 #pragma unroll
-  for (int k = 0; k < 10; k++) s[k] = 0.0;
-  for (int i = threadIdx.x; i < nb; i += SDPLR_NT) {
+    for (int q = 0; q < PT; q++) {
+      const int i = (int)threadIdx.x + SDPLR_LSF_NT * q;
 #pragma unroll
-    for (int k = 0; k < 8; k++) s[k] += slot_partials(partials, SLOT_LS + k)[i];
-    s[8] += slot_partials(partials, SLOT_PD)[i];
-    s[9] += slot_partials(partials, SLOT_DW)[i];
+      for (int k = 0; k < 8; k++) v[k][q] = slot_partials(partials, SLOT_LS + k)[i];
+      v[8][q] = slot_partials(partials, SLOT_PD)[i];
+      v[9][q] = slot_partials(partials, SLOT_DW)[i];
+    }
+#pragma unroll
+    for (int k = 0; k < 10; k++) {
+      s[k] = 0.0;
+#pragma unroll
+      for (int q = 0; q < PT; q++) s[k] += ((int)threadIdx.x + SDPLR_LSF_NT * q < nb) ? v[k][q] : 0.0;
+    }
+    for (int i = threadIdx.x + PT * SDPLR_LSF_NT; i < nb; i += SDPLR_LSF_NT) {
+#pragma unroll
+      for (int k = 0; k < 8; k++) s[k] += slot_partials(partials, SLOT_LS + k)[i];
+      s[8] += slot_partials(partials, SLOT_PD)[i];
+      s[9] += slot_partials(partials, SLOT_DW)[i];
+    }
+    if (red2) {
+      s[8] = (threadIdx.x == 0) ? red2[0] : 0.0;
+      s[9] = (threadIdx.x == 0) ? red2[1] : 0.0;
+    }
   }
   if (dn) return;
   if (lr_tail) {
@@ -476,7 +514,7 @@ k_ls_solve_fast(DevCtrl* __restrict__ c, int m, int gid_g, int n_extra, const in
     // A_RD[gid] = 2·Σ_c D_c⟨W0_c, W1_c⟩, A_DD[gid] = Σ_c D_c‖W1_c‖², from the projections W = [RᵀB; DᵀB]
     const int per = lr_ST * r;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    for (int t = wave; t < lr_n; t += SDPLR_NT / 64) {   // one wave per matrix, lanes over the rank
+    for (int t = wave; t < lr_n; t += SDPLR_LSF_NT / 64) {   // one wave per matrix, lanes over the rank
       double s0 = 0.0, s1 = 0.0;
       for (int cc = lr_mat_ptr[t]; cc < lr_mat_ptr[t + 1]; cc++) {
         double d0 = 0.0, d1 = 0.0;
@@ -497,17 +535,38 @@ k_ls_solve_fast(DevCtrl* __restrict__ c, int m, int gid_g, int n_extra, const in
     rd_m = A_RD[m];
     dd_m = A_DD[m];
   }
-  block_sum<10>(s, sh);
+  {  // block sums over the 16 waves, fixed order
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+    for (int k = 0; k < 10; k++) s[k] = wave_sum(s[k]);
+    __syncthreads();
+    if (lane == 0) {
+#pragma unroll
+      for (int k = 0; k < 10; k++) sh[k * (SDPLR_LSF_NT / 64) + wave] = s[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 10; k++) {
+      double t = 0.0;
+#pragma unroll
+      for (int w = 0; w < SDPLR_LSF_NT / 64; w++) t += sh[k * (SDPLR_LSF_NT / 64) + w];
+      s[k] = t;
+    }
+  }
   __shared__ double sh_alpha;
   __shared__ int sh_err;
   if (threadIdx.x == 0) {
     const double g_rd = s[8] + s[8], g_dd = s[9];
-    A_RD[gid_g] = g_rd;   // ⟨A_g, RDᵀ+DRᵀ⟩ = 2⟨P, D⟩
-    A_DD[gid_g] = g_dd;   // ⟨A_g, DDᵀ⟩ = ⟨D, W⟩
+    if (gid_g >= 0) {     // (−1: the edge path without a multi-entry matrix)
+      A_RD[gid_g] = g_rd;   // ⟨A_g, RDᵀ+DRᵀ⟩ = 2⟨P, D⟩
+      A_DD[gid_g] = g_dd;   // ⟨A_g, DDᵀ⟩ = ⟨D, W⟩
+    }
     for (int t = 0; t < n_extra; t++) {
-      const int k = extra[t];
+      const bool st = t < SDPLR_LSF_EXMAX;
+      const int k = st ? ex_k[t] : extra[t];
       if (k >= m) continue;
-      const double l = lam[k], nq0 = pv_raw[k], q1 = (k == gid_g) ? g_rd : A_RD[k], q2 = (k == gid_g) ? g_dd : A_DD[k];
+      const double l = st ? ex_v[t][0] : lam[k], nq0 = st ? ex_v[t][2] : pv_raw[k];
+      const double q1 = (k == gid_g) ? g_rd : A_RD[k], q2 = (k == gid_g) ? g_dd : A_DD[k];
       s[0] += l * nq0;
       s[1] += nq0 * nq0;
       s[2] += l * q1;
@@ -540,18 +599,19 @@ k_ls_solve_fast(DevCtrl* __restrict__ c, int m, int gid_g, int n_extra, const in
       // commit of the extra slots
       double pv2 = 0.0;
       for (int t = 0; t < n_extra; t++) {
-        const int k = extra[t];
+        const bool st = t < SDPLR_LSF_EXMAX;
+        const int k = st ? ex_k[t] : extra[t];
         const double q1 = (k == gid_g) ? g_rd : A_RD[k], q2 = (k == gid_g) ? g_dd : A_DD[k];
-        const double v = pv_raw[k] + a * (a * q2 + q1);
+        const double v = (st ? ex_v[t][2] : pv_raw[k]) + a * (a * q2 + q1);
         pv_raw[k] = v;
         if (k == m) {
           c->obj = v;
           y[m] = 1.0;
         } else {
-          const double pc = fmax(v, lb[k]);
+          const double pc = fmax(v, st ? ex_v[t][3] : lb[k]);
           pv[k] = pc;
           pv2 += pc * pc;
-          y[k] = -fmin(lam_ub[k], lam[k] - sigma * v);
+          y[k] = -fmin(st ? ex_v[t][1] : lam_ub[k], (st ? ex_v[t][0] : lam[k]) - sigma * v);
         }
       }
       c->pv2_extra = pv2;
@@ -561,7 +621,7 @@ k_ls_solve_fast(DevCtrl* __restrict__ c, int m, int gid_g, int n_extra, const in
   if (sh_err != 0) return;
   const double a = sh_alpha;
   const int per = lr_ST * r;
-  for (int t = threadIdx.x; t < per; t += SDPLR_NT) {  // W0 ← W0 + α·W1 = R_newᵀB ; WS = y·D·W0
+  for (int t = threadIdx.x; t < per; t += SDPLR_LSF_NT) {  // W0 ← W0 + α·W1 = R_newᵀB ; WS = y·D·W0
     const double w = lrW[t] + a * lrW[per + t];
     lrW[t] = w;
     lrWS[t] = y[lr_col_gid[t / r]] * lr_D[t / r] * w;

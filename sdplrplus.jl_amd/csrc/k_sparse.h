@@ -32,6 +32,21 @@ struct DevSparse {
   // rows of the full pattern with more than long_thresh nonzeros (hub vertices): one block each (spmm_long_rows)
   int n_long_rows, long_thresh;
   const int* long_rows;
+  // "edge path" (disjoint supports: every position of the pattern belongs to at most one matrix — Lovász-θ's one
+  // constraint per edge): the owner of each position, so that S need not be assembled and 𝒜 needs no segment pass
+  const int* q_gid;        // [nnzT] slot of the owning matrix in the (m+1)-vectors, −1 ⇒ none
+  const double* q_two;     // [nnzT] its nzval_two (value ×2 off the diagonal, src/preprocess.jl:124-131)
+  const double* q_rec;     // [nnzT][4] the same as one 32-byte record per position: {row | col << 32, gid, two, 0}
+                           //           (bit patterns): four lanes of a group fetch it with ONE load instruction
+  const int* s_gid;        // [nnzS] the same per entry of the full pattern …
+  const double* s_one;     // [nnzS] … with nzval_one: S.nzval[p] = s_one[p]·y[s_gid[p]]   (src/coreop.jl:205-227)
+  int big_gid;             // the one matrix with several entries (Lovász-θ: the identity), −1 ⇒ none
+  // S assembly by owner (k_edge_step): the ≤ 2 full-pattern entries of each single-entry matrix, and the big one's
+  const int* own_pos;      // [2(m+1)] positions p0, p1 in the full pattern of slot k's matrix, −1 ⇒ none
+  const double* own_one;   // [m+1]    its nzval_one
+  int n_big_pos;
+  const int* big_pos;      // [n_big_pos] full-pattern positions of the big matrix's entries
+  const double* big_one;   // [n_big_pos]
 };
 
 struct DevLowRank {
@@ -364,12 +379,23 @@ __device__ __forceinline__ void upd_flush(const UpdCtx& u, DevCtrl* c, double* p
 // low-rank product of src/structs.jl:135-145 prepared by k_lr_finalize.
 // (bid, nblk: this block's index and the number of blocks working on the short rows — the body is shared by
 // k_spmm and by k_spmm_both, where the hub-row blocks come first in the same grid)
-template <int LPR, int VEC, int HMU = 0>
+// S value of full-pattern entry p: the assembled array, or (EDGE) the owner's y on the fly
+template <bool EDGE>
+__device__ __forceinline__ double s_value(const DevSparse& sp, const double* __restrict__ yv, int p) {
+  if constexpr (EDGE) {
+    const int g = sp.s_gid[p];
+    return g >= 0 ? sp.s_one[p] * yv[g] : 0.0;
+  } else {
+    return sp.nzval[p];
+  }
+}
+
+template <int LPR, int VEC, int HMU = 0, bool EDGE = false>
 __device__ __forceinline__ void
 spmm_rows(DevSparse sp, const double* __restrict__ X, double* Y, int r, double scale,
           DevLowRank lr, const double* __restrict__ WS, int slot, double* __restrict__ partials,
           const DevCtrl* __restrict__ c, int check_done, const double* __restrict__ Xdot, int bid, int nblk,
-          const UpdCtx* u = nullptr) {
+          const UpdCtx* u = nullptr, const double* __restrict__ yv = nullptr) {
   __shared__ double sh[8];
   if (check_done && c->done) return;
   constexpr int G = SDPLR_NT / LPR;
@@ -390,7 +416,7 @@ spmm_rows(DevSparse sp, const double* __restrict__ X, double* Y, int r, double s
       for (int base = beg; base < end; base += LPR) {
         const int cnt = min(LPR, end - base);
         const int my_i = (lane < cnt) ? sp.rowval[base + lane] : 0;
-        const double my_v = (lane < cnt) ? sp.nzval[base + lane] : 0.0;
+        const double my_v = (lane < cnt) ? s_value<EDGE>(sp, yv, base + lane) : 0.0;
         for (int k0 = 0; k0 < cnt; k0 += 8) {
           vecd<VEC> x[8];
           double v[8];
@@ -603,21 +629,26 @@ k_lr_finalize(DevLowRank lr, int r, int F, int nb, const double* __restrict__ lr
   }
 }
 
-// first stage of k_lr_finalize alone, one wave per output and four outputs per block: used when the partials
-// come from many blocks (k_spmm_tile's fused projections) and one block would spend its time reading them
+// first stage of k_lr_finalize alone: used when the partials come from many blocks (the fused projections of
+// k_spmm_tile / k_sddmm_edge) and one block would spend its time reading them.  One BLOCK per output; its ≤ 4096
+// partials are fetched 16 per thread in one round trip (clamped, unconditional) and summed in a fixed order.
 __global__ void __launch_bounds__(SDPLR_NT)
 k_lr_reduce(int nout, int nb, const double* __restrict__ lr_part, double* __restrict__ W,
             const DevCtrl* __restrict__ c, int check_done) {
+  __shared__ double sh[8];
   const int dn = check_done ? c->done : 0;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int t = blockIdx.x * (SDPLR_NT / 64) + wave;
-  if (t >= nout) return;
+  const int t = blockIdx.x;
   const double* p = lr_part + (long long)t * nb;
+  double v[16];
+#pragma unroll
+  for (int q = 0; q < 16; q++) v[q] = p[min((int)threadIdx.x + SDPLR_NT * q, nb - 1)];
   double s = 0.0;
-  for (int b = lane; b < nb; b += 64) s += p[b];
-  s = wave_sum(s);
+#pragma unroll
+  for (int q = 0; q < 16; q++) s += ((int)threadIdx.x + SDPLR_NT * q < nb) ? v[q] : 0.0;
+  for (int b = threadIdx.x + 16 * SDPLR_NT; b < nb; b += SDPLR_NT) s += p[b];
+  s = block_sum1(s, sh);
   if (dn) return;
-  if (lane == 0) W[t] = s;
+  if (threadIdx.x == 0) W[t] = s;
 }
 
 // ⟨B[c], x⟩ partials for the SpMV low-rank term; grid.y = column
@@ -1435,12 +1466,12 @@ k_spmm_tile(DevTile tl, int n, int m, DevFast ff, const double* __restrict__ R, 
 // Same result as k_spmm for those rows (which k_spmm skips): the row's nonzeros are dealt round-robin to the
 // block's sub-wave groups, the group partials are added in group order (deterministic).  Partials of the
 // norm / dot go to slot entries [pbase, pbase + n_long_rows).
-template <int LPR, int VEC, int HMU = 0>
+template <int LPR, int VEC, int HMU = 0, bool EDGE = false>
 __device__ __forceinline__ void
 spmm_long_rows(DevSparse sp, const double* __restrict__ X, double* Y, int r, double scale,
                DevLowRank lr, const double* __restrict__ WS, int slot, int pbase, double* __restrict__ partials,
                const DevCtrl* __restrict__ c, int check_done, const double* __restrict__ Xdot, int bid, int nblk,
-               const UpdCtx* u = nullptr) {
+               const UpdCtx* u = nullptr, const double* __restrict__ yv = nullptr) {
   __shared__ double shg[SDPLR_NT * VEC];
   __shared__ double sh[8];
   if (check_done && c->done) return;
@@ -1464,7 +1495,7 @@ spmm_long_rows(DevSparse sp, const double* __restrict__ X, double* Y, int r, dou
 #pragma unroll
         for (int q = 0; q < 8; q++) {
           ii[q] = sp.rowval[p + q * G];
-          vv[q] = sp.nzval[p + q * G];
+          vv[q] = s_value<EDGE>(sp, yv, p + q * G);
         }
 #pragma unroll
         for (int q = 0; q < 8; q++) xx[q] = ldrow<VEC>(X + ii[q] * r + ch);
@@ -1475,7 +1506,7 @@ spmm_long_rows(DevSparse sp, const double* __restrict__ X, double* Y, int r, dou
       }
       for (; p + 3 * G < end; p += 4 * G) {  // four
         const long long i0 = sp.rowval[p], i1 = sp.rowval[p + G], i2 = sp.rowval[p + 2 * G], i3 = sp.rowval[p + 3 * G];
-        const double v0 = sp.nzval[p], v1 = sp.nzval[p + G], v2 = sp.nzval[p + 2 * G], v3 = sp.nzval[p + 3 * G];
+        const double v0 = s_value<EDGE>(sp, yv, p), v1 = s_value<EDGE>(sp, yv, p + G), v2 = s_value<EDGE>(sp, yv, p + 2 * G), v3 = s_value<EDGE>(sp, yv, p + 3 * G);
         const vecd<VEC> x0 = ldrow<VEC>(X + i0 * r + ch), x1 = ldrow<VEC>(X + i1 * r + ch);
         const vecd<VEC> x2 = ldrow<VEC>(X + i2 * r + ch), x3 = ldrow<VEC>(X + i3 * r + ch);
 #pragma unroll
@@ -1488,7 +1519,7 @@ spmm_long_rows(DevSparse sp, const double* __restrict__ X, double* Y, int r, dou
       }
       for (; p < end; p += G) {
         const long long i = sp.rowval[p];
-        const double v = sp.nzval[p];
+        const double v = s_value<EDGE>(sp, yv, p);
         const vecd<VEC> x = ldrow<VEC>(X + i * r + ch);
 #pragma unroll
         for (int k = 0; k < VEC; k++) acc.v[k] += x.v[k] * v;
@@ -1551,19 +1582,20 @@ k_spmm_both(DevSparse sp, const double* __restrict__ X, double* __restrict__ Y, 
 
 // G = 2·R·S of the in-loop g! with lbfgs_update! riding along (see upd_row): hub blocks first, then short rows;
 // every block contributes one entry to each Gram partial slot (hub block b → b, short block b → nb_long + b)
-template <int LPR, int VEC, int HMU>
+// EDGE: S is not read from its assembled array — entry p is s_one[p]·y[s_gid[p]] (see DevSparse, "edge path")
+template <int LPR, int VEC, int HMU, bool EDGE = false>
 __global__ void __launch_bounds__(SDPLR_NT)
 k_spmm_both_upd(DevSparse sp, const double* __restrict__ X, double* Y, int r, double scale, DevLowRank lr,
                 const double* __restrict__ WS, int slot, double* __restrict__ partials, DevCtrl* __restrict__ c,
-                int nb_long, FactorArena A, int h, const double* __restrict__ D) {
+                int nb_long, FactorArena A, int h, const double* __restrict__ D, const double* __restrict__ yv = nullptr) {
   extern __shared__ double upd_accl[];
   if (c->done) return;
   const UpdCtx u = upd_ctx<HMU>(c, A, h, D, upd_accl);
   const int nb_short = gridDim.x - nb_long;
   if ((int)blockIdx.x < nb_long)
-    spmm_long_rows<LPR, VEC, HMU>(sp, X, Y, r, scale, lr, WS, slot, nb_short, partials, c, 0, nullptr, blockIdx.x, nb_long, &u);
+    spmm_long_rows<LPR, VEC, HMU, EDGE>(sp, X, Y, r, scale, lr, WS, slot, nb_short, partials, c, 0, nullptr, blockIdx.x, nb_long, &u, yv);
   else
-    spmm_rows<LPR, VEC, HMU>(sp, X, Y, r, scale, lr, WS, slot, partials, c, 0, nullptr, blockIdx.x - nb_long, nb_short, &u);
+    spmm_rows<LPR, VEC, HMU, EDGE>(sp, X, Y, r, scale, lr, WS, slot, partials, c, 0, nullptr, blockIdx.x - nb_long, nb_short, &u, yv);
   upd_flush<HMU>(u, c, partials, blockIdx.x, blockIdx.x == 0);
 }
 
@@ -1744,6 +1776,270 @@ k_lz_step(int n, DevCtrl* __restrict__ c, const double* __restrict__ uprev, cons
     const long long st = c->lz_steps;
     alpha_out[st] = al;
     c->lz_steps = st + 1;                                       // iter += 1 (:482)
+  }
+}
+
+// ================================================================================================
+// Edge path (Lovász-θ and alike): the sparse matrices have DISJOINT supports and all but at most one of them a
+// single entry of the upper-triangular pattern (one constraint per edge; the exception is the identity).  Then
+//   𝒜(·)_k = two_q·UVt[q] for the one position q of matrix k — written by the SDDMM lane that holds the dot, no
+//            segmented reduction (src/coreop.jl:80-90) and no UVt round trip; the big matrix is a plain sum;
+//   S_p   = s_one[p]·y[s_gid[p]]  — gathered by the SpMM itself, no assembly pass (src/coreop.jl:205-227).
+// One inner iteration is 7 launches instead of 12: seam, direction, this kernel, projection sums, scalar stage
+// (k_ls_solve_fast: the big matrix and the low-rank matrices are its "extra slots"), step (R += αD ‖ commit),
+// SpMM + lbfgs_update!.
+// ================================================================================================
+// Both line-search passes (src/linesearch.jl:10-16) in one sweep over the pattern, as k_sddmm<…,2>, plus:
+// A_RD/A_DD of the single-entry matrices, the big matrix's sums (block partials → SLOT_PD: half of it, SLOT_DW) and
+// — LRN = 1, every row has a diagonal position — the projections RᵀB, DᵀB of the one low-rank column on the
+// diagonal positions (src/coreop.jl:125-126).
+// The kernel is bound by the NUMBER of vector-memory instructions a CU can issue (one wave instruction per ≈ 16
+// cycles whatever its width — the Lanczos band kernel taught that), not by bytes: with row, column, owner, weight,
+// λ, primal_vio_raw and B fetched by seven separate (group-uniform) loads per position it took 42 µs against 21 µs
+// for the bare k_sddmm<…,2> with its two.  So the per-position scalars come as ONE load — lanes 0..3 of the group
+// fetch the four words of a 32-byte record and hand them round by DPP broadcast — and the line-search sums of the
+// single-entry matrices moved to k_edge_sums, which reads λ and primal_vio_raw coalesced.
+#ifndef SDPLR_EDGE_POS
+#define SDPLR_EDGE_POS 2   /* pattern positions per sub-wave group and trip (1 and 2 equal, 4: 196 VGPRs, slower) */
+#endif
+template <int LPR, int VEC, int LRN>
+__global__ void __launch_bounds__(SDPLR_NT)
+k_sddmm_edge(DevSparse sp, int m, const double* __restrict__ U, const double* __restrict__ V, int r,
+             double* __restrict__ A_RD, double* __restrict__ A_DD, DevLowRank lr, double* __restrict__ lr_part,
+             double* __restrict__ partials, const DevCtrl* __restrict__ c) {
+  __shared__ double sh[2 * (SDPLR_NT / 64)];
+  __shared__ double lrs[LRN > 0 ? 2 * SDPLR_NT * VEC : 1];
+  if (c->done) return;
+  constexpr int G = SDPLR_NT / LPR;
+  constexpr int POS = SDPLR_EDGE_POS;
+  const int lane = threadIdx.x % LPR, grp = threadIdx.x / LPR;
+  const long long total = (long long)gridDim.x * G;
+  double acc[2] = {0.0, 0.0};   // ½·Σ big·UVt0, Σ big·UVt1
+  double l0[VEC], l1[VEC];
+#pragma unroll
+  for (int k = 0; k < VEC; k++) l0[k] = l1[k] = 0.0;
+  for (long long q0 = (long long)blockIdx.x * G + grp; q0 < sp.nnzT; q0 += POS * total) {
+    long long row[POS], col[POS];
+    int gid[POS];
+    double w[POS], bb[POS];
+#pragma unroll
+    for (int t = 0; t < POS; t++) {
+      const long long qq = min(q0 + t * total, (long long)sp.nnzT - 1);
+      const bool in = q0 + t * total < sp.nnzT;
+      if constexpr (LPR >= 4) {
+        const double word = sp.q_rec[qq * 4 + (lane & 3)];
+        const double w0 = group_bcast<LPR>(word, 0), w1 = group_bcast<LPR>(word, 1);
+        row[t] = (unsigned)__double2loint(w0);
+        col[t] = (unsigned)__double2hiint(w0);
+        gid[t] = in ? __double2loint(w1) : -1;
+        w[t] = group_bcast<LPR>(word, 2);
+      } else {
+        row[t] = sp.triu_rowval[qq];
+        col[t] = sp.triu_colidx[qq];
+        gid[t] = in ? sp.q_gid[qq] : -1;
+        w[t] = sp.q_two[qq];
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < POS; t++) bb[t] = LRN > 0 ? lr.Bcat[row[t]] : 0.0;   // (with the row chunks: inside the chunk loop
+                                                                             //  it would be one more dependent round trip)
+    double a0[POS], a1[POS];
+#pragma unroll
+    for (int t = 0; t < POS; t++) a0[t] = a1[t] = 0.0;
+    for (int ch = lane * VEC; ch < r; ch += LPR * VEC) {
+      vecd<VEC> uc[POS], ur[POS], vc[POS], vr[POS];
+#pragma unroll
+      for (int t = 0; t < POS; t++) {
+        uc[t] = ldrow<VEC>(U + col[t] * r + ch);
+        ur[t] = ldrow<VEC>(U + row[t] * r + ch);
+        vc[t] = ldrow<VEC>(V + col[t] * r + ch);
+        vr[t] = ldrow<VEC>(V + row[t] * r + ch);
+      }
+#pragma unroll
+      for (int t = 0; t < POS; t++) {
+#pragma unroll
+        for (int k = 0; k < VEC; k++) {
+          a0[t] += uc[t].v[k] * vr[t].v[k];
+          a0[t] += vc[t].v[k] * ur[t].v[k];
+          a1[t] += vc[t].v[k] * vr[t].v[k];
+        }
+        if (LRN > 0 && row[t] == col[t] && gid[t] != -2 && q0 + t * total < sp.nnzT) {   // (single chunk when LRN > 0: r ≤ LPR·VEC)
+#pragma unroll
+          for (int k = 0; k < VEC; k++) {
+            l0[k] += uc[t].v[k] * bb[t];
+            l1[k] += vc[t].v[k] * bb[t];
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < POS; t++) {
+      a0[t] = group_sum<LPR>(a0[t]);
+      a1[t] = group_sum<LPR>(a1[t]);
+    }
+    if (lane == 0) {
+#pragma unroll
+      for (int t = 0; t < POS; t++) {
+        if (gid[t] < 0) continue;
+        const double q1 = w[t] * a0[t], q2 = w[t] * a1[t];
+        if (gid[t] == sp.big_gid) {
+          acc[0] += 0.5 * q1;
+          acc[1] += q2;
+        } else {
+          A_RD[gid[t]] = q1;
+          A_DD[gid[t]] = q2;
+        }
+      }
+    }
+  }
+  if constexpr (LRN > 0) {   // block partials of the projections, in k_lr_project's layout (block index fastest)
+#pragma unroll
+    for (int k = 0; k < VEC; k++) {
+      lrs[(0 * SDPLR_NT + threadIdx.x) * VEC + k] = l0[k];
+      lrs[(1 * SDPLR_NT + threadIdx.x) * VEC + k] = l1[k];
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < 2 * LPR * VEC; t += SDPLR_NT) {
+      const int f = t / (LPR * VEC), ch = t % (LPR * VEC);   // channel ch = lane·VEC + k
+      if (ch < r) {
+        double sum = 0.0;
+        for (int g = 0; g < G; g++) sum += lrs[(f * SDPLR_NT + g * LPR + ch / VEC) * VEC + ch % VEC];
+        lr_part[((long long)f * lr.ST * r + ch) * gridDim.x + blockIdx.x] = sum;
+      }
+    }
+    __syncthreads();
+  }
+  block_sum<2>(acc, sh);
+  if (threadIdx.x == 0) {
+    slot_partials(partials, SLOT_PD)[blockIdx.x] = acc[0];
+    slot_partials(partials, SLOT_DW)[blockIdx.x] = acc[1];
+  }
+}
+
+// Everything between k_sddmm_edge and the scalar stage that is a sum, in one grid:
+//   blocks [0, nout):            projection sums W[t] = Σ_blocks lr_part[t][·]                 (as k_lr_reduce)
+//   blocks [nout, nout + 2):     the big matrix's two sums → red2[0..1]
+//   the rest (nb_c blocks):      the eight line-search sums (src/linesearch.jl:36-56) over the constraints the
+//                                scalar stage does not take itself — λ, primal_vio_raw, A_RD, A_DD read coalesced —
+//                                as block partials in SLOT_LS + 0..7
+__global__ void __launch_bounds__(SDPLR_NT)
+k_edge_sums(int nout, int nb, const double* __restrict__ lr_part, double* __restrict__ W, double* __restrict__ red2,
+            int nb_c, int m, int n_extra, const int* __restrict__ extra, const double* __restrict__ lam,
+            const double* __restrict__ pv_raw, const double* __restrict__ A_RD, const double* __restrict__ A_DD,
+            double* __restrict__ partials, const DevCtrl* __restrict__ c) {
+  __shared__ double sh[8 * (SDPLR_NT / 64)];
+  const int dn = c->done;
+  const int t = blockIdx.x;
+  if (t < nout + 2) {
+    const double* p = t < nout ? lr_part + (long long)t * nb : slot_partials(partials, t == nout ? SLOT_PD : SLOT_DW);
+    double v[16];
+#pragma unroll
+    for (int q = 0; q < 16; q++) v[q] = p[min((int)threadIdx.x + SDPLR_NT * q, nb - 1)];
+    double s = 0.0;
+#pragma unroll
+    for (int q = 0; q < 16; q++) s += ((int)threadIdx.x + SDPLR_NT * q < nb) ? v[q] : 0.0;
+    for (int b = threadIdx.x + 16 * SDPLR_NT; b < nb; b += SDPLR_NT) s += p[b];
+    s = block_sum1(s, sh);
+    if (dn) return;
+    if (threadIdx.x == 0) (t < nout ? W[t] : red2[t - nout]) = s;
+    return;
+  }
+  if (dn) return;
+  const double sigma = c->sigma;
+  const int bc = t - nout - 2;
+  double s[8];
+#pragma unroll
+  for (int k = 0; k < 8; k++) s[k] = 0.0;
+  for (int i = bc * SDPLR_NT + threadIdx.x; i < m; i += nb_c * SDPLR_NT) {
+    bool skip = false;
+    for (int e = 0; e < n_extra; e++) skip |= (extra[e] == i);
+    const double l = lam[i], nq0 = pv_raw[i], q1 = A_RD[i], q2 = A_DD[i];
+    if (skip) continue;
+    s[0] += l * nq0;
+    s[1] += nq0 * nq0;
+    s[2] += l * q1;
+    s[3] += nq0 * q1;
+    s[4] += (l - sigma * nq0) * q2;
+    s[5] += q1 * q1;
+    s[6] += q1 * q2;
+    s[7] += q2 * q2;
+  }
+  block_sum<8>(s, sh);
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int k = 0; k < 8; k++) slot_partials(partials, SLOT_LS + k)[bc] = s[k];
+  }
+}
+
+// The two independent jobs between the scalar stage and the SpMM of g!, in one grid:
+//   blocks [0, nb_ax):   R += α·dirt                                                          (src/sdplr.jl:219)
+//   blocks [nb_ax, nb_ax + nb_c): commit of every constraint slot the scalar stage has not committed (the single-entry
+//                        matrices and uncovered slots): primal_vio_raw, primal_vio, y (src/linesearch.jl:118-124,
+//                        src/coreop.jl:229-236), the ‖pv‖² partials (src/sdplr.jl:229-234) — and S assembly BY
+//                        OWNER: the thread that forms y_k stores y_k·nzval_one into the ≤ 2 entries of S that
+//                        matrix k owns (src/coreop.jl:205-227 without the scatter-add or the map)
+//   the rest:            the entries of S the multi-entry matrix owns (its y comes from the scalar stage)
+__global__ void __launch_bounds__(SDPLR_NT)
+k_edge_step(DevSparse sp, DevCtrl* __restrict__ c, double* __restrict__ R, const double* __restrict__ D, long long N, int nb_ax, int nb_c,
+            int m, int n_extra, const int* __restrict__ extra, double* __restrict__ pv_raw,
+            const double* __restrict__ A_RD, const double* __restrict__ A_DD, const double* __restrict__ lb,
+            double* __restrict__ pv, double* __restrict__ y, const double* __restrict__ lam,
+            const double* __restrict__ lam_ub, double* __restrict__ partials, int nb_gnorm) {
+  __shared__ double sh[8];
+  if (c->done) return;
+  const double a = c->alpha, sigma = c->sigma;
+  const int b = blockIdx.x;
+  if (b < nb_ax) {
+    const long long N2 = N >> 1;
+    const long long stride = (long long)nb_ax * SDPLR_NT;
+    for (long long i = (long long)b * SDPLR_NT + threadIdx.x; i < N2; i += stride) {
+      double2 x = reinterpret_cast<double2*>(R)[i];
+      const double2 d = reinterpret_cast<const double2*>(D)[i];
+      x.x += a * d.x;
+      x.y += a * d.y;
+      reinterpret_cast<double2*>(R)[i] = x;
+    }
+    if ((N & 1) && b == 0 && threadIdx.x == 0) R[N - 1] += a * D[N - 1];
+    return;
+  }
+  if (b >= nb_ax + nb_c) {
+    const int nb_b = gridDim.x - nb_ax - nb_c;
+    const double yb = sp.big_gid >= 0 ? y[sp.big_gid] : 0.0;
+    for (int e = (b - nb_ax - nb_c) * SDPLR_NT + threadIdx.x; e < sp.n_big_pos; e += nb_b * SDPLR_NT)
+      sp.nzval[sp.big_pos[e]] = sp.big_one[e] * yb;
+    return;
+  }
+  const int bc = b - nb_ax;
+  double t = 0.0;
+  for (int i = bc * SDPLR_NT + threadIdx.x; i <= m; i += nb_c * SDPLR_NT) {
+    bool skip = false;
+    for (int e = 0; e < n_extra; e++) skip |= (extra[e] == i);
+    if (skip) continue;
+    const int p0 = sp.own_pos[2 * i], p1 = sp.own_pos[2 * i + 1];
+    const double one = sp.own_one[i];
+    const double v = pv_raw[i] + a * (a * A_DD[i] + A_RD[i]);
+    pv_raw[i] = v;
+    double yi = 1.0;
+    if (i == m) {
+      c->obj = v;
+    } else {
+      const double pc = fmax(v, lb[i]);
+      pv[i] = pc;
+      t += pc * pc;
+      yi = -fmin(lam_ub[i], lam[i] - sigma * v);
+    }
+    y[i] = yi;
+    if (p0 >= 0) sp.nzval[p0] = one * yi;
+    if (p1 >= 0) sp.nzval[p1] = one * yi;
+  }
+  t = block_sum1(t, sh);
+  if (threadIdx.x == 0) {
+    slot_partials(partials, SLOT_PVNORM2)[bc] = t;
+    if (bc == 0) {   // the SpMM that follows produces the ‖G‖² partials; the seam kernel folds both
+      c->norms_pending = 1;
+      c->nb_pvnorm = nb_c;
+      c->nb_gnorm = nb_gnorm;
+    }
   }
 }
 

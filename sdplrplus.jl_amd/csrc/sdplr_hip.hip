@@ -81,6 +81,10 @@ struct sdplr_hip_solver {
   DevSparse sp_fast{};       // sp with the segmented-reduction plan restricted to the diagonal-only matrices
   DevSparse spg{};           // the general matrix A_g alone, as a symmetric CSR with fixed values
   DevTile tile{};            // the same matrix as column-sorted K-row tiles (k_spmm_tile)
+  bool edge = false;         // edge path (k_sparse.h): disjoint supports, at most one multi-entry sparse matrix
+  const int* edge_extra = nullptr;   // its extra slots: the multi-entry matrix and the low-rank matrices
+  int n_edge_extra = 0, nb_edge = 1;
+  bool edge_lr_fused = false;
   DevBand band{};            // full pattern as LDS-band slices for the Lanczos SpMV (k_lz_band)
   bool use_band = false;
   int nb_tile = 0, nb_step = 1;
@@ -109,6 +113,7 @@ struct sdplr_hip_solver {
   double *lz_buf[3] = {nullptr, nullptr, nullptr}, *lz_v0 = nullptr, *lz_alpha = nullptr, *lz_beta = nullptr;
   int64_t lz_cap = 0;
   double *lr_part = nullptr, *lr_W = nullptr, *lr_WS = nullptr, *lr_coef = nullptr, *lr_btx_part = nullptr;
+  double* red10 = nullptr;   // the ten line-search sums, when summed ahead of the scalar stage (k_lr_reduce)
   int nb_lr = 1;
 
   // kernel shapes
@@ -516,6 +521,7 @@ int alloc_factors(S* s) {
   s->nb_upd = std::min(s->nb_dense, 256);  // one block per CU streams at full rate; fewer Gram partials for the seam kernel
   if (const char* e = getenv("SDPLR_HIP_NB_UPD")) s->nb_upd = std::max(1, std::min(atoi(e), SDPLR_MAXNB));
   s->nb_sddmm = blocks_for(s->nnzT, G, 8192);
+  s->nb_edge = blocks_for(s->nnzT, SDPLR_EDGE_POS * G, SDPLR_MAXNB);   // k_sddmm_edge: its per-block partials are folded by one block
   s->nb_spmm = blocks_for(s->n, G, 768);  // + up to 256 hub-row blocks share the partial slot
   s->nb_tile = blocks_for(s->tile.n_tiles, G, 1024);
   s->nb_lr = (s->N >= (1LL << 22)) ? 1024 : 256;   // low-rank projection grid (lr_part is sized for 1024)
@@ -765,6 +771,7 @@ int32_t sdplr_hip_finalize(S* s) {
   s->nb_lr = 256;   // (alloc_factors raises it to 1024 for large factors: n·r ≥ 4M)
   if ((rc = dzero(s, &s->lr_btx_part, (size_t)std::max(lr.ST, 1) * SDPLR_MAXNB))) return rc;
   if ((rc = dzero(s, &s->lr_coef, 2 * (size_t)std::max(lr.ST, 1)))) return rc;
+  if ((rc = dzero(s, &s->red10, 16))) return rc;
   {
     DevCtrl* d = nullptr;
     if ((rc = dalloc(s, &d, 1))) return rc;
@@ -883,6 +890,77 @@ int32_t sdplr_hip_finalize(S* s) {
       s->fast_singleton = single && s->spg.n_long_rows == 0 && getenv("SDPLR_HIP_NO_FAST2") == nullptr;
     }
   }
+  // ---- edge path: disjoint supports (every pattern position owned by at most one sparse matrix) and at most one
+  // sparse matrix with more than one upper-triangular entry (Lovász-θ: one constraint per edge + the identity) ----
+  sp.big_gid = -1;
+  if (s->have_sparse && !s->fast && s->n_sparse > 0 && getenv("SDPLR_HIP_NO_EDGE") == nullptr) {
+    bool disjoint = true;
+    for (int64_t q = 0; q < s->nnzT && disjoint; q++) disjoint = tptr[q + 1] - tptr[q] <= 1;
+    int n_big = 0, big = -1;
+    for (int64_t k = 0; k < s->n_sparse; k++)
+      if (s->h_matptr[k + 1] - s->h_matptr[k] > 1) { n_big++; big = s->h_gids[k]; }
+    if (disjoint && n_big <= 1) {
+      std::vector<int> q_gid(s->nnzT, -1), s_gid(s->nnzS, -1);
+      std::vector<double> q_two(s->nnzT, 0.0), s_one(s->nnzS, 0.0);
+      for (int64_t k = 0; k < s->n_sparse; k++)
+        for (int e = s->h_matptr[k]; e < s->h_matptr[k + 1]; e++) {
+          q_gid[s->h_nzind[e]] = s->h_gids[k];
+          q_two[s->h_nzind[e]] = s->h_two[e];
+        }
+      for (int64_t p = 0; p < s->nnzS; p++) {
+        const int q = s->h_mapped[p];
+        if (tptr[q + 1] > tptr[q]) { s_gid[p] = tmat[tptr[q]]; s_one[p] = tval[tptr[q]]; }
+      }
+      {
+        std::vector<double> rec((size_t)s->nnzT * 4, 0.0);
+        for (int64_t q = 0; q < s->nnzT; q++) {
+          const unsigned long long w0 = (unsigned long long)(unsigned)s->h_trv[q] | ((unsigned long long)(unsigned)colidx[q] << 32);
+          const unsigned long long w1 = (unsigned long long)(unsigned)q_gid[q];
+          memcpy(&rec[q * 4 + 0], &w0, 8);
+          memcpy(&rec[q * 4 + 1], &w1, 8);
+          rec[q * 4 + 2] = q_two[q];
+        }
+        if ((rc = upload(s, &sp.q_rec, rec))) return rc;
+      }
+      if ((rc = upload(s, &sp.q_gid, q_gid))) return rc;
+      if ((rc = upload(s, &sp.q_two, q_two))) return rc;
+      if ((rc = upload(s, &sp.s_gid, s_gid))) return rc;
+      if ((rc = upload(s, &sp.s_one, s_one))) return rc;
+      sp.big_gid = big;
+      {   // S assembly by owner: the full-pattern entries of each single-entry matrix; the big matrix's list
+        std::vector<int> own_pos(2 * (m + 1), -1), big_pos;
+        std::vector<double> own_one(m + 1, 0.0), big_one;
+        for (int64_t p = 0; p < s->nnzS; p++) {
+          const int g = s_gid[p];
+          if (g < 0) continue;
+          if (g == big) { big_pos.push_back((int)p); big_one.push_back(s_one[p]); continue; }
+          if (own_pos[2 * g] < 0) own_pos[2 * g] = (int)p; else own_pos[2 * g + 1] = (int)p;
+          own_one[g] = s_one[p];
+        }
+        if ((rc = upload(s, &sp.own_pos, own_pos))) return rc;
+        if ((rc = upload(s, &sp.own_one, own_one))) return rc;
+        if ((rc = upload(s, &sp.big_pos, big_pos))) return rc;
+        if ((rc = upload(s, &sp.big_one, big_one))) return rc;
+        sp.n_big_pos = (int)big_pos.size();
+      }
+      std::vector<int> extra;
+      if (big >= 0) extra.push_back(big);
+      for (auto& L : s->h_lr) extra.push_back((int)L.gid);
+      if ((rc = upload(s, &s->edge_extra, extra))) return rc;
+      s->n_edge_extra = (int)extra.size();
+      // the low-rank projections ride the SDDMM when there is one column and every row has a diagonal position
+      bool all_diag = true;
+      {
+        std::vector<char> has(n, 0);
+        for (int64_t j = 0; j < n; j++)
+          for (int q = s->h_tcp[j]; q < s->h_tcp[j + 1]; q++)
+            if (s->h_trv[q] == (int)j) has[j] = 1;
+        all_diag = std::all_of(has.begin(), has.end(), [](char c) { return c != 0; });
+      }
+      s->edge_lr_fused = lr.ST == 1 && all_diag && !s->no_lrfuse;
+      s->edge = true;
+    }
+  }
   if ((rc = alloc_factors(s))) return rc;
   s->nb_m = blocks_for(m + 1, SDPLR_NT, 256);
   s->nb_spmv = blocks_for(n, SDPLR_NT / 8, 768);
@@ -890,7 +968,7 @@ int32_t sdplr_hip_finalize(S* s) {
   s->nb_nnzS = blocks_for(s->nnzS, SDPLR_NT, 4096);
   s->nb_n = blocks_for(n, SDPLR_NT, 1024);
   // low-rank scratch depends on r: allocated for the largest rank seen (reset_rank re-allocates)
-  if ((rc = dzero(s, &s->lr_part, (size_t)std::max(s->nb_lr, 1024) * 2 * std::max(lr.ST, 1) * s->r))) return rc;
+  if ((rc = dzero(s, &s->lr_part, (size_t)std::max(s->nb_lr, SDPLR_MAXNB) * 2 * std::max(lr.ST, 1) * s->r))) return rc;
   if ((rc = dzero(s, &s->lr_W, (size_t)2 * std::max(lr.ST, 1) * s->r))) return rc;
   if ((rc = dzero(s, &s->lr_WS, (size_t)std::max(lr.ST, 1) * s->r))) return rc;
   // release host staging
@@ -943,7 +1021,7 @@ int32_t sdplr_hip_reset_rank(S* s, int64_t new_r) {
   HIPCK(s, hipMemsetAsync(s->lambda, 0, std::max<int64_t>(m, 1) * sizeof(double), s->stream));
   HIPCK(s, hipMemsetAsync(s->pv, 0, std::max<int64_t>(m, 1) * sizeof(double), s->stream));
   for (double* p : {s->y, s->pv_raw, s->A_RD, s->A_DD}) HIPCK(s, hipMemsetAsync(p, 0, (m + 1) * sizeof(double), s->stream));
-  if ((rc = dzero(s, &s->lr_part, (size_t)std::max(s->nb_lr, 1024) * 2 * std::max(s->lr.ST, 1) * s->r))) return rc;
+  if ((rc = dzero(s, &s->lr_part, (size_t)std::max(s->nb_lr, SDPLR_MAXNB) * 2 * std::max(s->lr.ST, 1) * s->r))) return rc;
   if ((rc = dzero(s, &s->lr_W, (size_t)2 * std::max(s->lr.ST, 1) * s->r))) return rc;
   if ((rc = dzero(s, &s->lr_WS, (size_t)std::max(s->lr.ST, 1) * s->r))) return rc;
   if ((rc = pull(s))) return rc;
@@ -1110,7 +1188,7 @@ void enq_lowrank(S* s, const double* X0, const double* X1, int F, int mode, doub
   if (s->nb_lr > 256) {   // many blocks: their partials are summed by many waves, not by the one finalize block
     ProfScope ps(s, "lr_reduce");
     const int nout = F * s->lr.ST * (int)s->r;
-    k_lr_reduce<<<(nout + 3) / 4, SDPLR_NT, 0, s->stream>>>(nout, s->nb_lr, s->lr_part, s->lr_W, s->ctrl, chk);
+    k_lr_reduce<<<nout, SDPLR_NT, 0, s->stream>>>(nout, s->nb_lr, s->lr_part, s->lr_W, s->ctrl, chk);
     nbf = 0;
   }
   ProfScope ps(s, "lr_finalize");
@@ -1315,6 +1393,49 @@ void enq_iteration(S* s, int armijo) {
   enq_lbfgs_update(s, 1);                    // :244-246
 }
 
+// edge path (k_sparse.h): exact line search, lbfgs_update! fused into the SpMM (h ≤ 4): 7 launches
+bool edge_applies(const S* s, int armijo) {
+  return s->edge && !armijo && spmm_fuses_update(s);
+}
+void enq_iteration_edge(S* s) {
+  double *R = aslot(s->arena, AS_R), *G = aslot(s->arena, AS_G), *D = aslot(s->arena, AS_D);
+  s->gram_nb = spmm_upd_blocks(s);
+  enq_lbfgs_dir(s, 1, 1, 1, true);                                                       // :197-205
+  if (!s->all_covered) {
+    (void)hipMemsetAsync(s->A_RD, 0, (s->m + 1) * sizeof(double), s->stream);
+    (void)hipMemsetAsync(s->A_DD, 0, (s->m + 1) * sizeof(double), s->stream);
+  }
+  const bool lrf = s->edge_lr_fused && s->r <= (int64_t)s->LPR * s->VEC;
+  const int nb_c = blocks_for(s->m + 1, SDPLR_NT, 1024);   // one constraint per thread: the m-passes are latency-bound
+  {
+    ProfScope ps(s, "sddmm_linesearch");   // 𝒜(RDᵀ+DRᵀ), 𝒜(DDᵀ) of the sparse matrices + line-search sums (+ projections)
+    if (lrf) { LV_DISPATCH((k_sddmm_edge<LPR, VEC, 1><<<s->nb_edge, SDPLR_NT, 0, s->stream>>>(s->sp, (int)s->m, R, D, (int)s->r, s->A_RD, s->A_DD, s->lr, s->lr_part, s->partials, s->ctrl))) }
+    else { LV_DISPATCH((k_sddmm_edge<LPR, VEC, 0><<<s->nb_edge, SDPLR_NT, 0, s->stream>>>(s->sp, (int)s->m, R, D, (int)s->r, s->A_RD, s->A_DD, s->lr, s->lr_part, s->partials, s->ctrl))) }
+  }
+  if (!lrf) enq_lowrank(s, R, D, 2, 2, s->A_RD, s->A_DD, 1);
+  {
+    ProfScope ps(s, "edge_sums");   // projection sums ‖ the big matrix's sums ‖ line-search partials of the other constraints
+    const int nout = lrf ? 2 * s->lr.ST * (int)s->r : 0;
+    k_edge_sums<<<nout + 2 + nb_c, SDPLR_NT, 0, s->stream>>>(nout, s->nb_edge, s->lr_part, s->lr_W, s->red10, nb_c, (int)s->m, s->n_edge_extra, s->edge_extra, s->lambda, s->pv_raw, s->A_RD, s->A_DD, s->partials, s->ctrl);
+  }
+  {
+    ProfScope ps(s, "ls_solve_fast");
+    k_ls_solve_fast<<<1, SDPLR_LSF_NT, 0, s->stream>>>(s->ctrl, (int)s->m, s->sp.big_gid, s->n_edge_extra, s->edge_extra, nb_c, s->A_RD, s->A_DD, s->lambda, s->lambda_ub, s->pv_raw, s->pv_lb, s->pv, s->y, s->lr.ST, (int)s->r, s->lr.col_gid, s->lr.Dcat, s->lr_W, s->lr_WS, s->partials, 1, lrf ? 1 : 0, s->lr.n_lr, s->lr.mat_ptr, s->lr.mat_gid, s->red10);
+  }
+  const int nbl = std::min(s->sp.n_long_rows, 256);
+  {
+    ProfScope ps(s, "step_jobs");                                                         // :219 ‖ commit + y
+    const int nb_big = s->sp.n_big_pos > 0 ? blocks_for(s->sp.n_big_pos, SDPLR_NT, 256) : 0;
+    k_edge_step<<<s->nb_dense + nb_c + nb_big, SDPLR_NT, 0, s->stream>>>(s->sp, s->ctrl, R, D, s->N, s->nb_dense, nb_c, (int)s->m, s->n_edge_extra, s->edge_extra, s->pv_raw, s->A_RD, s->A_DD, s->pv_lb, s->pv, s->y, s->lambda, s->lambda_ub, s->partials, s->nb_spmm + nbl);
+  }
+  ProfScope ps(s, "spmm");                                                                // g! (:221) + lbfgs_update! (:244-246)
+  if (getenv("SDPLR_HIP_EDGE_GATHER_S")) {   // S gathered by the SpMM itself (an extra dependent round trip per batch: slower; kept for the comparison)
+    LV_DISPATCH((k_spmm_both_upd<LPR, VEC, 4, true><<<s->nb_spmm + nbl, SDPLR_NT, 5 * 4 * SDPLR_NT * sizeof(double), s->stream>>>(s->sp, R, G, (int)s->r, 2.0, s->lr, s->lr_WS, SLOT_GNORM2, s->partials, s->ctrl, nbl, s->arena, (int)s->h, D, s->y)))
+  } else {
+    LV_DISPATCH((k_spmm_both_upd<LPR, VEC, 4, false><<<s->nb_spmm + nbl, SDPLR_NT, 5 * 4 * SDPLR_NT * sizeof(double), s->stream>>>(s->sp, R, G, (int)s->r, 2.0, s->lr, s->lr_WS, SLOT_GNORM2, s->partials, s->ctrl, nbl, s->arena, (int)s->h, D)))
+  }
+}
+
 // ---- structured fast path (k_sparse.h, DevFast) -----------------------------------------------------
 inline double* fast_P(S* s) { return aslot(s->arena, 3 + 2 * (int)s->h); }
 inline double* fast_W(S* s) { return aslot(s->arena, 3 + 2 * (int)s->h + 1); }
@@ -1444,13 +1565,13 @@ void enq_iteration_fast2(S* s) {
                    // per output); the mode-2 tail of k_lr_finalize is taken by k_ls_solve_fast
     ProfScope ps(s, "lr_reduce");
     const int nout = 2 * s->lr.ST * (int)s->r;
-    k_lr_reduce<<<(nout + 3) / 4, SDPLR_NT, 0, s->stream>>>(nout, s->nb_tile, s->lr_part, s->lr_W, s->ctrl, 1);
+    k_lr_reduce<<<nout, SDPLR_NT, 0, s->stream>>>(nout, s->nb_tile, s->lr_part, s->lr_W, s->ctrl, 1);
   } else {
     enq_lowrank(s, R, D, 2, 2, s->A_RD, s->A_DD, 1);
   }
   {
     ProfScope ps(s, "ls_solve_fast");
-    k_ls_solve_fast<<<1, SDPLR_NT, 0, s->stream>>>(s->ctrl, (int)s->m, s->ff.gid_g, s->n_extra, s->extra_slots, (s->use_tile && s->tile_lpr == s->LPR && s->n * s->r * 8 < (1LL << 32)) ? s->nb_tile : s->nb_spmm, s->A_RD, s->A_DD, s->lambda, s->lambda_ub, s->pv_raw, s->pv_lb, s->pv, s->y, s->lr.ST, (int)s->r, s->lr.col_gid, s->lr.Dcat, s->lr_W, s->lr_WS, s->partials, 1, lr_fused ? 1 : 0, s->lr.n_lr, s->lr.mat_ptr, s->lr.mat_gid);
+    k_ls_solve_fast<<<1, SDPLR_LSF_NT, 0, s->stream>>>(s->ctrl, (int)s->m, s->ff.gid_g, s->n_extra, s->extra_slots, (s->use_tile && s->tile_lpr == s->LPR && s->n * s->r * 8 < (1LL << 32)) ? s->nb_tile : s->nb_spmm, s->A_RD, s->A_DD, s->lambda, s->lambda_ub, s->pv_raw, s->pv_lb, s->pv, s->y, s->lr.ST, (int)s->r, s->lr.col_gid, s->lr.Dcat, s->lr_W, s->lr_WS, s->partials, 1, lr_fused ? 1 : 0, s->lr.n_lr, s->lr.mat_ptr, s->lr.mat_gid);
   }
   // (a variant fusing this step kernel with lbfgs_update! was measured at 111 µs against 38 + 59 µs for the
   // two kernels — 166 VGPRs and scratch — and dropped)
@@ -1942,9 +2063,11 @@ int32_t sdplr_hip_inner_loop(S* s, double normC, double normb, int32_t grel, int
   const int ar = use_armijo ? 1 : 0;
   const bool fastp = s->fast;
   const bool fast2 = fastp && s->fast_singleton && !use_armijo;
+  const bool edgep = !fastp && edge_applies(s, use_armijo);
   auto enq_iter = [&]() {
     if (fast2) enq_iteration_fast2(s);
     else if (fastp) enq_iteration_fast(s, use_armijo);
+    else if (edgep) enq_iteration_edge(s);
     else enq_iteration(s, use_armijo);
   };
   if (fastp) enq_fast_refresh_P(s);
@@ -2051,7 +2174,7 @@ int32_t sdplr_hip_inner_loop(S* s, double normC, double normb, int32_t grel, int
   const bool loop_fused = fastp ? step_fuses_update(s) : spmm_fuses_update(s);   // lbfgs_update! rode another kernel
   s->gram_nb = !loop_fused ? s->nb_upd : (fastp ? s->nb_step : spmm_upd_blocks(s));
   enq_boundary(s, 0, 1, 0, 0);
-  if (fastp) enq_At_preprocess(s, 0);  // leave S consistent with the y of the last step, as g! would
+  if (fastp || edgep) enq_At_preprocess(s, 0);  // leave S consistent with the y of the last step, as g! would
   if ((rc = pull(s))) return rc;
   if (c->done) why = c->exit_reason;   // the device's verdict wins over the host's time check
   if (loop_fused && c->iters > 0 && c->err == 0 && why != EXIT_RELDELTA) {

@@ -73,7 +73,8 @@ def test_first_iterations_match_oracle_at_baseline_size(hip_abi, oracle_abi, whi
     assert rel(h["pv"], o["pv"]) < TOL and rel(h["y"], o["y"]) < TOL
     # Plain Lanczos (no re-orthogonalisation, src/coreop.jl:481-500) is only comparable while its recurrence is
     # well conditioned: a round-off ε in step j comes back multiplied by ≈ ‖S‖/β_j in step j + 1, and once a Ritz pair has
-    # converged (β collapses) the two runs decouple.  Steps are compared to 1e-9 while ε·Π_j(‖S‖/β_j) < 1e-10,
+    # converged (β collapses) the two runs decouple.  Steps are compared to 1e-8 (the two S already differ by the
+    # 1e-9 of the two R they come from) while ε·Π_j(‖S‖/β_j) < 1e-10,
     # ten at most: all ten on MaxCut (‖S‖/β ≈ 2-7); two on Lovász-θ and one on MinBisection, whose rank-one terms
     # (−11ᵀ, y·11ᵀ: λ_max ≈ 5e4 resp. 7e7 against β ≈ 30 … 1e3) converge within three steps.
     scale = np.max(np.abs(o["lz_alpha"][:10]))
@@ -82,8 +83,8 @@ def test_first_iterations_match_oracle_at_baseline_size(hip_abi, oracle_abi, whi
         K += 1
         amp *= scale / o["lz_beta"][K - 1]
     assert K >= 1 and (which != "maxcut_n1e5" or K == 10), (K, o["lz_beta"][:10])
-    assert np.allclose(h["lz_alpha"][:K], o["lz_alpha"][:K], rtol=1e-9, atol=1e-12 * scale), (K, h["lz_alpha"][:K], o["lz_alpha"][:K])
-    assert np.allclose(h["lz_beta"][:K], o["lz_beta"][:K], rtol=1e-9, atol=1e-12 * scale)
+    assert np.allclose(h["lz_alpha"][:K], o["lz_alpha"][:K], rtol=1e-8, atol=1e-12 * scale), (K, h["lz_alpha"][:K], o["lz_alpha"][:K])
+    assert np.allclose(h["lz_beta"][:K], o["lz_beta"][:K], rtol=1e-8, atol=1e-12 * scale)
     # … and what the dual bound actually uses, the smallest Ritz value of all q steps (src/coreop.jl:502-513)
     assert abs(h["ritz"] - o["ritz"]) <= 1e-6 * scale, (h["ritz"], o["ritz"])
 

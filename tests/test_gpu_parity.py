@@ -498,6 +498,7 @@ def test_concurrent_handles_match_serial(hip_abi):
     ("lovasz_theta", ["SDPLR_HIP_NO_LRFUSE"]), ("minimum_bisection", ["SDPLR_HIP_NO_FAST", "SDPLR_HIP_NO_LRFUSE"]),
     ("mu_conductance_0.05", ["SDPLR_HIP_NO_FAST"]), ("ineq_0.05", ["SDPLR_HIP_NO_FAST"]),
     # the eager route (what instances below n·r = 2¹⁷ take by default; the suite forces graphs otherwise) for EVERY family
+    ("lovasz_theta", ["SDPLR_HIP_NO_EDGE"]), ("lovasz_theta", ["SDPLR_HIP_NO_EDGE", "SDPLR_HIP_NO_UPDFUSE"]),
     ("minimum_bisection", ["SDPLR_HIP_NO_GRAPH"]), ("lovasz_theta", ["SDPLR_HIP_NO_GRAPH"]),
     ("cutnorm", ["SDPLR_HIP_NO_GRAPH"]), ("mu_conductance_0.01", ["SDPLR_HIP_NO_GRAPH"]),
     ("mu_conductance_0.05", ["SDPLR_HIP_NO_GRAPH"]), ("mu_conductance_0.1", ["SDPLR_HIP_NO_GRAPH"]),
