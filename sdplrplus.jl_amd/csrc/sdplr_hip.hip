@@ -131,6 +131,11 @@ struct sdplr_hip_solver {
 
   // Gram bookkeeping (see k_dense.h)
   bool gram_dirty = false, sg_stale = false, ynext_pending = false;
+  // structured paths: P = A_g·R is resident and updated incrementally; it is recomputed from scratch when R was
+  // written outside the loop or after SDPLR_P_REFRESH_ITERS incremental updates (drift control).  The loop leaves y
+  // current but not the assembled S: whoever reads S next assembles it first (ensure_S).
+  bool P_valid = false, S_stale = false;
+  int64_t P_age = 0;
 
   // scratch arrays for operator calls on the caller's own matrices / vectors (SDPLR_F_SCRATCH, SDPLR_V_SCRATCH)
   double* scratchF[2] = {nullptr, nullptr};
@@ -152,6 +157,7 @@ struct sdplr_hip_solver {
 
 namespace {
 using S = sdplr_hip_solver;
+void ensure_S(S* s);
 
 int fail(S* s, int code, const std::string& msg) {
   if (s) s->err = msg; else g_err = msg;
@@ -297,6 +303,7 @@ double* factor_ptr(S* s, int32_t slot) {
   return nullptr;
 }
 void note_factor_written(S* s, int32_t slot) {
+  if (slot == SDPLR_F_RT) s->P_valid = false;
   if (slot == SDPLR_F_GT) s->sg_stale = true;
   if (slot >= SDPLR_F_LBFGS_S && slot < SDPLR_F_SCRATCH) s->gram_dirty = true;
 }
@@ -1031,6 +1038,8 @@ int32_t sdplr_hip_reset_rank(S* s, int64_t new_r) {
   s->hc->alpha_max = 1.0;
   s->hc->latest = (int)s->h;
   s->gram_dirty = s->sg_stale = s->ynext_pending = false;
+  s->P_valid = false;
+  s->S_stale = false;
   return push(s);
 }
 
@@ -1110,6 +1119,7 @@ int32_t sdplr_hip_get_vec(S* s, int32_t which, double* h, int64_t len) {
   int64_t L; bool in_ctrl;
   double* p = vec_ptr(s, which, &L, &in_ctrl);
   if (L < 0 || len != L || (!h && L > 0)) return fail(s, SDPLR_ERR_INVALID_ARG, "get_vec: bad slot/length");
+  if (which == SDPLR_V_S_NZVAL || which == SDPLR_V_TRIU_S_NZVAL) ensure_S(s);
   if (L == 0) return SDPLR_OK;
   if (in_ctrl) {
     int rc = pull(s);
@@ -1233,6 +1243,13 @@ void enq_At_preprocess(S* s, int chk) {
   }
   ProfScope ps(s, "assemble_full");
   k_assemble_full<<<s->nb_nnzS, SDPLR_NT, 0, s->stream>>>(s->sp, s->ctrl, chk);
+}
+
+// the inner loop of the structured / edge paths leaves y current but S unassembled: assemble on first use
+void ensure_S(S* s) {
+  if (!s->S_stale) return;
+  enq_At_preprocess(s, 0);
+  s->S_stale = false;
 }
 
 // Y = scale·(X·S + low-rank); slot ≥ 0 also yields the ‖Y‖² partials
@@ -1822,6 +1839,7 @@ int32_t sdplr_hip_At_preprocess(S* s) {
   ApiShared api_guard;
   NEED_FINAL(s);
   enq_At_preprocess(s, 0);
+  s->S_stale = false;
   return sync_check(s);
 }
 int32_t sdplr_hip_At_left(S* s, int32_t ys, int32_t xs) {
@@ -1829,6 +1847,7 @@ int32_t sdplr_hip_At_left(S* s, int32_t ys, int32_t xs) {
   NEED_FINAL(s);
   double *Y = factor_ptr(s, ys), *X = factor_ptr(s, xs);
   if (!Y || !X || Y == X) return fail(s, SDPLR_ERR_INVALID_ARG, "At_left: bad slots");
+  ensure_S(s);
   enq_At_left(s, Y, X, 1.0, -1, 0);
   note_factor_written(s, ys);
   return sync_check(s);
@@ -1837,6 +1856,7 @@ int32_t sdplr_hip_At_right(S* s, const double* x, double* yh, int64_t k) {
   ApiShared api_guard;
   NEED_FINAL(s);
   if (!x || !yh || k < 1) return fail(s, SDPLR_ERR_INVALID_ARG, "At_right: bad args");
+  ensure_S(s);
   const int64_t n = s->n;
   for (int64_t c = 0; c < k; c++) {
     HIPCK(s, hipMemcpyAsync(s->lz_buf[0], x + c * n, n * sizeof(double), hipMemcpyHostToDevice, s->stream));
@@ -1857,6 +1877,7 @@ int32_t sdplr_hip_At_right_device(S* s, const double* x, double* yd, int64_t k) 
     (void)hipGetLastError();
     return fail(s, SDPLR_ERR_INVALID_ARG, "At_right_device: x and y must be device pointers");
   }
+  ensure_S(s);
   const int64_t n = s->n;
   for (int64_t c = 0; c < k; c++) enq_spmv(s, x + c * n, yd + c * n, -1, nullptr);
   return sync_check(s);
@@ -1885,6 +1906,7 @@ int32_t sdplr_hip_g(S* s) {
   ApiShared api_guard;
   NEED_FINAL(s);
   enq_g(s, 0, false);
+  s->S_stale = false;
   s->sg_stale = true;
   return sync_check(s);
 }
@@ -1908,6 +1930,7 @@ int32_t sdplr_hip_fg(S* s, double normC, double normb, int32_t grel, int32_t pre
   if (rc) return rc;
   enq_f(s);
   enq_g(s, 0, false);
+  s->S_stale = false;
   {
     ProfScope ps(s, "pv_norm");  // src/coreop.jl:340-347
     k_pv_norm<<<s->nb_m, SDPLR_NT, 0, s->stream>>>((int)s->m, s->pv_raw, s->pv_lb, s->pv, 1, s->partials);
@@ -1943,6 +1966,7 @@ int32_t sdplr_hip_axpy_R(S* s, double alpha) {
   if (rc) return rc;
   s->hc->alpha = alpha;
   if ((rc = push(s))) return rc;
+  s->P_valid = false;
   enq_axpy_R(s, 0);
   return sync_check(s);
 }
@@ -2070,7 +2094,14 @@ int32_t sdplr_hip_inner_loop(S* s, double normC, double normb, int32_t grel, int
     else if (edgep) enq_iteration_edge(s);
     else enq_iteration(s, use_armijo);
   };
-  if (fastp) enq_fast_refresh_P(s);
+  if (fastp) {
+    static const int64_t refresh_iters = getenv("SDPLR_HIP_P_REFRESH_ITERS") ? atoll(getenv("SDPLR_HIP_P_REFRESH_ITERS")) : 256;
+    if (!s->P_valid || s->P_age >= refresh_iters) {
+      enq_fast_refresh_P(s);
+      s->P_valid = true;
+      s->P_age = 0;
+    }
+  }
   // hipGraph batches pay for their capture (milliseconds, and exclusive of every other handle's HIP calls) only
   // on instances whose solve is long: small factors (config 5's n = 800 batch: 64 solves 1.3 → 0.95 s) stay eager
   bool use_graph = !s->prof_on && !s->graph_disabled && max_local_iters >= 4 && getenv("SDPLR_HIP_NO_GRAPH") == nullptr &&
@@ -2109,7 +2140,12 @@ int32_t sdplr_hip_inner_loop(S* s, double normC, double normb, int32_t grel, int
   if (!s->graph_exec[ar]) use_graph = false;
   // the time budget starts here: after any wait for the capture lock
   const auto t0 = std::chrono::steady_clock::now();
-  const int64_t eager_batch = std::min<int64_t>(max_local_iters + 1, 8);
+  const int64_t eager_batch = 8;
+  // The plan never runs past the iteration budget: whole graph batches while they fit, the remainder as eager
+  // launches, then ONE loop-test seam (it sets done / EXIT_ITERS, src/sdplr.jl:272-277) — no batch of kernels that
+  // could only fall through, and nothing speculative behind the last planned batch.
+  int64_t planned = 0;
+  bool plan_closed = false;
   const bool dbg = getenv("SDPLR_HIP_DEBUG") != nullptr;
   double t_enq = 0.0, t_wait = 0.0;
   int n_batches = 0;
@@ -2117,13 +2153,23 @@ int32_t sdplr_hip_inner_loop(S* s, double normC, double normb, int32_t grel, int
   auto launch_batch = [&](int slot) -> int {
     const double ta = now();
     n_batches++;
-    if (use_graph) {
+    const int64_t left = max_local_iters - planned;
+    if (use_graph && left >= s->graph_iters) {
       HIPCK(s, hipGraphLaunch(s->graph_exec[ar], s->stream));
+      planned += s->graph_iters;
       s->st_graph_batches++;
-    } else {
-      for (int64_t i = 0; i < eager_batch; i++) enq_iter();
+    } else if (left > 0) {
+      const int64_t nb_it = std::min<int64_t>(left, eager_batch);
+      for (int64_t i = 0; i < nb_it; i++) enq_iter();
       HIPCK(s, hipGetLastError());
+      planned += nb_it;
       s->st_eager_batches++;
+    }
+    if (planned >= max_local_iters && !plan_closed) {
+      const bool lf = fastp ? step_fuses_update(s) : spmm_fuses_update(s);
+      s->gram_nb = !lf ? s->nb_upd : (fastp ? s->nb_step : spmm_upd_blocks(s));
+      enq_boundary(s, 0, 1, 1, 0);       // fold the last update, then the loop tests: the budget exit fires here
+      plan_closed = true;
     }
     HIPCK(s, hipMemcpyAsync(s->snap[slot], s->ctrl, sizeof(DevCtrl), hipMemcpyDeviceToHost, s->stream));
     HIPCK(s, hipEventRecord(s->snap_ev[slot], s->stream));
@@ -2157,7 +2203,8 @@ int32_t sdplr_hip_inner_loop(S* s, double normC, double normb, int32_t grel, int
     int cur = 0;
     if ((rc = launch_batch(cur))) return rc;
     for (;;) {
-      if ((rc = launch_batch(cur ^ 1))) return rc;          // speculative: queued behind batch `cur`
+      const bool more = !plan_closed;
+      if (more && (rc = launch_batch(cur ^ 1))) return rc;  // speculative: queued behind batch `cur`
       const double tw = now();
       HIPCK(s, hipEventSynchronize(s->snap_ev[cur]));
       t_wait += now() - tw;
@@ -2166,6 +2213,7 @@ int32_t sdplr_hip_inner_loop(S* s, double normC, double normb, int32_t grel, int
         const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         if (el > time_budget_s) { why = EXIT_TIME; break; }
       }
+      if (!more) break;   // (the closing seam always sets done; not reached)
       cur ^= 1;
     }
   }
@@ -2174,7 +2222,7 @@ int32_t sdplr_hip_inner_loop(S* s, double normC, double normb, int32_t grel, int
   const bool loop_fused = fastp ? step_fuses_update(s) : spmm_fuses_update(s);   // lbfgs_update! rode another kernel
   s->gram_nb = !loop_fused ? s->nb_upd : (fastp ? s->nb_step : spmm_upd_blocks(s));
   enq_boundary(s, 0, 1, 0, 0);
-  if (fastp || edgep) enq_At_preprocess(s, 0);  // leave S consistent with the y of the last step, as g! would
+  if (fastp || edgep) s->S_stale = true;   // y is current, S is assembled by whoever reads it next (ensure_S)
   if ((rc = pull(s))) return rc;
   if (c->done) why = c->exit_reason;   // the device's verdict wins over the host's time check
   if (loop_fused && c->iters > 0 && c->err == 0 && why != EXIT_RELDELTA) {
@@ -2194,6 +2242,7 @@ int32_t sdplr_hip_inner_loop(S* s, double normC, double normb, int32_t grel, int
     return fail(s, SDPLR_ERR_NOT_DESCENT, "Error: cubic[1] should be less than 0.");
   }
   s->st_iters += c->iters;
+  s->P_age += c->iters;
   *Lio = c->L; *gnio = c->gnorm; *pnio = c->pvnorm;
   if (last_alpha) *last_alpha = c->alpha;
   if (iters) *iters = c->iters;
@@ -2206,6 +2255,7 @@ int32_t sdplr_hip_lanczos(S* s, int64_t q, const double* v0, double* alpha, doub
   ApiShared api_guard;
   NEED_FINAL(s);
   if (!v0 || !alpha || !beta || !steps || q < 1) return fail(s, SDPLR_ERR_INVALID_ARG, "lanczos: bad args");
+  ensure_S(s);
   return run_lanczos(s, q, v0, alpha, beta, steps, &api_guard.l);
 }
 int32_t sdplr_hip_tridiag_mineig(const double* alpha, const double* beta, int64_t k, double* out) {
@@ -2238,6 +2288,7 @@ int32_t sdplr_hip_approx_mineigval_lanczos(S* s, int64_t q, const double* v0, do
   ApiShared api_guard;
   NEED_FINAL(s);
   if (!v0 || !mineig || q < 1) return fail(s, SDPLR_ERR_INVALID_ARG, "approx_mineigval_lanczos: bad args");
+  ensure_S(s);
   return approx_mineig_impl(s, q, v0, mineig, &api_guard.l);
 }
 int32_t sdplr_hip_dual_obj(S* s, double trace_bound, int64_t iter, const double* v0, double* dual_value, double* mineig) {
@@ -2246,6 +2297,7 @@ int32_t sdplr_hip_dual_obj(S* s, double trace_bound, int64_t iter, const double*
   if (!v0) return fail(s, SDPLR_ERR_INVALID_ARG, "dual_obj: null v0");
   enq_copy2y(s, 0);              // src/coreop.jl:384
   enq_At_preprocess(s, 0);       // :385
+  s->S_stale = false;
   const double it = (double)std::max<int64_t>(iter, 100);
   const int64_t eig_iter = (int64_t)(2 * std::ceil(std::pow(it, 0.5) * std::log((double)s->n)));  // :402
   double ev = 0.0;
@@ -2319,6 +2371,7 @@ int32_t sdplr_hip_S_eigval(S* s, int64_t nev, int32_t which, int64_t ncv_in, dou
   const int64_t n = s->n;
   if (!evals || nev < 1 || nev > n || (which != 0 && which != 1) || maxiter < 1)
     return fail(s, SDPLR_ERR_INVALID_ARG, "S_eigval: bad args");
+  ensure_S(s);
   int m = (int)std::min<int64_t>(n, std::max<int64_t>(ncv_in > 0 ? ncv_in : 100, std::min<int64_t>(n, 2 * nev + 1)));
   if (m > 256) m = 256;
   if (nev > m) return fail(s, SDPLR_ERR_INVALID_ARG, "S_eigval: nev exceeds the basis size");
