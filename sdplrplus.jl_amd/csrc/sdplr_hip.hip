@@ -87,8 +87,10 @@ struct sdplr_hip_solver {
   bool edge_lr_fused = false;
   DevBand band{};            // full pattern as LDS-band slices for the Lanczos SpMV (k_lz_band)
   bool use_band = false;
-  int nb_tile = 0, nb_step = 1;
+  int nb_tile = 0, nb_step = 1, tile_blocks = 512;
   bool use_tile = false;
+  bool tile_attr_done = false;
+  bool tile_panels = false;  // SDPLR_HIP_TILE_PANELS: 128-byte half-row gathers, two passes over the lists (experiment)
   bool no_updfuse = false;   // SDPLR_HIP_NO_UPDFUSE: lbfgs_update! as a kernel of its own on the singleton fast path
   int gram_nb = 1;           // number of Gram partials the latest enqueued producer writes (k_lbfgs_update / fused step)
   bool force_graph = false;  // SDPLR_HIP_FORCE_GRAPH: hipGraph batches on small instances too (the tests' default)
@@ -331,16 +333,28 @@ int build_tiles(S* s) {
   }
   s->tile_allocs.clear();
   s->use_tile = false;
+  s->tile_attr_done = false;
   s->tile = DevTile{};
   if (s->h_gptr.empty() || n >= (1LL << SDPLR_TILE_COLBITS) || getenv("SDPLR_HIP_NO_TILE") != nullptr) return SDPLR_OK;
   const std::vector<int>&g_ptr = s->h_gptr, &g_col = s->h_gcol;
   const std::vector<double>& g_val = s->h_gval;
   choose_shape(s);
   const int G = SDPLR_NT / s->LPR, L = s->LPR;
-  const int64_t cap = 1024LL * G, nnz = g_ptr[n];
+  // Tile height and grid: the tallest tiles of which TWO blocks fit a CU's 160 KB of LDS (16 rows at r = 32), cut for
+  // 512 blocks — one resident round of 2 blocks per CU.  Measured on the north-star instance (µs per launch):
+  // 1024 blocks × ≤ 8 rows 77, 768 × ≤ 10 64, 512 × ≤ 16 58, 256 × ≤ 32 69; a grid that is not a whole number of
+  // resident rounds (896, 640 blocks; 512 blocks with ≤ 12 rows) costs 77–84.  Longer column-sorted lists keep the
+  // groups closer together in the sweep (the spread of a list's position shrinks as 1/√length), so more of the band
+  // of D they are reading is still in the XCD's L2; fewer resident groups narrow the band further.
+  const size_t lds_row = (size_t)SDPLR_NT * s->VEC * sizeof(double), lds_fix = (size_t)G * 8 * sizeof(double) + 2048;
+  int kmax = (int)std::max<size_t>(1, std::min<size_t>(16, (80 * 1024 - lds_fix) / (lds_row + (size_t)G * 16) - 1));
+  int tblocks = 512;
+  if (const char* e = getenv("SDPLR_HIP_TILE_KMAX")) kmax = std::max(1, std::min(atoi(e), 40));
+  if (const char* e = getenv("SDPLR_HIP_TILE_BLOCKS")) tblocks = std::max(64, std::min(atoi(e), 1024));
+  const int64_t cap = (int64_t)tblocks * G, nnz = g_ptr[n];
   std::vector<int> t_row;
   if (const char* e = getenv("SDPLR_HIP_TILE_K")) {   // fixed tile height (tests)
-    const int kk = std::max(1, std::min(atoi(e), 8));
+    const int kk = std::max(1, std::min(atoi(e), 16));
     for (int64_t r0 = 0; r0 < n; r0 += kk) t_row.push_back((int)r0);
   } else {
     // Tiles of (nearly) equal NONZERO count, at most 8 rows each: a group's position in the column sweep is
@@ -355,11 +369,11 @@ int build_tiles(S* s) {
         t_row.push_back((int)r0);
         const double goal = (double)(t + 1) * (double)(nnz + n) / (double)want;   // rows count as one entry too
         int64_t r1 = r0 + 1;
-        while (r1 < n && r1 - r0 < 8 && (double)(g_ptr[r1 + 1] + r1 + 1) <= goal) r1++;
+        while (r1 < n && r1 - r0 < kmax && (double)(g_ptr[r1 + 1] + r1 + 1) <= goal) r1++;
         r0 = r1;
         t++;
       }
-      if ((int64_t)t_row.size() <= cap || (n + 7) / 8 > cap) break;
+      if ((int64_t)t_row.size() <= cap || (n + kmax - 1) / kmax > cap) break;
       want -= ((int64_t)t_row.size() - cap) + 8;
       if (want < 1) { want = 1; }
     }
@@ -400,6 +414,7 @@ int build_tiles(S* s) {
   s->tile_allocs.assign(s->allocs.begin() + first, s->allocs.end());
   s->tile.K = K;
   s->tile.n_tiles = (int)nt;
+  s->tile_blocks = tblocks;
   s->tile_lpr = L;
   s->use_tile = true;
   return SDPLR_OK;
@@ -530,7 +545,7 @@ int alloc_factors(S* s) {
   s->nb_sddmm = blocks_for(s->nnzT, G, 8192);
   s->nb_edge = blocks_for(s->nnzT, SDPLR_EDGE_POS * G, SDPLR_MAXNB);   // k_sddmm_edge: its per-block partials are folded by one block
   s->nb_spmm = blocks_for(s->n, G, 768);  // + up to 256 hub-row blocks share the partial slot
-  s->nb_tile = blocks_for(s->tile.n_tiles, G, 1024);
+  s->nb_tile = blocks_for(s->tile.n_tiles, G, s->tile_blocks);   // one resident round; taller instances stride
   s->nb_lr = (s->N >= (1LL << 22)) ? 1024 : 256;   // low-rank projection grid (lr_part is sized for 1024)
   { const int tr = std::min<int>(s->LPR, SDPLR_STEP_TR); s->nb_step = blocks_for((s->n + tr - 1) / tr, G, step_fuses_update(s) ? 512 : 1024); }  // one group per tile of LPR rows; its ‖G‖², ‖pv‖² (and Gram)
                                                                     // partials are folded by the one-block seam kernel: keep them few
@@ -801,6 +816,7 @@ int32_t sdplr_hip_finalize(S* s) {
   s->no_lrfuse = getenv("SDPLR_HIP_NO_LRFUSE") != nullptr;
   s->force_graph = getenv("SDPLR_HIP_FORCE_GRAPH") != nullptr;
   s->no_updfuse = getenv("SDPLR_HIP_NO_UPDFUSE") != nullptr;
+  s->tile_panels = getenv("SDPLR_HIP_TILE_PANELS") != nullptr;
   if (s->have_sparse && getenv("SDPLR_HIP_NO_FAST") == nullptr) {
     std::vector<int> general;
     for (int64_t k = 0; k < s->n_sparse; k++) {
@@ -1185,6 +1201,19 @@ namespace {
   if (s->HM == 4) { constexpr int HM = 4; CALL; }               \
   else if (s->HM == 8) { constexpr int HM = 8; CALL; }          \
   else { constexpr int HM = 16; CALL; }
+
+// tiles taller than 8 rows need more than 64 KB of dynamic LDS per block: asked for once per (shape, handle), outside
+// any stream capture (sdplr_hip_inner_loop calls this before it enqueues anything)
+int tile_lds_attr(S* s) {
+  if (!s->use_tile || s->tile_attr_done) return SDPLR_OK;
+  const int bytes = (int)(((size_t)SDPLR_NT * s->VEC * (s->tile.K + 1) + (size_t)(SDPLR_NT / s->LPR) * (2 * s->tile.K + 8) + (size_t)(SDPLR_NT / 64) * 2 * s->LPR * s->VEC) * sizeof(double));
+  hipError_t e = hipSuccess;
+  LV_DISPATCH((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_spmm_tile<LPR, VEC, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes)))
+  if (e == hipSuccess) { LV_DISPATCH((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_spmm_tile<LPR, VEC, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes))) }
+  if (e != hipSuccess) return fail(s, SDPLR_ERR_HIP, std::string("hipFuncSetAttribute(k_spmm_tile): ") + hipGetErrorString(e));
+  s->tile_attr_done = true;
+  return SDPLR_OK;
+}
 
 // W = X0ᵀB (and X1ᵀB) followed by the mode-specific tail of k_lr_finalize
 void enq_lowrank(S* s, const double* X0, const double* X1, int F, int mode, double* out0, double* out1, int chk) {
@@ -1573,6 +1602,12 @@ void enq_iteration_fast2(S* s) {
       lr_fused = s->lr.ST == 1 && s->r <= (int64_t)s->LPR * s->VEC && !s->no_lrfuse;
       const size_t lds = ((size_t)SDPLR_NT * s->VEC * (s->tile.K + 1) + (size_t)(SDPLR_NT / s->LPR) * (2 * s->tile.K + 8) + (lr_fused ? (size_t)(SDPLR_NT / 64) * 2 * s->LPR * s->VEC : 0)) * sizeof(double);
       if (lr_fused) { LV_DISPATCH((k_spmm_tile<LPR, VEC, 1><<<s->nb_tile, SDPLR_NT, lds, s->stream>>>(s->tile, (int)s->n, (int)s->m, s->ff, R, D, P, W, (int)s->r, s->lambda, s->pv_raw, s->A_RD, s->A_DD, s->partials, s->ctrl, 1, s->lr, s->lr_part, 0))) }
+      else if (s->tile_panels && s->VEC == 2 && s->LPR == 16) {
+        // rank panels: the same kernel with 8 bytes per lane walks the lists once per 16-column half of the rank, so a
+        // gathered row is 128 B and the XCD's L2 holds twice as many of them (tile kernel)
+        const size_t lds1 = ((size_t)SDPLR_NT * 1 * (s->tile.K + 1) + (size_t)(SDPLR_NT / s->LPR) * (2 * s->tile.K + 8)) * sizeof(double);
+        k_spmm_tile<16, 1, 0><<<s->nb_tile, SDPLR_NT, lds1, s->stream>>>(s->tile, (int)s->n, (int)s->m, s->ff, R, D, P, W, (int)s->r, s->lambda, s->pv_raw, s->A_RD, s->A_DD, s->partials, s->ctrl, 1, s->lr, s->lr_part, 0);
+      }
       else { LV_DISPATCH((k_spmm_tile<LPR, VEC, 0><<<s->nb_tile, SDPLR_NT, lds, s->stream>>>(s->tile, (int)s->n, (int)s->m, s->ff, R, D, P, W, (int)s->r, s->lambda, s->pv_raw, s->A_RD, s->A_DD, s->partials, s->ctrl, 1, s->lr, s->lr_part, 0))) }
     } else {
       LV_DISPATCH((k_spmm_fast<LPR, VEC><<<s->nb_spmm, SDPLR_NT, 0, s->stream>>>(s->spg, (int)s->m, s->ff, R, D, P, W, (int)s->r, s->lambda, s->pv_raw, s->A_RD, s->A_DD, s->partials, s->ctrl, 1)))
@@ -2070,8 +2105,9 @@ int32_t sdplr_hip_inner_loop(S* s, double normC, double normb, int32_t grel, int
   NEED_FINAL(s);
   if (!Lio || !gnio || !pnio || max_local_iters < 1) return fail(s, SDPLR_ERR_INVALID_ARG, "inner_loop: bad args");
   ensure_gram(s);
-  int rc = pull(s);
+  int rc = tile_lds_attr(s);
   if (rc) return rc;
+  if ((rc = pull(s))) return rc;
   DevCtrl* c = s->hc;
   c->done = 0; c->exit_reason = 0; c->err = 0; c->use_armijo = use_armijo;
   c->iters = 0; c->max_iters = max_local_iters; c->reldelta_exit = 0; c->norms_pending = 0; c->pv2_extra = 0.0;

@@ -543,6 +543,7 @@ def test_code_paths_agree(hip_abi, oracle_abi, family, toggles, monkeypatch):
     (1, 90, 0.2, None), (2, 90, 0.2, None), (3, 64, 0.3, 4), (5, 70, 0.3, None), (8, 120, 0.1, 8),
     (16, 150, 0.1, 3), (27, 150, 0.1, None), (32, 400, 0.05, 8), (32, 1000, 0.02, None), (48, 200, 0.1, 5),
     (64, 130, 0.2, 8), (100, 90, 0.3, 2), (128, 70, 0.3, None), (200, 60, 0.4, 7),
+    (32, 600, 0.04, 16), (32, 500, 0.05, 13), (10, 300, 0.05, 16), (33, 200, 0.1, 11),     # tiles taller than 8 rows
 ])
 def test_column_sweep_tiles_match_row_kernel(hip_abi, oracle_abi, r, n, p, tile_k, monkeypatch):
     """W = A_g·D on the singleton fast path has two forms: one sub-wave group per row (k_spmm_fast) and the
