@@ -218,7 +218,8 @@ def main():
     if args.gpus < 1:
         print("bench.py: --gpus must be ≥ 1", file=sys.stderr)
         return 2
-    if env_world is None and args.gpus > 1:
+    if env_world is None and (args.gpus > 1 or os.environ.get("SDPLR_BENCH_FORCE_LAUNCH")):
+        # (SDPLR_BENCH_FORCE_LAUNCH: take the launcher route for N = 1 too — rehearses spawn + RCCL on a one-GPU box)
         return launch_children(args)            # the parent never imports torch / the HIP library
     if env_world is not None and int(env_world) != args.gpus:
         print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={env_world}: launch with --nproc-per-node {args.gpus}",
@@ -234,7 +235,7 @@ def main():
     from sdplrplus_jl_amd import problems
     selftest = args.selftest_cpu
     dist = None
-    if world > 1 or os.environ.get("SDPLR_BENCH_FORCE_DIST"):
+    if world > 1 or os.environ.get("SDPLR_BENCH_FORCE_DIST") or os.environ.get("SDPLR_BENCH_FORCE_LAUNCH"):
         # torch first: its wheel bundles a HIP runtime with the same SONAME as /opt/rocm's, and whichever is
         # loaded first serves both torch and libsdplr_hip.so — one runtime per process either way
         import torch
@@ -284,8 +285,10 @@ def main():
     barrier()
     t0 = time.perf_counter()
     state = run_fixed(var, normC, normb, state, K)      # timed region: hipGraph batches, no events
-    barrier()
+    abi.device_synchronize()                            # this rank's K steps are complete here …
     dt = time.perf_counter() - t0
+    barrier()                                           # … the closing barrier brackets the region; the MAX over ranks of
+                                                        # dt (below) is the time until the slowest rank was done
     obj = var.obj
 
     # Per-kernel device time: the same iteration stream replayed eagerly right after the timed
@@ -366,7 +369,8 @@ def reduce_over_ranks(dist, dt, obj, device):
     """max-over-ranks of the timed region and the per-rank objectives — the only collectives of the
     workload (RCCL over xGMI on the GPU node; gloo in tests/test_batch_gloo.py)."""
     if dist is None or not dist.is_initialized() or (
-            dist.get_world_size() == 1 and not os.environ.get("SDPLR_BENCH_FORCE_DIST")):
+            dist.get_world_size() == 1 and not os.environ.get("SDPLR_BENCH_FORCE_DIST")
+            and not os.environ.get("SDPLR_BENCH_FORCE_LAUNCH")):
         return dt, [obj]
     import torch
     world = dist.get_world_size()
