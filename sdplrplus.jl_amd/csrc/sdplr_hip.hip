@@ -545,6 +545,7 @@ int alloc_factors(S* s) {
   s->nb_sddmm = blocks_for(s->nnzT, G, 8192);
   s->nb_edge = blocks_for(s->nnzT, SDPLR_EDGE_POS * G, SDPLR_MAXNB);   // k_sddmm_edge: its per-block partials are folded by one block
   s->nb_spmm = blocks_for(s->n, G, 768);  // + up to 256 hub-row blocks share the partial slot
+  if (const char* e = getenv("SDPLR_HIP_NB_SPMM")) s->nb_spmm = std::max(1, std::min(atoi(e), 768));
   s->nb_tile = blocks_for(s->tile.n_tiles, G, s->tile_blocks);   // one resident round; taller instances stride
   s->nb_lr = (s->N >= (1LL << 22)) ? 1024 : 256;   // low-rank projection grid (lr_part is sized for 1024)
   { const int tr = std::min<int>(s->LPR, SDPLR_STEP_TR); s->nb_step = blocks_for((s->n + tr - 1) / tr, G, step_fuses_update(s) ? 512 : 1024); }  // one group per tile of LPR rows; its ‖G‖², ‖pv‖² (and Gram)
@@ -675,6 +676,15 @@ int32_t sdplr_hip_finalize(S* s) {
   HIPCK(s, hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
   const int64_t n = s->n, m = s->m;
   int rc;
+  // SDPLR_HIP_TIMING=1: where the set-up time goes (stderr)
+  const bool timing = getenv("SDPLR_HIP_TIMING") != nullptr;
+  auto t_last = std::chrono::steady_clock::now();
+  auto lap = [&](const char* what) {
+    if (!timing) return;
+    const auto t = std::chrono::steady_clock::now();
+    fprintf(stderr, "[sdplr_hip finalize] %-28s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(t - t_last).count());
+    t_last = t;
+  };
   // ---- sparse layout ----
   DevSparse& sp = s->sp;
   sp.n = (int)n; sp.nnzT = (int)s->nnzT; sp.nnzS = (int)s->nnzS; sp.nnzAgg = (int)s->nnzAgg; sp.n_sparse = (int)s->n_sparse;
@@ -717,6 +727,7 @@ int32_t sdplr_hip_finalize(S* s) {
     for (auto& L : s->h_lr) cov[L.gid] = 1;
     s->all_covered = std::all_of(cov.begin(), cov.end(), [](char c) { return c != 0; });
   }
+  lap("transpose + reduction plan");
 #define UP(field, vec) if ((rc = upload(s, &sp.field, vec))) return rc
   UP(triu_colptr, s->h_tcp); UP(triu_rowval, s->h_trv); UP(triu_colidx, colidx);
   UP(colptr, s->h_fcp); UP(rowval, s->h_frv); UP(mapped, s->h_mapped);
@@ -739,8 +750,10 @@ int32_t sdplr_hip_finalize(S* s) {
     dst.long_thresh = thresh;
     return upload(s, &dst.long_rows, rows);
   };
+  lap("uploads (layout)");
   if ((rc = plan_long(s->h_fcp, sp))) return rc;
   if ((rc = build_band(s))) return rc;
+  lap("band plan");
   if ((rc = dzero(s, &sp.nzval, s->nnzS))) return rc;
   if ((rc = dzero(s, &sp.triu_nzval, s->nnzT))) return rc;
   if ((rc = dzero(s, &sp.UVt0, s->nnzT))) return rc;
@@ -810,6 +823,7 @@ int32_t sdplr_hip_finalize(S* s) {
       HIPCK(s, hipEventCreateWithFlags(&s->snap_ev[k], hipEventDisableTiming));
     }
   }
+  lap("vectors + control block");
   // ---- structured fast path: classify the sparse matrices ----
   s->dot_descent = getenv("SDPLR_HIP_DOT_DESCENT") != nullptr;
   if (const char* e = getenv("SDPLR_HIP_GRAPH_ITERS")) s->graph_iters = std::max(1, std::min(atoi(e), 64));
@@ -828,23 +842,49 @@ int32_t sdplr_hip_finalize(S* s) {
     if (general.size() == 1) {
       const int kg = general[0];
       // A_g as a symmetric CSR (mirror the upper-triangular entries, merge duplicates)
-      struct Ent { int i, j; double v; };
-      std::vector<Ent> ents;
-      for (int e = s->h_matptr[kg]; e < s->h_matptr[kg + 1]; e++) {
-        const int q = s->h_nzind[e], i = s->h_trv[q], j = colidx[q];
-        ents.push_back({i, j, s->h_one[e]});
-        if (i != j) ents.push_back({j, i, s->h_one[e]});
-      }
-      std::sort(ents.begin(), ents.end(), [](const Ent& a, const Ent& b) { return a.i != b.i ? a.i < b.i : a.j < b.j; });
       std::vector<int> g_ptr(n + 1, 0), g_col;
       std::vector<double> g_val;
-      for (size_t t = 0; t < ents.size(); t++) {
-        if (t > 0 && ents[t].i == ents[t - 1].i && ents[t].j == ents[t - 1].j) { g_val.back() += ents[t].v; continue; }
-        g_col.push_back(ents[t].j);
-        g_val.push_back(ents[t].v);
-        g_ptr[ents[t].i + 1]++;
+      const int eb = s->h_matptr[kg], ee = s->h_matptr[kg + 1];
+      bool ascending = true;   // positions of the (column-major) triu pattern, strictly ascending: the usual case
+      for (int e = eb + 1; e < ee && ascending; e++) ascending = s->h_nzind[e] > s->h_nzind[e - 1];
+      if (ascending) {
+        // two counting passes: row j first receives its mirrored entries (i < j, ascending i as column j is
+        // walked), then row i its own upper entries (j ≥ i, ascending j) — every row comes out sorted by column
+        for (int e = eb; e < ee; e++) {
+          const int q = s->h_nzind[e], i = s->h_trv[q], j = colidx[q];
+          g_ptr[i + 1]++;
+          if (i != j) g_ptr[j + 1]++;
+        }
+        for (int64_t i = 0; i < n; i++) g_ptr[i + 1] += g_ptr[i];
+        g_col.resize(g_ptr[n]);
+        g_val.resize(g_ptr[n]);
+        std::vector<int> fillg(g_ptr.begin(), g_ptr.end() - 1);
+        for (int e = eb; e < ee; e++) {
+          const int q = s->h_nzind[e], i = s->h_trv[q], j = colidx[q];
+          if (i != j) { const int pos = fillg[j]++; g_col[pos] = i; g_val[pos] = s->h_one[e]; }
+        }
+        for (int e = eb; e < ee; e++) {
+          const int q = s->h_nzind[e], i = s->h_trv[q], j = colidx[q];
+          const int pos = fillg[i]++; g_col[pos] = j; g_val[pos] = s->h_one[e];
+        }
+      } else {
+        struct Ent { int i, j; double v; };
+        std::vector<Ent> ents;
+        for (int e = eb; e < ee; e++) {
+          const int q = s->h_nzind[e], i = s->h_trv[q], j = colidx[q];
+          ents.push_back({i, j, s->h_one[e]});
+          if (i != j) ents.push_back({j, i, s->h_one[e]});
+        }
+        std::stable_sort(ents.begin(), ents.end(), [](const Ent& a, const Ent& b) { return a.i != b.i ? a.i < b.i : a.j < b.j; });
+        for (size_t t = 0; t < ents.size(); t++) {
+          if (t > 0 && ents[t].i == ents[t - 1].i && ents[t].j == ents[t - 1].j) { g_val.back() += ents[t].v; continue; }
+          g_col.push_back(ents[t].j);
+          g_val.push_back(ents[t].v);
+          g_ptr[ents[t].i + 1]++;
+        }
+        for (int64_t i = 0; i < n; i++) g_ptr[i + 1] += g_ptr[i];
       }
-      for (int64_t i = 0; i < n; i++) g_ptr[i + 1] += g_ptr[i];
+      lap("A_g CSR");
       // diagonal-only matrices, by row, ascending matrix order
       std::vector<int> d_ptr(n + 1, 0);
       for (int64_t k = 0; k < s->n_sparse; k++)
@@ -896,7 +936,9 @@ int32_t sdplr_hip_finalize(S* s) {
       // host copy of A_g's CSR: the column-sweep tiles depend on the sub-wave width, i.e. on the rank, and are
       // rebuilt by reset_rank
       s->h_gptr = g_ptr; s->h_gcol = g_col; s->h_gval = g_val;
+      lap("diagonal lists + uploads");
       if ((rc = build_tiles(s))) return rc;
+      lap("tiles");
       s->ff.gid_g = s->h_gids[kg];
       if ((rc = upload(s, &s->ff.diagpos, diagpos))) return rc;
       if ((rc = upload(s, &s->ff.drow_ptr, d_ptr))) return rc;
@@ -984,7 +1026,9 @@ int32_t sdplr_hip_finalize(S* s) {
       s->edge = true;
     }
   }
+  lap("classification / edge plan");
   if ((rc = alloc_factors(s))) return rc;
+  lap("factors");
   s->nb_m = blocks_for(m + 1, SDPLR_NT, 256);
   s->nb_spmv = blocks_for(n, SDPLR_NT / 8, 768);
   s->nb_nnzT = blocks_for(s->nnzT, SDPLR_NT, 4096);
