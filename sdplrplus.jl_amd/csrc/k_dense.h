@@ -156,6 +156,155 @@ __device__ inline void seam_serial(SeamLds& gd, int h, int jfixed, int fin_mode,
   }
 }
 
+// seam_serial for h = H ≤ 4, the same arithmetic in the same order, laid out for latency: thread 0 fetches what it
+// needs from the LDS copy in a few batches of independent reads (the Gram data permuted into time order, newest first,
+// so that every index below is a compile-time constant and the recursion runs in registers) instead of one dependent LDS
+// round trip per operand — measured with s_memtime on the north-star instance: 11.7 k cycles → see DESIGN.md §10.
+template <int H>
+__device__ inline void seam_serial_small(SeamLds& gd, int jfixed, int fin_mode, int do_loop, int do_coeff,
+                                         bool fin, bool norms, int desc_mode) {
+  DevCtrl& c = gd.c;
+  // batch 1: every scalar of the loop tests and the norms
+  int latest = c.latest;
+  const int done0 = c.done, rde = c.reldelta_exit, grel = c.grel, prel = c.prel;
+  const long long iters = c.iters, max_iters = c.max_iters;
+  const double cur_gtol = c.cur_gtol, Lcur = c.L, normC = c.normC, normb = c.normb, pv2x = c.pv2_extra;
+  const double nrm0 = gd.nrm[0], nrm1 = gd.nrm[1];
+  double gnorm = c.gnorm;
+  if (fin) {
+    const int j = (fin_mode == 1) ? (latest % H) : jfixed;
+    double rd[5][H];
+#pragma unroll
+    for (int q = 0; q < 5; q++)
+#pragma unroll
+      for (int l = 0; l < H; l++) rd[q][l] = gd.red[q * SDPLR_HMAX + l];
+#pragma unroll
+    for (int l = 0; l < H; l++) {
+      c.SY[j * SDPLR_HMAX + l] = rd[0][l];
+      if (l != j) c.SY[l * SDPLR_HMAX + j] = rd[1][l];
+      c.YY[j * SDPLR_HMAX + l] = rd[2][l];
+      c.YY[l * SDPLR_HMAX + j] = rd[2][l];
+      c.Sg[l] = rd[3][l];
+      c.Yg[l] = rd[4][l];
+    }
+    if (fin_mode == 1) {
+      double syjj = 0.0;   // = c.SY[j][j] as just stored
+#pragma unroll
+      for (int l = 0; l < H; l++)
+        if (l == j) syjj = rd[0][l];
+      c.rho[j] = 1.0 / syjj;
+      latest = j + 1;
+      c.latest = latest;
+      c.gram_pending = 0;
+    }
+  }
+  if (norms) {
+    const double g = sqrt(nrm0), pn = sqrt(nrm1 + pv2x);
+    gnorm = grel ? g / normC : g;
+    c.gnorm = gnorm;
+    c.pvnorm = prel ? pn / normb : pn;
+    c.norms_pending = 0;
+  }
+  if (do_loop) {
+    if (done0) return;
+    if (rde) {                                        // :238-241 (after g! and the norms)
+      c.reldelta_exit = 0;
+      c.done = 1;
+      c.exit_reason = EXIT_RELDELTA;
+      return;
+    }
+    if (iters > 0 && iters >= max_iters) {            // :272-277 (checked after the update)
+      c.done = 1;
+      c.exit_reason = EXIT_ITERS;
+      return;
+    }
+    if (!(gnorm > cur_gtol)) {                        // :190
+      c.done = 1;
+      c.exit_reason = EXIT_GTOL;
+      return;
+    }
+    c.iters = iters + 1;
+    c.lastval = Lcur;
+  }
+  // batch 2: the Gram data in time order (position 0 = newest slot), src/lbfgs.jl:93-113
+  int ord[H];
+  {
+    int j = latest - 1;
+#pragma unroll
+    for (int i = 0; i < H; i++) {
+      ord[i] = j;
+      j = (j <= 0) ? H - 1 : j - 1;
+    }
+  }
+  double Sg_s[H], Yg_s[H];   // by slot (the descent sum below runs over slots)
+#pragma unroll
+  for (int l = 0; l < H; l++) {
+    Sg_s[l] = c.Sg[l];
+    Yg_s[l] = c.Yg[l];
+  }
+  double al_s[H], ga_s[H];   // coefficients by slot
+#pragma unroll
+  for (int l = 0; l < H; l++) {
+    al_s[l] = c.c_alpha[l];
+    ga_s[l] = c.c_gamma[l];
+  }
+  if (do_coeff) {
+    double SYp[H][H], YYp[H][H], Sgp[H], Ygp[H], rhop[H];
+#pragma unroll
+    for (int a = 0; a < H; a++) {
+      Sgp[a] = c.Sg[ord[a]];
+      Ygp[a] = c.Yg[ord[a]];
+      rhop[a] = c.rho[ord[a]];
+#pragma unroll
+      for (int b = 0; b < H; b++) {
+        SYp[a][b] = c.SY[ord[a] * SDPLR_HMAX + ord[b]];
+        YYp[a][b] = c.YY[ord[a] * SDPLR_HMAX + ord[b]];
+      }
+    }
+    double al[H], ga[H];
+#pragma unroll
+    for (int i = 0; i < H; i++) {        // α_j = ρ_j ⟨s_j, q⟩,  q = G − Σ_{newer l} α_l y_l
+      double sq = Sgp[i];
+#pragma unroll
+      for (int k = 0; k < i; k++) sq -= al[k] * SYp[i][k];
+      al[i] = rhop[i] * sq;
+    }
+#pragma unroll
+    for (int i = H - 1; i >= 0; i--) {   // β_j = ρ_j ⟨y_j, r⟩,  r = q + Σ_{older l} γ_l s_l
+      double yr = Ygp[i];
+#pragma unroll
+      for (int k = 0; k < H; k++) yr -= al[k] * YYp[i][k];
+#pragma unroll
+      for (int k = H - 1; k > i; k--) yr += ga[k] * SYp[k][i];
+      const double beta = rhop[i] * yr;
+      ga[i] = al[i] - beta;              // γ = a − β  (:107)
+    }
+#pragma unroll
+    for (int i = 0; i < H; i++) {
+      c.a[ord[i]] = al[i];               // lbfgshis.vecs[j].a[] = α  (:97)
+      c.c_alpha[ord[i]] = al[i];
+      c.c_gamma[ord[i]] = ga[i];
+#pragma unroll
+      for (int l = 0; l < H; l++)
+        if (ord[i] == l) {
+          al_s[l] = al[i];
+          ga_s[l] = ga[i];
+        }
+    }
+  }
+  if (desc_mode) {
+    const double g = grel ? gnorm * normC : gnorm;
+    double d = norms ? nrm0 : g * g;
+#pragma unroll
+    for (int l = 0; l < H; l++) d -= al_s[l] * Yg_s[l];
+#pragma unroll
+    for (int l = 0; l < H; l++) d += ga_s[l] * Sg_s[l];
+    if (desc_mode == 1) d = -d;
+    c.descent = d;
+    c.fallback = (isnan(d) || d >= 0.0) ? 1 : 0;
+  }
+}
+
 // The seam between two inner iterations, one block of 1024 threads:
 //  1. fold the partials of the preceding k_lbfgs_update into the Gram data —
 //     fin_mode 1: only if that kernel ran (c->gram_pending), then ρ_j = 1/⟨y_j,s_j⟩ (src/lbfgs.jl:146)
@@ -171,6 +320,9 @@ k_lbfgs_boundary(DevCtrl* __restrict__ c, int h, int jfixed, int fin_mode, int d
                  int nb_partials, const double* __restrict__ partials, int desc_mode) {
   __shared__ SeamLds gd;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+#ifdef SDPLR_STAMPS
+  const unsigned long long st0 = __builtin_amdgcn_s_memtime();
+#endif
   // Everything this kernel reads from global memory is requested in one go — the flags, the control block
   // and the partials (summed whether or not the flags will want them) — so the kernel pays one memory round
   // trip, not flag → count → partials.
@@ -216,13 +368,33 @@ k_lbfgs_boundary(DevCtrl* __restrict__ c, int h, int jfixed, int fin_mode, int d
   const bool norms = np != 0;
   if (!fin && !do_coeff && !do_loop && !norms) return;
   __syncthreads();
-  if (tid == 0) seam_serial(gd, h, jfixed, fin_mode, do_loop, do_coeff, fin, norms, desc_mode);
+#ifdef SDPLR_STAMPS
+  const unsigned long long st1 = __builtin_amdgcn_s_memtime();
+#endif
+  if (tid == 0) {
+    switch (h) {
+      case 1: seam_serial_small<1>(gd, jfixed, fin_mode, do_loop, do_coeff, fin, norms, desc_mode); break;
+      case 2: seam_serial_small<2>(gd, jfixed, fin_mode, do_loop, do_coeff, fin, norms, desc_mode); break;
+      case 3: seam_serial_small<3>(gd, jfixed, fin_mode, do_loop, do_coeff, fin, norms, desc_mode); break;
+      case 4: seam_serial_small<4>(gd, jfixed, fin_mode, do_loop, do_coeff, fin, norms, desc_mode); break;
+      default: seam_serial(gd, h, jfixed, fin_mode, do_loop, do_coeff, fin, norms, desc_mode);
+    }
+  }
   __syncthreads();
+#ifdef SDPLR_STAMPS
+  const unsigned long long st2 = __builtin_amdgcn_s_memtime();
+#endif
   {
     const unsigned long long* src = reinterpret_cast<const unsigned long long*>(&gd.c);
     unsigned long long* dst = reinterpret_cast<unsigned long long*>(c);
     for (int t = tid; t < (int)(sizeof(DevCtrl) / 8); t += 1024) dst[t] = src[t];
   }
+#ifdef SDPLR_STAMPS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  const unsigned long long st3 = __builtin_amdgcn_s_memtime();
+  if (tid == 0 && do_loop && (gd.c.iters % 64) == 33)
+    printf("[seam] loads+sums %llu  serial %llu  store %llu (s_memtime ticks)\n", st1 - st0, st2 - st1, st3 - st2);
+#endif
 }
 
 // ---- direction: dir = ∓(G − Σ α_l y_l + Σ γ_l s_l); y_next = −G; partial ⟨dir, G⟩ -----------------

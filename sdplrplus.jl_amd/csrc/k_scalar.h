@@ -446,6 +446,7 @@ k_lz_update2(DevCtrl* __restrict__ c, int n, int step, double* __restrict__ Av, 
 // arrays are SDPLR_MAXNB wide); `red2` ≠ null: sums 8 and 9 (the big matrix) were already folded by k_edge_sums.
 #define SDPLR_LSF_NT SDPLR_NT
 #define SDPLR_LSF_EXMAX 16
+struct ExtraHead { int k[4]; };   // the first extra slots by value: their data is requested without waiting for the index list
 __global__ void __launch_bounds__(SDPLR_LSF_NT)
 k_ls_solve_fast(DevCtrl* __restrict__ c, int m, int gid_g, int n_extra, const int* __restrict__ extra,
                 int nb, double* __restrict__ A_RD, double* __restrict__ A_DD,
@@ -455,8 +456,12 @@ k_ls_solve_fast(DevCtrl* __restrict__ c, int m, int gid_g, int n_extra, const in
                 const double* __restrict__ lr_D, double* __restrict__ lrW, double* __restrict__ lrWS,
                 const double* __restrict__ partials, int check_done,
                 int lr_tail, int lr_n, const int* __restrict__ lr_mat_ptr, const int* __restrict__ lr_mat_gid,
-                const double* __restrict__ red2 = nullptr) {
+                const double* __restrict__ red2, ExtraHead eh) {
   __shared__ double sh[10 * (SDPLR_LSF_NT / 64)];
+#ifdef SDPLR_STAMPS
+  const unsigned long long st0 = __builtin_amdgcn_s_memtime();
+  const long long stamp_it = c->iters;
+#endif
   const int dn = check_done ? c->done : 0;
   // every scalar the serial part needs, requested up front: their latency overlaps the partial sums below
   // instead of forming a chain of dependent global round trips in thread 0
@@ -471,7 +476,11 @@ k_ls_solve_fast(DevCtrl* __restrict__ c, int m, int gid_g, int n_extra, const in
   __shared__ int ex_k[SDPLR_LSF_EXMAX];
   __shared__ double ex_v[SDPLR_LSF_EXMAX][4];   // λ, λ_ub, primal_vio_raw, lb
   if ((int)threadIdx.x < n_extra && threadIdx.x < SDPLR_LSF_EXMAX) {
-    const int k = extra[threadIdx.x];
+    int k = eh.k[0];
+    if (threadIdx.x == 1) k = eh.k[1];
+    if (threadIdx.x == 2) k = eh.k[2];
+    if (threadIdx.x == 3) k = eh.k[3];
+    if (threadIdx.x >= 4) k = extra[threadIdx.x];
     ex_k[threadIdx.x] = k;
     const int kc = min(k, m - (m > 0));
     ex_v[threadIdx.x][0] = lam[kc];
@@ -555,6 +564,9 @@ k_ls_solve_fast(DevCtrl* __restrict__ c, int m, int gid_g, int n_extra, const in
   }
   __shared__ double sh_alpha;
   __shared__ int sh_err;
+#ifdef SDPLR_STAMPS
+  const unsigned long long st1 = __builtin_amdgcn_s_memtime();
+#endif
   if (threadIdx.x == 0) {
     const double g_rd = s[8] + s[8], g_dd = s[9];
     if (gid_g >= 0) {     // (−1: the edge path without a multi-entry matrix)
@@ -618,6 +630,13 @@ k_ls_solve_fast(DevCtrl* __restrict__ c, int m, int gid_g, int n_extra, const in
     }
   }
   __syncthreads();
+#ifdef SDPLR_STAMPS
+  if (threadIdx.x == 0 && (stamp_it % 64) == 33) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned long long st2 = __builtin_amdgcn_s_memtime();
+    printf("[ls_solve_fast] loads+sums %llu  serial+stores %llu (s_memtime ticks)\n", st1 - st0, st2 - st1);
+  }
+#endif
   if (sh_err != 0) return;
   const double a = sh_alpha;
   const int per = lr_ST * r;

@@ -842,6 +842,9 @@ k_fast_step2(int n, int m, DevFast ff, double* __restrict__ R, double* __restric
     // in-loop direction kernel skips that store: N bytes per iteration less)
     // (gold_in_G; if the direction kernel took the steepest-descent fallback it has flipped G: sign gs)
     if (HMU > 0 && gold_in_G && l == jslot) ylp[l] = Gout;
+    // the old s_j is overwritten, never used: its (unconditional) load is pointed at the D row this lane has just
+    // requested — a cache hit instead of N bytes from memory
+    if (HMU > 0 && l == jslot) slp[l] = D;
   }
   if (HMU > 0) {
 #pragma unroll

@@ -83,6 +83,7 @@ struct sdplr_hip_solver {
   DevTile tile{};            // the same matrix as column-sorted K-row tiles (k_spmm_tile)
   bool edge = false;         // edge path (k_sparse.h): disjoint supports, at most one multi-entry sparse matrix
   const int* edge_extra = nullptr;   // its extra slots: the multi-entry matrix and the low-rank matrices
+  ExtraHead edge_extra_head{}, extra_head{};   // the first four of each list, passed to k_ls_solve_fast by value
   int n_edge_extra = 0, nb_edge = 1;
   bool edge_lr_fused = false;
   DevBand band{};            // full pattern as LDS-band slices for the Lanczos SpMV (k_lz_band)
@@ -951,6 +952,7 @@ int32_t sdplr_hip_finalize(S* s) {
       std::vector<int> extra(1, s->h_gids[kg]);
       for (auto& L : s->h_lr) extra.push_back((int)L.gid);
       if ((rc = upload(s, &s->extra_slots, extra))) return rc;
+      for (size_t t = 0; t < 4; t++) s->extra_head.k[t] = t < extra.size() ? extra[t] : 0;
       s->n_extra = (int)extra.size();
       s->fast_singleton = single && s->spg.n_long_rows == 0 && getenv("SDPLR_HIP_NO_FAST2") == nullptr;
     }
@@ -1012,6 +1014,7 @@ int32_t sdplr_hip_finalize(S* s) {
       if (big >= 0) extra.push_back(big);
       for (auto& L : s->h_lr) extra.push_back((int)L.gid);
       if ((rc = upload(s, &s->edge_extra, extra))) return rc;
+      for (size_t t = 0; t < 4; t++) s->edge_extra_head.k[t] = t < extra.size() ? extra[t] : 0;
       s->n_edge_extra = (int)extra.size();
       // the low-rank projections ride the SDDMM when there is one column and every row has a diagonal position
       bool all_diag = true;
@@ -1510,7 +1513,7 @@ void enq_iteration_edge(S* s) {
   }
   {
     ProfScope ps(s, "ls_solve_fast");
-    k_ls_solve_fast<<<1, SDPLR_LSF_NT, 0, s->stream>>>(s->ctrl, (int)s->m, s->sp.big_gid, s->n_edge_extra, s->edge_extra, nb_c, s->A_RD, s->A_DD, s->lambda, s->lambda_ub, s->pv_raw, s->pv_lb, s->pv, s->y, s->lr.ST, (int)s->r, s->lr.col_gid, s->lr.Dcat, s->lr_W, s->lr_WS, s->partials, 1, lrf ? 1 : 0, s->lr.n_lr, s->lr.mat_ptr, s->lr.mat_gid, s->red10);
+    k_ls_solve_fast<<<1, SDPLR_LSF_NT, 0, s->stream>>>(s->ctrl, (int)s->m, s->sp.big_gid, s->n_edge_extra, s->edge_extra, nb_c, s->A_RD, s->A_DD, s->lambda, s->lambda_ub, s->pv_raw, s->pv_lb, s->pv, s->y, s->lr.ST, (int)s->r, s->lr.col_gid, s->lr.Dcat, s->lr_W, s->lr_WS, s->partials, 1, lrf ? 1 : 0, s->lr.n_lr, s->lr.mat_ptr, s->lr.mat_gid, s->red10, s->edge_extra_head);
   }
   const int nbl = std::min(s->sp.n_long_rows, 256);
   {
@@ -1667,7 +1670,7 @@ void enq_iteration_fast2(S* s) {
   }
   {
     ProfScope ps(s, "ls_solve_fast");
-    k_ls_solve_fast<<<1, SDPLR_LSF_NT, 0, s->stream>>>(s->ctrl, (int)s->m, s->ff.gid_g, s->n_extra, s->extra_slots, (s->use_tile && s->tile_lpr == s->LPR && s->n * s->r * 8 < (1LL << 32)) ? s->nb_tile : s->nb_spmm, s->A_RD, s->A_DD, s->lambda, s->lambda_ub, s->pv_raw, s->pv_lb, s->pv, s->y, s->lr.ST, (int)s->r, s->lr.col_gid, s->lr.Dcat, s->lr_W, s->lr_WS, s->partials, 1, lr_fused ? 1 : 0, s->lr.n_lr, s->lr.mat_ptr, s->lr.mat_gid);
+    k_ls_solve_fast<<<1, SDPLR_LSF_NT, 0, s->stream>>>(s->ctrl, (int)s->m, s->ff.gid_g, s->n_extra, s->extra_slots, (s->use_tile && s->tile_lpr == s->LPR && s->n * s->r * 8 < (1LL << 32)) ? s->nb_tile : s->nb_spmm, s->A_RD, s->A_DD, s->lambda, s->lambda_ub, s->pv_raw, s->pv_lb, s->pv, s->y, s->lr.ST, (int)s->r, s->lr.col_gid, s->lr.Dcat, s->lr_W, s->lr_WS, s->partials, 1, lr_fused ? 1 : 0, s->lr.n_lr, s->lr.mat_ptr, s->lr.mat_gid, nullptr, s->extra_head);
   }
   // (a variant fusing this step kernel with lbfgs_update! was measured at 111 µs against 38 + 59 µs for the
   // two kernels — 166 VGPRs and scratch — and dropped)
