@@ -446,6 +446,8 @@ k_lz_update2(DevCtrl* __restrict__ c, int n, int step, double* __restrict__ Av, 
 // arrays are SDPLR_MAXNB wide); `red2` ≠ null: sums 8 and 9 (the big matrix) were already folded by k_edge_sums.
 #define SDPLR_LSF_NT SDPLR_NT
 #define SDPLR_LSF_EXMAX 16
+#define SDPLR_LSF_LRW 512     /* doubles of low-rank projections staged in LDS (2·ST·r) */
+#define SDPLR_LSF_LRN 16      /* low-rank matrices whose line-search values are kept in LDS */
 struct ExtraHead { int k[4]; };   // the first extra slots by value: their data is requested without waiting for the index list
 __global__ void __launch_bounds__(SDPLR_LSF_NT)
 k_ls_solve_fast(DevCtrl* __restrict__ c, int m, int gid_g, int n_extra, const int* __restrict__ extra,
@@ -466,10 +468,18 @@ k_ls_solve_fast(DevCtrl* __restrict__ c, int m, int gid_g, int n_extra, const in
   // every scalar the serial part needs, requested up front: their latency overlaps the partial sums below
   // instead of forming a chain of dependent global round trips in thread 0
   const double sigma = c->sigma, obj0 = c->obj, amax = c->alpha_max, last = c->lastval, feps = c->fprec_eps;
-  double rd_m = 0.0, dd_m = 0.0;
-  if (!lr_tail) {
-    rd_m = A_RD[m];
-    dd_m = A_DD[m];
+  // A_RD[m], A_DD[m] as stored (the low-rank tail below overrides them when the cost matrix is one of its matrices)
+  double rd_m = A_RD[m], dd_m = A_DD[m];
+  // low-rank tail: the projections W = [RᵀB; DᵀB] and the matrices' column ranges are requested now, with everything
+  // else, into LDS (≤ SDPLR_LSF_LRW doubles of W, ≤ SDPLR_LSF_LRN matrices; larger sets take the global-memory route)
+  __shared__ double lw[SDPLR_LSF_LRW];
+  __shared__ int lr_p[SDPLR_LSF_LRN + 1], lr_g[SDPLR_LSF_LRN];
+  __shared__ double lr_rd[SDPLR_LSF_LRN], lr_dd[SDPLR_LSF_LRN];
+  const bool lr_lds = lr_tail && 2 * lr_ST * r <= SDPLR_LSF_LRW && lr_n <= SDPLR_LSF_LRN;
+  if (lr_lds) {
+    for (int t = threadIdx.x; t < 2 * lr_ST * r; t += SDPLR_LSF_NT) lw[t] = lrW[t];
+    if ((int)threadIdx.x <= lr_n) lr_p[threadIdx.x] = lr_mat_ptr[threadIdx.x];
+    if ((int)threadIdx.x < lr_n) lr_g[threadIdx.x] = lr_mat_gid[threadIdx.x];
   }
   // the extra slots' own data (≤ SDPLR_LSF_EXMAX of them staged; more fall back to global reads), fetched by one thread
   // each alongside the partials: the serial part below then reads LDS instead of chaining global round trips
@@ -523,12 +533,15 @@ k_ls_solve_fast(DevCtrl* __restrict__ c, int m, int gid_g, int n_extra, const in
     // A_RD[gid] = 2·Σ_c D_c⟨W0_c, W1_c⟩, A_DD[gid] = Σ_c D_c‖W1_c‖², from the projections W = [RᵀB; DᵀB]
     const int per = lr_ST * r;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lr_lds) __syncthreads();
     for (int t = wave; t < lr_n; t += SDPLR_LSF_NT / 64) {   // one wave per matrix, lanes over the rank
       double s0 = 0.0, s1 = 0.0;
-      for (int cc = lr_mat_ptr[t]; cc < lr_mat_ptr[t + 1]; cc++) {
+      const int c0 = lr_lds ? lr_p[t] : lr_mat_ptr[t], c1 = lr_lds ? lr_p[t + 1] : lr_mat_ptr[t + 1];
+      for (int cc = c0; cc < c1; cc++) {
         double d0 = 0.0, d1 = 0.0;
         for (int k = lane; k < r; k += 64) {
-          const double w0 = lrW[cc * r + k], w1 = lrW[per + cc * r + k];
+          const double w0 = lr_lds ? lw[cc * r + k] : lrW[cc * r + k];
+          const double w1 = lr_lds ? lw[per + cc * r + k] : lrW[per + cc * r + k];
           d0 += w0 * w1;
           d1 += w1 * w1;
         }
@@ -536,13 +549,26 @@ k_ls_solve_fast(DevCtrl* __restrict__ c, int m, int gid_g, int n_extra, const in
         s1 += wave_sum(d1) * lr_D[cc];
       }
       if (lane == 0) {
-        A_RD[lr_mat_gid[t]] = 2.0 * s0;
-        A_DD[lr_mat_gid[t]] = s1;
+        const int gid = lr_lds ? lr_g[t] : lr_mat_gid[t];
+        A_RD[gid] = 2.0 * s0;
+        A_DD[gid] = s1;
+        if (lr_lds) {
+          lr_rd[t] = 2.0 * s0;
+          lr_dd[t] = s1;
+        }
       }
     }
     __syncthreads();
-    rd_m = A_RD[m];
-    dd_m = A_DD[m];
+    if (lr_lds) {       // the values just formed are read back from LDS, not through global memory
+      for (int t = 0; t < lr_n; t++)
+        if (lr_g[t] == m) {
+          rd_m = lr_rd[t];
+          dd_m = lr_dd[t];
+        }
+    } else {
+      rd_m = A_RD[m];
+      dd_m = A_DD[m];
+    }
   }
   {  // block sums over the 16 waves, fixed order
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -569,6 +595,23 @@ k_ls_solve_fast(DevCtrl* __restrict__ c, int m, int gid_g, int n_extra, const in
 #endif
   if (threadIdx.x == 0) {
     const double g_rd = s[8] + s[8], g_dd = s[9];
+    // 𝒜 values of an extra slot: A_g's from the sums above, a low-rank matrix's from the tail's LDS copy
+    auto extra_q = [&](int k, double& q1, double& q2) {
+      if (k == gid_g) {
+        q1 = g_rd;
+        q2 = g_dd;
+        return;
+      }
+      if (lr_lds)
+        for (int t = 0; t < lr_n; t++)
+          if (lr_g[t] == k) {
+            q1 = lr_rd[t];
+            q2 = lr_dd[t];
+            return;
+          }
+      q1 = A_RD[k];
+      q2 = A_DD[k];
+    };
     if (gid_g >= 0) {     // (−1: the edge path without a multi-entry matrix)
       A_RD[gid_g] = g_rd;   // ⟨A_g, RDᵀ+DRᵀ⟩ = 2⟨P, D⟩
       A_DD[gid_g] = g_dd;   // ⟨A_g, DDᵀ⟩ = ⟨D, W⟩
@@ -578,7 +621,8 @@ k_ls_solve_fast(DevCtrl* __restrict__ c, int m, int gid_g, int n_extra, const in
       const int k = st ? ex_k[t] : extra[t];
       if (k >= m) continue;
       const double l = st ? ex_v[t][0] : lam[k], nq0 = st ? ex_v[t][2] : pv_raw[k];
-      const double q1 = (k == gid_g) ? g_rd : A_RD[k], q2 = (k == gid_g) ? g_dd : A_DD[k];
+      double q1, q2;
+      extra_q(k, q1, q2);
       s[0] += l * nq0;
       s[1] += nq0 * nq0;
       s[2] += l * q1;
@@ -613,7 +657,8 @@ k_ls_solve_fast(DevCtrl* __restrict__ c, int m, int gid_g, int n_extra, const in
       for (int t = 0; t < n_extra; t++) {
         const bool st = t < SDPLR_LSF_EXMAX;
         const int k = st ? ex_k[t] : extra[t];
-        const double q1 = (k == gid_g) ? g_rd : A_RD[k], q2 = (k == gid_g) ? g_dd : A_DD[k];
+        double q1, q2;
+        extra_q(k, q1, q2);
         const double v = (st ? ex_v[t][2] : pv_raw[k]) + a * (a * q2 + q1);
         pv_raw[k] = v;
         if (k == m) {

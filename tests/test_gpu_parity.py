@@ -91,7 +91,7 @@ def test_operators_match_oracle_and_dense(hip_abi, oracle_abi, family, seed, n, 
     g.close(); o.close()
 
 
-@pytest.mark.parametrize("h", [0, 1, 4, 6, 9])
+@pytest.mark.parametrize("h", [0, 1, 2, 3, 4, 6, 9])
 @pytest.mark.parametrize("r", [2, 3, 32])
 def test_lbfgs_matches_oracle(hip_abi, oracle_abi, h, r):
     """lbfgs_dir!/lbfgs_update!/lbfgs_clear! (src/lbfgs.jl) incl. the cyclic wrap and host-written slots."""
@@ -178,6 +178,72 @@ def test_inner_loop_trajectory(hip_abi, oracle_abi, family):
     assert rg2[4] == ro2[4] == 4 and np.allclose(rg2[:3], ro2[:3], rtol=1e-5) and rel(g2.Rt, o2.Rt) < 1e-5
     for s_ in (g, o, g2, o2):
         s_.close()
+
+
+def test_armijo_decision_at_the_bound(hip_abi, oracle_abi):
+    """Which step the backtracking accepts when ℒ(α) sits at the Armijo bound (src/linesearch.jl:173-181).
+    (1) an exact tie — dirt = 0 makes ℒ(α) = ℒ(0) for every α and the slope 0 — is accepted at once (`≤`, :177),
+    by construction of the sums and not by luck of rounding; (2) the direction is scaled until the oracle's decision
+    flips between two neighbouring scales (bisection to 1e-12), and 1e-7 to either side of that flip the device picks
+    the oracle's step: the windows in which a different summation order may legitimately decide otherwise are
+    ~1e-13 wide."""
+    data, *_ = make_data("ineq_0.05", 3, 12, 0.4)
+    g, o = pair(hip_abi, oracle_abi, data, 3, 5)
+    R0 = g.Rt.copy()
+    for s_ in (g, o):
+        s_.f(); s_.g()
+    D0 = -o.Gt
+
+    def arm(s_, t):
+        s_.Rt = R0
+        s_.f(); s_.g()            # primal_vio_raw, obj and the y the slope uses (:171)
+        s_.dirt = t * D0
+        return s_.linesearch_armijo(1.0)
+
+    (ag, Lg), (ao, Lo) = arm(g, 0.0), arm(o, 0.0)
+    assert ag == ao == 1.0 and Lg == pytest.approx(Lo, rel=1e-13)
+    ts = [2.0 ** k for k in range(-12, 13)]
+    al = [arm(o, t)[0] for t in ts]
+    flips = [i for i in range(len(ts) - 1) if al[i] != al[i + 1]]
+    assert len(flips) >= 2, al    # the sweep crosses several backtracking counts
+    checked = 0
+    for i in flips[:3]:
+        lo, hi = ts[i], ts[i + 1]
+        a_lo = al[i]
+        while hi / lo - 1.0 > 1e-12:
+            mid = 0.5 * (lo + hi)
+            if arm(o, mid)[0] == a_lo:
+                lo = mid
+            else:
+                hi = mid
+        for t in (lo * (1 - 1e-7), hi * (1 + 1e-7)):
+            (ag, Lg), (ao, Lo) = arm(g, t), arm(o, t)
+            assert ag == ao, (t, ag, ao)
+            assert Lg == pytest.approx(Lo, rel=1e-11)
+        assert arm(o, lo * (1 - 1e-7))[0] != arm(o, hi * (1 + 1e-7))[0]
+        checked += 1
+    assert checked >= 2
+    g.close(); o.close()
+
+
+@pytest.mark.parametrize("family", ["maxcut", "lovasz_theta"])
+@pytest.mark.parametrize("h", [1, 2, 3, 5, 8])
+def test_inner_loop_trajectory_over_history_lengths(hip_abi, oracle_abi, family, h):
+    """numlbfgsvecs ≠ 4 inside the device-driven loop: the seam kernel's register form (h ≤ 4) and its general form,
+    through several wraps of the cyclic history (src/lbfgs.jl:77-149), one call of 3h + 2 iterations."""
+    data, *_ = make_data(family, 3, 12, 0.4)
+    g, o = pair(hip_abi, oracle_abi, data, 3, 7, h=h)
+    normC, normb = data.normC(), float(np.linalg.norm(data.b))
+    sg, so = g.fg(normC, normb), o.fg(normC, normb)
+    k = 3 * h + 2
+    rg = g.inner_loop(normC, normb, True, True, False, 0.0, -1e300, k, 0.0, *sg)
+    ro = o.inner_loop(normC, normb, True, True, False, 0.0, -1e300, k, 0.0, *so)
+    assert rg[4] == ro[4] == k
+    assert np.allclose(rg[:3], ro[:3], rtol=1e-7, atol=1e-12), (rg, ro)
+    assert rel(g.Rt, o.Rt) < 1e-7
+    assert g.get_scalar(cabi.S_LBFGS_LATEST) == o.get_scalar(cabi.S_LBFGS_LATEST)
+    assert np.allclose(g.get_vec(cabi.V_LBFGS_RHO), o.get_vec(cabi.V_LBFGS_RHO), rtol=1e-6)
+    g.close(); o.close()
 
 
 @pytest.mark.parametrize("family", ["maxcut", "minimum_bisection", "lovasz_theta", "mu_conductance_0.05", "ineq_0.05"])
