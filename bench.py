@@ -104,7 +104,7 @@ def algorithmic_bytes(d, h):
         "assemble_full": 4 * nnzS + 8 * nnzT + 8 * nnzS,
         "spmm": 2 * N + 4 * (n + 1) + 12 * nnzS,
         # structured fast path: W = A_g·D with the row dots riding along; the fused step
-        "spmm_W": 4 * N + 4 * (n + 1) + 12 * nnzS,    # D rows (once), R, P read; W written; A_g pattern+values
+        "spmm_W": 3 * N + 4 * (n + 1) + 12 * nnzS,    # D rows (once), R read; W written; A_g pattern+values (⟨P,D⟩ is formed as ⟨R,W⟩)
         "fast_step": 7 * N,                            # R, D, P, W read; R, P, G written
         # … with lbfgs_update! fused in: R, D, P, W, G_old in; R, P, G, s_j, y_j out (the other history pairs the
         # Gram form re-reads are this design's choice, not compulsory)

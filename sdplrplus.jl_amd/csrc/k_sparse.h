@@ -1083,13 +1083,12 @@ k_spmm_fast(DevSparse sg, int m, DevFast ff, const double* __restrict__ R, const
       // end (r not a multiple of LPR·VEC) just do not touch memory
       const int ch = chb + lane * VEC;
       const bool act = ch < r;
-      vecd<VEC> xr, xd, xp, w;
+      vecd<VEC> xr, xd, w;
 #pragma unroll
-      for (int k = 0; k < VEC; k++) xr.v[k] = xd.v[k] = xp.v[k] = w.v[k] = 0.0;
+      for (int k = 0; k < VEC; k++) xr.v[k] = xd.v[k] = w.v[k] = 0.0;
       if (act) {
         xr = ldrow<VEC>(R + j * r + ch);
         xd = ldrow<VEC>(D + j * r + ch);
-        xp = ldrow<VEC>(P + j * r + ch);
       }
       // The row's (index, value) pairs are fetched LPR at a time by the group's lanes and handed round with
       // shuffles, so the gathers — eight in flight per lane — never wait on an index load: per row the chain is
@@ -1124,7 +1123,7 @@ k_spmm_fast(DevSparse sg, int m, DevFast ff, const double* __restrict__ R, const
       for (int k = 0; k < VEC; k++) {
         rd += xr.v[k] * xd.v[k];
         dd += xd.v[k] * xd.v[k];
-        acc[8] += xp.v[k] * xd.v[k];
+        acc[8] += xr.v[k] * w.v[k];   // ⟨R, W⟩ = ⟨R, A_g·D⟩ = ⟨A_g·R, D⟩ = ⟨P, D⟩ (A_g symmetric): no read of P here
         acc[9] += xd.v[k] * w.v[k];
       }
       if (act) strow<VEC>(W + j * r + ch, w);
@@ -1321,14 +1320,13 @@ k_spmm_tile(DevTile tl, int n, int m, DevFast ff, const double* __restrict__ R, 
 #pragma unroll
         for (int q = 0; q < VEC; q++) lr0[cc][q] = lr1[cc][q] = 0.0;
       for (int k = 0; k < nrows; k += EB) {
-        vecd<VEC> xr[EB], xd[EB], xp[EB], w[EB];
+        vecd<VEC> xr[EB], xd[EB], w[EB];
         const long long chs = act ? ch : 0;
 #pragma unroll
         for (int i = 0; i < EB; i++) {
           const long long j = j0 + min(k + i, nrows - 1);
           xr[i] = ldrow<VEC>(R + j * r + chs);
           xd[i] = ldrow<VEC>(D + j * r + chs);
-          xp[i] = ldrow<VEC>(P + j * r + chs);
 #pragma unroll
           for (int q = 0; q < VEC; q++) w[i].v[q] = rows[min(k + i, nrows - 1) * RW + q];
         }
@@ -1343,7 +1341,7 @@ k_spmm_tile(DevTile tl, int n, int m, DevFast ff, const double* __restrict__ R, 
           for (int q = 0; q < VEC; q++) {
             rd[i] += xr[i].v[q] * xd[i].v[q];
             dd[i] += xd[i].v[q] * xd[i].v[q];
-            tp += xp[i].v[q] * xd[i].v[q];
+            tp += xr[i].v[q] * w[i].v[q];    // ⟨R, W⟩ = ⟨P, D⟩ (A_g symmetric): the P stream stays out of this kernel
             tw += xd[i].v[q] * w[i].v[q];
           }
           rd[i] = ok ? rd[i] : 0.0;
