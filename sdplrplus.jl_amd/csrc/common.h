@@ -65,25 +65,33 @@ struct DevCtrl {
 };
 
 // ---- deterministic reductions --------------------------------------------------------------------
+// A 16-lane DPP row summed by rotations of 8, 4, 2, 1 (v_mov_b32_dpp row_ror: VALU only, no trip over the LDS
+// crossbar).  Lane i adds the same partners in the same order as an xor butterfly of the same widths (after the step
+// of width o the partial sums have period o), so every lane of the row ends with the same value.
+#define SDPLR_ROR(n)                                                                              \
+  v += __hiloint2double(__builtin_amdgcn_mov_dpp(__double2hiint(v), 0x120 + n, 0xf, 0xf, true),   \
+                        __builtin_amdgcn_mov_dpp(__double2loint(v), 0x120 + n, 0xf, 0xf, true));
+__device__ __forceinline__ double row_sum16(double v) {
+  SDPLR_ROR(8) SDPLR_ROR(4) SDPLR_ROR(2) SDPLR_ROR(1)
+  return v;
+}
+__device__ __forceinline__ double lane_value(double v, int l) {   // l: compile-time constant (v_readlane_b32)
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+// Sum over the 64 lanes of a wave, all lanes active: the four row totals, then ((r0 + r1) + r2) + r3 — the same value
+// in every lane, a fixed order.  (Six ds_bpermute round trips per sum before: ten sums at the end of a kernel kept the
+// LDS pipe busy for ≈ 3 k cycles — k_ls_solve_fast, in-kernel stamps.)
 __device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;  // every lane holds the same, order-fixed sum
+  v = row_sum16(v);
+  const double r0 = lane_value(v, 0), r1 = lane_value(v, 16), r2 = lane_value(v, 32), r3 = lane_value(v, 48);
+  return ((r0 + r1) + r2) + r3;
 }
 
 // sum over a sub-wave group of G lanes (G power of two ≤ 64); every lane of the group gets it
 template <int G>
 __device__ __forceinline__ double group_sum(double v) {
   if constexpr (G == 16) {
-    // a 16-lane group is one DPP row: rotate by 8, 4, 2, 1 (v_mov_b32_dpp row_ror, VALU only).  Lane i adds
-    // the same partners in the same order as the xor butterfly below (after the step of width o the partial
-    // sums have period o), so the result is bit-identical to it — without four trips over the LDS crossbar.
-#define SDPLR_ROR(n)                                                                              \
-    v += __hiloint2double(__builtin_amdgcn_mov_dpp(__double2hiint(v), 0x120 + n, 0xf, 0xf, true),   \
-                          __builtin_amdgcn_mov_dpp(__double2loint(v), 0x120 + n, 0xf, 0xf, true));
-    SDPLR_ROR(8) SDPLR_ROR(4) SDPLR_ROR(2) SDPLR_ROR(1)
-#undef SDPLR_ROR
-    return v;
+    return row_sum16(v);
   } else {
 #pragma unroll
     for (int o = G / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -327,6 +327,10 @@ k_lbfgs_boundary(DevCtrl* __restrict__ c, int h, int jfixed, int fin_mode, int d
   // and the partials (summed whether or not the flags will want them) — so the kernel pays one memory round
   // trip, not flag → count → partials.
   const int gp = c->gram_pending, np = c->norms_pending;
+#ifdef SDPLR_STAMPS2
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  const unsigned long long st_first = __builtin_amdgcn_s_memtime();
+#endif
   {
     const unsigned long long* src = reinterpret_cast<const unsigned long long*>(c);
     unsigned long long* dst = reinterpret_cast<unsigned long long*>(&gd.c);
@@ -356,8 +360,15 @@ k_lbfgs_boundary(DevCtrl* __restrict__ c, int h, int jfixed, int fin_mode, int d
         ta += pa[i];
         tb += pb[i];
       }
+#ifdef SDPLR_STAMPS2
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (tid == 0) gd.al[15] = (double)(__builtin_amdgcn_s_memtime() - st0);
+#endif
       ta = wave_sum(ta);
       tb = wave_sum(tb);
+#ifdef SDPLR_STAMPS2
+      if (tid == 0) gd.ga[15] = (double)(__builtin_amdgcn_s_memtime() - st0);
+#endif
       if (lane == 0) {
         gd.red[(s0 / h) * SDPLR_HMAX + s0 % h] = ta;
         if (two) gd.red[(s1 / h) * SDPLR_HMAX + s1 % h] = tb;
@@ -367,6 +378,10 @@ k_lbfgs_boundary(DevCtrl* __restrict__ c, int h, int jfixed, int fin_mode, int d
   const bool fin = (fin_mode == 2) || (fin_mode == 1 && gp);
   const bool norms = np != 0;
   if (!fin && !do_coeff && !do_loop && !norms) return;
+#ifdef SDPLR_STAMPS2
+  __shared__ double wave_done[16];
+  if (lane == 0) wave_done[wave] = (double)(__builtin_amdgcn_s_memtime() - st0);
+#endif
   __syncthreads();
 #ifdef SDPLR_STAMPS
   const unsigned long long st1 = __builtin_amdgcn_s_memtime();
@@ -392,8 +407,15 @@ k_lbfgs_boundary(DevCtrl* __restrict__ c, int h, int jfixed, int fin_mode, int d
 #ifdef SDPLR_STAMPS
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   const unsigned long long st3 = __builtin_amdgcn_s_memtime();
-  if (tid == 0 && do_loop && (gd.c.iters % 64) == 33)
+  if (tid == 0 && do_loop && (gd.c.iters % 64) == 33) {
+#ifdef SDPLR_STAMPS2
+    printf("[seamw a] %.0f %.0f %.0f %.0f %.0f %.0f %.0f %.0f\n", wave_done[0], wave_done[1], wave_done[2], wave_done[3], wave_done[4], wave_done[5], wave_done[6], wave_done[7]);
+    printf("[seamw b] %.0f %.0f %.0f %.0f %.0f %.0f | %.0f %.0f\n", wave_done[8], wave_done[9], wave_done[10], wave_done[11], wave_done[12], wave_done[13], wave_done[14], wave_done[15]);
+    printf("[seam] partials in %.0f  wave sums done %.0f  first load %llu  loads+sums %llu  serial %llu  store %llu (s_memtime ticks)\n", gd.al[15], gd.ga[15], st_first - st0, st1 - st0, st2 - st1, st3 - st2);
+#else
     printf("[seam] loads+sums %llu  serial %llu  store %llu (s_memtime ticks)\n", st1 - st0, st2 - st1, st3 - st2);
+#endif
+  }
 #endif
 }
 

@@ -500,15 +500,23 @@ k_ls_solve_fast(DevCtrl* __restrict__ c, int m, int gid_g, int n_extra, const in
   }
   double s[10];
   {
+    // (the block's CU takes these in at ≈ 35–70 GB/s: only the columns that hold partials are requested — two per
+    // thread up to 512 producer blocks, four up to 1024; absent ones contribute +0.0, so the sums do not depend on it)
     constexpr int PT = 4;
     double v[10][PT];
+    const bool wide = nb > 2 * SDPLR_LSF_NT;
 #pragma unroll
     for (int q = 0; q < PT; q++) {
       const int i = (int)threadIdx.x + SDPLR_LSF_NT * q;
+      if (q < 2 || wide) {
 #pragma unroll
-      for (int k = 0; k < 8; k++) v[k][q] = slot_partials(partials, SLOT_LS + k)[i];
-      v[8][q] = slot_partials(partials, SLOT_PD)[i];
-      v[9][q] = slot_partials(partials, SLOT_DW)[i];
+        for (int k = 0; k < 8; k++) v[k][q] = slot_partials(partials, SLOT_LS + k)[i];
+        v[8][q] = slot_partials(partials, SLOT_PD)[i];
+        v[9][q] = slot_partials(partials, SLOT_DW)[i];
+      } else {
+#pragma unroll
+        for (int k = 0; k < 10; k++) v[k][q] = 0.0;
+      }
     }
 #pragma unroll
     for (int k = 0; k < 10; k++) {
@@ -527,6 +535,10 @@ k_ls_solve_fast(DevCtrl* __restrict__ c, int m, int gid_g, int n_extra, const in
       s[9] = (threadIdx.x == 0) ? red2[1] : 0.0;
     }
   }
+#ifdef SDPLR_STAMPS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  const unsigned long long st_ld = __builtin_amdgcn_s_memtime();
+#endif
   if (dn) return;
   if (lr_tail) {
     // the tail of k_lr_finalize, mode 2 (src/linesearch.jl:10-16 for the low-rank matrices):
@@ -679,7 +691,7 @@ k_ls_solve_fast(DevCtrl* __restrict__ c, int m, int gid_g, int n_extra, const in
   if (threadIdx.x == 0 && (stamp_it % 64) == 33) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const unsigned long long st2 = __builtin_amdgcn_s_memtime();
-    printf("[ls_solve_fast] loads+sums %llu  serial+stores %llu (s_memtime ticks)\n", st1 - st0, st2 - st1);
+    printf("[ls_solve_fast] loads in %llu  loads+sums %llu  serial+stores %llu (s_memtime ticks)\n", st_ld - st0, st1 - st0, st2 - st1);
   }
 #endif
   if (sh_err != 0) return;
