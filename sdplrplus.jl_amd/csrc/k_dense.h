@@ -331,11 +331,10 @@ k_lbfgs_boundary(DevCtrl* __restrict__ c, int h, int jfixed, int fin_mode, int d
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   const unsigned long long st_first = __builtin_amdgcn_s_memtime();
 #endif
-  {
-    const unsigned long long* src = reinterpret_cast<const unsigned long long*>(c);
-    unsigned long long* dst = reinterpret_cast<unsigned long long*>(&gd.c);
-    for (int t = tid; t < (int)(sizeof(DevCtrl) / 8); t += 1024) dst[t] = src[t];
-  }
+  // (the control block's words go to registers here and into LDS only after the partials have been requested: an LDS
+  // store of a loaded value makes the wave wait for that load where the store stands in the program)
+  static_assert(sizeof(DevCtrl) / 8 <= 1024, "one word of the control block per thread");
+  const unsigned long long cw = reinterpret_cast<const unsigned long long*>(c)[min(tid, (int)(sizeof(DevCtrl) / 8) - 1)];
   if (wave >= 14) {  // ‖G‖², ‖pv‖² of the iteration that just ended (src/sdplr.jl:224-234): waves 14 and 15
     const int nbp = (wave == 14) ? c->nb_gnorm : c->nb_pvnorm;   // ≤ 1024 on every path
     const double* p = slot_partials(partials, wave == 14 ? SLOT_GNORM2 : SLOT_PVNORM2);
@@ -375,6 +374,7 @@ k_lbfgs_boundary(DevCtrl* __restrict__ c, int h, int jfixed, int fin_mode, int d
       }
     }
   }
+  if (tid < (int)(sizeof(DevCtrl) / 8)) reinterpret_cast<unsigned long long*>(&gd.c)[tid] = cw;
   const bool fin = (fin_mode == 2) || (fin_mode == 1 && gp);
   const bool norms = np != 0;
   if (!fin && !do_coeff && !do_loop && !norms) return;

@@ -476,39 +476,51 @@ k_ls_solve_fast(DevCtrl* __restrict__ c, int m, int gid_g, int n_extra, const in
   __shared__ int lr_p[SDPLR_LSF_LRN + 1], lr_g[SDPLR_LSF_LRN];
   __shared__ double lr_rd[SDPLR_LSF_LRN], lr_dd[SDPLR_LSF_LRN];
   const bool lr_lds = lr_tail && 2 * lr_ST * r <= SDPLR_LSF_LRW && lr_n <= SDPLR_LSF_LRN;
+  // Everything is requested into REGISTERS first and parked in LDS only after the partials below have been requested
+  // as well: an LDS store of a loaded value makes the wave wait for that load at the store's place in the program — with
+  // the stores up here the kernel paid three memory round trips (projections, extra slots, partials) instead of one
+  // (in-kernel stamps: 8.1 k cycles until the loads were in, against 5.5 k without the low-rank data).
+  constexpr int LWT = SDPLR_LSF_LRW / SDPLR_LSF_NT;
+  double lw_r[LWT];
+  int lrp_r = 0, lrg_r = 0;
   if (lr_lds) {
-    for (int t = threadIdx.x; t < 2 * lr_ST * r; t += SDPLR_LSF_NT) lw[t] = lrW[t];
-    if ((int)threadIdx.x <= lr_n) lr_p[threadIdx.x] = lr_mat_ptr[threadIdx.x];
-    if ((int)threadIdx.x < lr_n) lr_g[threadIdx.x] = lr_mat_gid[threadIdx.x];
+#pragma unroll
+    for (int q = 0; q < LWT; q++) {
+      const int t = (int)threadIdx.x + q * SDPLR_LSF_NT;
+      lw_r[q] = lrW[min(t, 2 * lr_ST * r - 1)];
+    }
+    lrp_r = lr_mat_ptr[min((int)threadIdx.x, lr_n)];
+    lrg_r = lr_mat_gid[min((int)threadIdx.x, lr_n - 1)];
   }
   // the extra slots' own data (≤ SDPLR_LSF_EXMAX of them staged; more fall back to global reads), fetched by one thread
   // each alongside the partials: the serial part below then reads LDS instead of chaining global round trips
   __shared__ int ex_k[SDPLR_LSF_EXMAX];
   __shared__ double ex_v[SDPLR_LSF_EXMAX][4];   // λ, λ_ub, primal_vio_raw, lb
-  if ((int)threadIdx.x < n_extra && threadIdx.x < SDPLR_LSF_EXMAX) {
-    int k = eh.k[0];
-    if (threadIdx.x == 1) k = eh.k[1];
-    if (threadIdx.x == 2) k = eh.k[2];
-    if (threadIdx.x == 3) k = eh.k[3];
-    if (threadIdx.x >= 4) k = extra[threadIdx.x];
-    ex_k[threadIdx.x] = k;
-    const int kc = min(k, m - (m > 0));
-    ex_v[threadIdx.x][0] = lam[kc];
-    ex_v[threadIdx.x][1] = lam_ub[kc];
-    ex_v[threadIdx.x][2] = pv_raw[k];
-    ex_v[threadIdx.x][3] = lb[kc];
+  const bool ex_mine = (int)threadIdx.x < n_extra && threadIdx.x < SDPLR_LSF_EXMAX;
+  int ex_kr = eh.k[0];   // (every thread requests: unconditional loads, clamped — threads past n_extra repeat slot 0's)
+  if (threadIdx.x == 1 && n_extra > 1) ex_kr = eh.k[1];
+  if (threadIdx.x == 2 && n_extra > 2) ex_kr = eh.k[2];
+  if (threadIdx.x == 3 && n_extra > 3) ex_kr = eh.k[3];
+  if (n_extra > 4 && threadIdx.x >= 4) ex_kr = extra[min((int)threadIdx.x, n_extra - 1)];
+  double ex_r[4];
+  {
+    const int kc = min(ex_kr, m - (m > 0));
+    ex_r[0] = lam[kc];
+    ex_r[1] = lam_ub[kc];
+    ex_r[2] = pv_raw[ex_kr];
+    ex_r[3] = lb[kc];
   }
   double s[10];
   {
-    // (the block's CU takes these in at ≈ 35–70 GB/s: only the columns that hold partials are requested — two per
-    // thread up to 512 producer blocks, four up to 1024; absent ones contribute +0.0, so the sums do not depend on it)
+    // (only the columns that hold partials are requested — one per thread up to 256 producer blocks, … four up to
+    // 1024; absent ones contribute +0.0, so the sums do not depend on it)
     constexpr int PT = 4;
     double v[10][PT];
-    const bool wide = nb > 2 * SDPLR_LSF_NT;
+    const int ncols = (nb + SDPLR_LSF_NT - 1) / SDPLR_LSF_NT;
 #pragma unroll
     for (int q = 0; q < PT; q++) {
       const int i = (int)threadIdx.x + SDPLR_LSF_NT * q;
-      if (q < 2 || wide) {
+      if (q < ncols) {
 #pragma unroll
         for (int k = 0; k < 8; k++) v[k][q] = slot_partials(partials, SLOT_LS + k)[i];
         v[8][q] = slot_partials(partials, SLOT_PD)[i];
@@ -534,6 +546,20 @@ k_ls_solve_fast(DevCtrl* __restrict__ c, int m, int gid_g, int n_extra, const in
       s[8] = (threadIdx.x == 0) ? red2[0] : 0.0;
       s[9] = (threadIdx.x == 0) ? red2[1] : 0.0;
     }
+  }
+  if (lr_lds) {
+#pragma unroll
+    for (int q = 0; q < LWT; q++) {
+      const int t = (int)threadIdx.x + q * SDPLR_LSF_NT;
+      if (t < 2 * lr_ST * r) lw[t] = lw_r[q];
+    }
+    if ((int)threadIdx.x <= lr_n) lr_p[threadIdx.x] = lrp_r;
+    if ((int)threadIdx.x < lr_n) lr_g[threadIdx.x] = lrg_r;
+  }
+  if (ex_mine) {
+    ex_k[threadIdx.x] = ex_kr;
+#pragma unroll
+    for (int q = 0; q < 4; q++) ex_v[threadIdx.x][q] = ex_r[q];
   }
 #ifdef SDPLR_STAMPS
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
