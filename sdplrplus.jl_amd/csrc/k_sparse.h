@@ -2103,8 +2103,8 @@ k_lz_band_fill(DevBand bd, const double* __restrict__ nzval) {
 // whatever its width: the first version — staging loop, then slot after slot, one 2-byte and one 8-byte load per
 // entry — sat 8.5 of its 12 µs in the request phase): the band of x (≤ 8 × 16 B per thread), per slot three 16-byte
 // loads per lane for four entries (packed columns + row, two value pairs), the chunk's rows of u for the dot.  Slots
-// past the block's end and groups past a slot's end are redirected to the all-padding dummy group, so nothing in the
-// sweep is conditional.
+// past the block's end and groups past a slot's end are skipped by a WAVE-UNIFORM branch (a slot belongs to one wave)
+// and stand in the registers as all-padding groups, so nothing in the sweep is conditional.
 __global__ void __launch_bounds__(SDPLR_LZB_NT)
 k_lz_band(DevBand bd, int n, DevCtrl* __restrict__ c, const double* __restrict__ u, DevLowRank lr,
           const double* __restrict__ yvec, const double* __restrict__ btx_part, int nb_prev,
@@ -2192,10 +2192,15 @@ k_lz_band(DevBand bd, int n, DevCtrl* __restrict__ c, const double* __restrict__
   for (int j = 0; j < NG; j++) {
     const int q = j < G0 ? 0 : j - G0 + 1;
     const int g = gfirst[q] + (j < G0 ? j : 0);
-    const long long e = (long long)(g < gend[q] ? g : bd.n_groups) * 64 + lane;
-    cw[j] = bd.cw[e];
-    va[j] = bd.vA[e];
-    vb[j] = bd.vB[e];
+    if (g < gend[q]) {     // wave-uniform (a scalar branch): slots and groups past the end are not requested at all
+      const long long e = (long long)g * 64 + lane;
+      cw[j] = bd.cw[e];
+      va[j] = bd.vA[e];
+      vb[j] = bd.vB[e];
+    } else {
+      cw[j] = make_uint4(0u, 0u, 0xFFFFu, 0u);
+      va[j].x = va[j].y = vb[j].x = vb[j].y = 0.0;
+    }
   }
   constexpr int XT = 16384 / 2 / SDPLR_LZB_NT;    // double2 per thread for the widest band
   const int npair = ncol >> 1;
