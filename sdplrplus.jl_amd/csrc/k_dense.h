@@ -327,47 +327,49 @@ k_lbfgs_boundary(DevCtrl* __restrict__ c, int h, int jfixed, int fin_mode, int d
   // and the partials (summed whether or not the flags will want them) — so the kernel pays one memory round
   // trip, not flag → count → partials.
   const int gp = c->gram_pending, np = c->norms_pending;
-#ifdef SDPLR_STAMPS2
-  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-  const unsigned long long st_first = __builtin_amdgcn_s_memtime();
-#endif
   // (the control block's words go to registers here and into LDS only after the partials have been requested: an LDS
   // store of a loaded value makes the wave wait for that load where the store stands in the program)
   static_assert(sizeof(DevCtrl) / 8 <= 1024, "one word of the control block per thread");
   const unsigned long long cw = reinterpret_cast<const unsigned long long*>(c)[min(tid, (int)(sizeof(DevCtrl) / 8) - 1)];
+  // The partials are fetched 16 bytes per lane (two neighbouring partials): this one CU issues a wave-load every ≈ 16
+  // cycles whatever its width, and with 8-byte loads the ≈ 200 of them WERE the load phase (in-kernel stamps: partials
+  // in after 3.3 k cycles).  Entries past the producers' count are masked (the slot arrays are SDPLR_MAXNB wide).
   if (wave >= 14) {  // ‖G‖², ‖pv‖² of the iteration that just ended (src/sdplr.jl:224-234): waves 14 and 15
     const int nbp = (wave == 14) ? c->nb_gnorm : c->nb_pvnorm;   // ≤ 1024 on every path
     const double* p = slot_partials(partials, wave == 14 ? SLOT_GNORM2 : SLOT_PVNORM2);
-    double v[16];
+    const double2* p2 = reinterpret_cast<const double2*>(p);
+    double2 v[8];
 #pragma unroll
-    for (int u = 0; u < 16; u++) v[u] = p[lane + 64 * u];        // the slot arrays hold SDPLR_MAXNB entries
+    for (int u = 0; u < 8; u++) v[u] = p2[lane + 64 * u];
     double t = 0.0;
 #pragma unroll
-    for (int u = 0; u < 16; u++) t += (lane + 64 * u < nbp) ? v[u] : 0.0;
+    for (int u = 0; u < 8; u++) {
+      const int i = 2 * (lane + 64 * u);
+      t += (i < nbp) ? v[u].x : 0.0;
+      t += (i + 1 < nbp) ? v[u].y : 0.0;
+    }
     for (int i = lane + 1024; i < nbp; i += 64) t += p[i];
     t = wave_sum(t);
     if (lane == 0) gd.nrm[wave - 14] = t;
   } else if (fin_mode != 0) {  // the 5h Gram sums, two per wave and trip
+    const int np2 = (nb_partials + 1) >> 1;
     for (int s0 = wave; s0 < 5 * h; s0 += 28) {
       const int s1 = s0 + 14;
       const bool two = s1 < 5 * h;
-      const double* pa = slot_partials(partials, SLOT_GRAM + (s0 / h) * SDPLR_HMAX + s0 % h);
-      const double* pb = two ? slot_partials(partials, SLOT_GRAM + (s1 / h) * SDPLR_HMAX + s1 % h) : pa;
+      const double2* pa = reinterpret_cast<const double2*>(slot_partials(partials, SLOT_GRAM + (s0 / h) * SDPLR_HMAX + s0 % h));
+      const double2* pb = two ? reinterpret_cast<const double2*>(slot_partials(partials, SLOT_GRAM + (s1 / h) * SDPLR_HMAX + s1 % h)) : pa;
       double ta = 0.0, tb = 0.0;
-#pragma unroll 8
-      for (int i = lane; i < nb_partials; i += 64) {
-        ta += pa[i];
-        tb += pb[i];
+#pragma unroll 4
+      for (int i = lane; i < np2; i += 64) {
+        const double2 a = pa[i], b = pb[i];
+        const bool hi = 2 * i + 1 < nb_partials;
+        ta += a.x;
+        ta += hi ? a.y : 0.0;
+        tb += b.x;
+        tb += hi ? b.y : 0.0;
       }
-#ifdef SDPLR_STAMPS2
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      if (tid == 0) gd.al[15] = (double)(__builtin_amdgcn_s_memtime() - st0);
-#endif
       ta = wave_sum(ta);
       tb = wave_sum(tb);
-#ifdef SDPLR_STAMPS2
-      if (tid == 0) gd.ga[15] = (double)(__builtin_amdgcn_s_memtime() - st0);
-#endif
       if (lane == 0) {
         gd.red[(s0 / h) * SDPLR_HMAX + s0 % h] = ta;
         if (two) gd.red[(s1 / h) * SDPLR_HMAX + s1 % h] = tb;
@@ -378,10 +380,6 @@ k_lbfgs_boundary(DevCtrl* __restrict__ c, int h, int jfixed, int fin_mode, int d
   const bool fin = (fin_mode == 2) || (fin_mode == 1 && gp);
   const bool norms = np != 0;
   if (!fin && !do_coeff && !do_loop && !norms) return;
-#ifdef SDPLR_STAMPS2
-  __shared__ double wave_done[16];
-  if (lane == 0) wave_done[wave] = (double)(__builtin_amdgcn_s_memtime() - st0);
-#endif
   __syncthreads();
 #ifdef SDPLR_STAMPS
   const unsigned long long st1 = __builtin_amdgcn_s_memtime();
@@ -408,13 +406,7 @@ k_lbfgs_boundary(DevCtrl* __restrict__ c, int h, int jfixed, int fin_mode, int d
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   const unsigned long long st3 = __builtin_amdgcn_s_memtime();
   if (tid == 0 && do_loop && (gd.c.iters % 64) == 33) {
-#ifdef SDPLR_STAMPS2
-    printf("[seamw a] %.0f %.0f %.0f %.0f %.0f %.0f %.0f %.0f\n", wave_done[0], wave_done[1], wave_done[2], wave_done[3], wave_done[4], wave_done[5], wave_done[6], wave_done[7]);
-    printf("[seamw b] %.0f %.0f %.0f %.0f %.0f %.0f | %.0f %.0f\n", wave_done[8], wave_done[9], wave_done[10], wave_done[11], wave_done[12], wave_done[13], wave_done[14], wave_done[15]);
-    printf("[seam] partials in %.0f  wave sums done %.0f  first load %llu  loads+sums %llu  serial %llu  store %llu (s_memtime ticks)\n", gd.al[15], gd.ga[15], st_first - st0, st1 - st0, st2 - st1, st3 - st2);
-#else
     printf("[seam] loads+sums %llu  serial %llu  store %llu (s_memtime ticks)\n", st1 - st0, st2 - st1, st3 - st2);
-#endif
   }
 #endif
 }

@@ -512,31 +512,35 @@ k_ls_solve_fast(DevCtrl* __restrict__ c, int m, int gid_g, int n_extra, const in
   }
   double s[10];
   {
-    // (only the columns that hold partials are requested — one per thread up to 256 producer blocks, … four up to
-    // 1024; absent ones contribute +0.0, so the sums do not depend on it)
-    constexpr int PT = 4;
-    double v[10][PT];
-    const int ncols = (nb + SDPLR_LSF_NT - 1) / SDPLR_LSF_NT;
+    // 16 bytes per lane (two neighbouring partials), and only the columns that hold partials — this one CU issues a
+    // wave-load every ≈ 16 cycles whatever its width; absent entries are masked, so the sums do not depend on it.
+    constexpr int PT = 2;                       // double2 columns of NT lanes: 2·PT·NT = 1024 partials
+    double2 v[10][PT];
+    const int ncols = (nb + 2 * SDPLR_LSF_NT - 1) / (2 * SDPLR_LSF_NT);
 #pragma unroll
     for (int q = 0; q < PT; q++) {
       const int i = (int)threadIdx.x + SDPLR_LSF_NT * q;
       if (q < ncols) {
 #pragma unroll
-        for (int k = 0; k < 8; k++) v[k][q] = slot_partials(partials, SLOT_LS + k)[i];
-        v[8][q] = slot_partials(partials, SLOT_PD)[i];
-        v[9][q] = slot_partials(partials, SLOT_DW)[i];
+        for (int k = 0; k < 8; k++) v[k][q] = reinterpret_cast<const double2*>(slot_partials(partials, SLOT_LS + k))[i];
+        v[8][q] = reinterpret_cast<const double2*>(slot_partials(partials, SLOT_PD))[i];
+        v[9][q] = reinterpret_cast<const double2*>(slot_partials(partials, SLOT_DW))[i];
       } else {
 #pragma unroll
-        for (int k = 0; k < 10; k++) v[k][q] = 0.0;
+        for (int k = 0; k < 10; k++) v[k][q].x = v[k][q].y = 0.0;
       }
     }
 #pragma unroll
     for (int k = 0; k < 10; k++) {
       s[k] = 0.0;
 #pragma unroll
-      for (int q = 0; q < PT; q++) s[k] += ((int)threadIdx.x + SDPLR_LSF_NT * q < nb) ? v[k][q] : 0.0;
+      for (int q = 0; q < PT; q++) {
+        const int i = 2 * ((int)threadIdx.x + SDPLR_LSF_NT * q);
+        s[k] += (i < nb) ? v[k][q].x : 0.0;
+        s[k] += (i + 1 < nb) ? v[k][q].y : 0.0;
+      }
     }
-    for (int i = threadIdx.x + PT * SDPLR_LSF_NT; i < nb; i += SDPLR_LSF_NT) {
+    for (int i = threadIdx.x + 2 * PT * SDPLR_LSF_NT; i < nb; i += SDPLR_LSF_NT) {
 #pragma unroll
       for (int k = 0; k < 8; k++) s[k] += slot_partials(partials, SLOT_LS + k)[i];
       s[8] += slot_partials(partials, SLOT_PD)[i];
