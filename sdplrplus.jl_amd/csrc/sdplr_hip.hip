@@ -17,6 +17,8 @@
 #include <mutex>
 #include <shared_mutex>
 #include <string>
+#include <unordered_map>
+#include <utility>
 #include <vector>
 
 #include "common.h"
@@ -184,10 +186,96 @@ int have_device() {
   return c;
 }
 
+// ---- device-memory pool ---------------------------------------------------------------------------------------
+// hipMalloc / hipFree take process-wide locks and hipFree waits for the whole device: with eight small instances in
+// flight (BASELINE config 5: n = 800, ≈ 60 arrays per handle, a handle created and destroyed per instance) the handles
+// stalled each other in the allocator.  Blocks of ≤ 16 MiB go back to a per-device free list keyed by their exact size
+// (instances of one batch have the same sizes) instead of to the runtime, ≤ 512 MiB in all; larger blocks (the factor
+// arena of a big instance) bypass the pool.  A block is only ever returned after the owning handle's stream has been
+// drained.  SDPLR_HIP_NO_POOL=1 switches the pool off.
+struct DevPool {
+  std::mutex mu;
+  std::map<std::pair<int, size_t>, std::vector<void*>> free_blocks;
+  std::unordered_map<void*, std::pair<int, size_t>> live;
+  std::vector<void*> pinned_free;   // pinned host blocks of sizeof(DevCtrl)
+  size_t cached = 0;
+  const bool off = getenv("SDPLR_HIP_NO_POOL") != nullptr;
+  static constexpr size_t MAX_BLOCK = (size_t)16 << 20, MAX_CACHED = (size_t)512 << 20;
+};
+DevPool& pool() {
+  static DevPool* p = new DevPool();   // never destroyed: the HIP runtime may be gone by the time statics are
+  return *p;
+}
+hipError_t pool_malloc(void** out, size_t bytes) {
+  DevPool& P = pool();
+  bytes = (std::max<size_t>(bytes, 1) + 255) / 256 * 256;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (!P.off && bytes <= DevPool::MAX_BLOCK) {
+    std::lock_guard<std::mutex> g(P.mu);
+    auto it = P.free_blocks.find({dev, bytes});
+    if (it != P.free_blocks.end() && !it->second.empty()) {
+      *out = it->second.back();
+      it->second.pop_back();
+      P.cached -= bytes;
+      P.live[*out] = {dev, bytes};
+      return hipSuccess;
+    }
+  }
+  hipError_t e = hipMalloc(out, bytes);
+  if (e == hipSuccess && !P.off) {
+    std::lock_guard<std::mutex> g(P.mu);
+    P.live[*out] = {dev, bytes};
+  }
+  return e;
+}
+void pool_free(void* p) {
+  if (!p) return;
+  DevPool& P = pool();
+  if (!P.off) {
+    std::lock_guard<std::mutex> g(P.mu);
+    auto it = P.live.find(p);
+    if (it != P.live.end()) {
+      const auto key = it->second;
+      P.live.erase(it);
+      if (key.second <= DevPool::MAX_BLOCK && P.cached + key.second <= DevPool::MAX_CACHED) {
+        P.free_blocks[key].push_back(p);
+        P.cached += key.second;
+        return;
+      }
+    }
+  }
+  (void)hipFree(p);
+}
+hipError_t pool_host_ctrl(void** out) {
+  DevPool& P = pool();
+  if (!P.off) {
+    std::lock_guard<std::mutex> g(P.mu);
+    if (!P.pinned_free.empty()) {
+      *out = P.pinned_free.back();
+      P.pinned_free.pop_back();
+      return hipSuccess;
+    }
+  }
+  return hipHostMalloc(out, sizeof(DevCtrl), hipHostMallocDefault);
+}
+void pool_host_ctrl_free(void* p) {
+  if (!p) return;
+  DevPool& P = pool();
+  if (!P.off) {
+    std::lock_guard<std::mutex> g(P.mu);
+    if (P.pinned_free.size() < 256) {
+      P.pinned_free.push_back(p);
+      return;
+    }
+  }
+  (void)hipHostFree(p);
+}
+
 template <typename T>
 int dalloc(S* s, T** p, size_t count) {
   void* q = nullptr;
-  hipError_t e = hipMalloc(&q, std::max<size_t>(count, 1) * sizeof(T));
+  hipError_t e = pool_malloc(&q, std::max<size_t>(count, 1) * sizeof(T));
   if (e != hipSuccess) return fail(s, SDPLR_ERR_ALLOC, std::string("hipMalloc: ") + hipGetErrorString(e));
   s->allocs.push_back(q);
   *p = (T*)q;
@@ -288,7 +376,7 @@ int blocks_for(long long work, int per_block, int cap) {
 // release one tracked allocation
 void dfree(S* s, void* p) {
   if (!p) return;
-  (void)hipFree(p);
+  pool_free(p);
   s->allocs.erase(std::remove(s->allocs.begin(), s->allocs.end(), p), s->allocs.end());
 }
 
@@ -329,7 +417,7 @@ void choose_shape(S* s) {
 int build_tiles(S* s) {
   const int64_t n = s->n;
   for (void* p : s->tile_allocs) {
-    (void)hipFree(p);
+    pool_free(p);
     s->allocs.erase(std::remove(s->allocs.begin(), s->allocs.end(), p), s->allocs.end());
   }
   s->tile_allocs.clear();
@@ -532,7 +620,7 @@ int alloc_factors(S* s) {
   s->arena.h = (int)s->h;
   const size_t used = (size_t)(3 + 2 * s->h + (s->fast ? 2 : 0));  // R, G, dirt, s_*, y_* [, P, W]
   double* base = nullptr;
-  hipError_t e = hipMalloc((void**)&base, std::max<size_t>(used * stride, 1) * sizeof(double));
+  hipError_t e = pool_malloc((void**)&base, std::max<size_t>(used * stride, 1) * sizeof(double));
   if (e != hipSuccess) return fail(s, SDPLR_ERR_ALLOC, std::string("hipMalloc(factors): ") + hipGetErrorString(e));
   HIPCK(s, hipMemsetAsync(base, 0, used * stride * sizeof(double), s->stream));
   HIPCK(s, hipStreamSynchronize(s->stream));
@@ -742,7 +830,11 @@ int32_t sdplr_hip_finalize(S* s) {
   auto plan_long = [&](const std::vector<int>& ptr, DevSparse& dst) -> int {
     std::vector<int> deg(n);
     for (int64_t j = 0; j < n; j++) deg[j] = ptr[j + 1] - ptr[j];
-    int thresh = 64;   // ≈ 3× the mean degree of the G(n,p) configurations: none of their rows qualify
+    // a hub is a row far longer than the rest: more than 64 nonzeros AND more than 3× the mean (the G(n,p)
+    // configurations have none; nor do the dense-ish Gset graphs of the batch configuration — mean degree 48, longest
+    // row 67 — which a fixed threshold of 64 pushed off the singleton fast path and onto a third Lanczos kernel)
+    const long long mean3 = n > 0 ? 3LL * ptr[n] / n : 0;
+    int thresh = (int)std::min<long long>(std::max<long long>(64, mean3), 1 << 30);
     if (const char* e = getenv("SDPLR_HIP_HUB_THRESH")) thresh = std::max(8, atoi(e));
     std::vector<int> rows;
     for (int64_t j = 0; j < n; j++)
@@ -812,7 +904,7 @@ int32_t sdplr_hip_finalize(S* s) {
     DevCtrl* d = nullptr;
     if ((rc = dalloc(s, &d, 1))) return rc;
     s->ctrl = d;
-    HIPCK(s, hipHostMalloc((void**)&s->hc, sizeof(DevCtrl), hipHostMallocDefault));
+    HIPCK(s, pool_host_ctrl((void**)&s->hc));
     memset(s->hc, 0, sizeof(DevCtrl));
     s->hc->sigma = 2.0;             // config.σ_0 default, src/options.jl:5
     s->hc->alpha_max = 1.0;
@@ -820,7 +912,7 @@ int32_t sdplr_hip_finalize(S* s) {
     HIPCK(s, hipMemcpyAsync(s->ctrl, s->hc, sizeof(DevCtrl), hipMemcpyHostToDevice, s->stream));
     HIPCK(s, hipStreamSynchronize(s->stream));
     for (int k = 0; k < 2; k++) {
-      HIPCK(s, hipHostMalloc((void**)&s->snap[k], sizeof(DevCtrl), hipHostMallocDefault));
+      HIPCK(s, pool_host_ctrl((void**)&s->snap[k]));
       HIPCK(s, hipEventCreateWithFlags(&s->snap_ev[k], hipEventDisableTiming));
     }
   }
@@ -1056,14 +1148,14 @@ int32_t sdplr_hip_destroy(S* s) {
   if (s->stream) (void)hipStreamSynchronize(s->stream);
   for (auto& p : s->prof_pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
   for (auto e : s->ev_pool) (void)hipEventDestroy(e);
-  for (void* p : s->allocs) (void)hipFree(p);
-  if (s->arena.base) (void)hipFree(s->arena.base);
-  if (s->lz_alpha) (void)hipFree(s->lz_alpha);
-  if (s->lz_beta) (void)hipFree(s->lz_beta);
-  if (s->hc) (void)hipHostFree(s->hc);
+  for (void* p : s->allocs) pool_free(p);
+  if (s->arena.base) pool_free(s->arena.base);
+  if (s->lz_alpha) pool_free(s->lz_alpha);
+  if (s->lz_beta) pool_free(s->lz_beta);
+  if (s->hc) pool_host_ctrl_free(s->hc);
   if (s->lz_graph) (void)hipGraphExecDestroy(s->lz_graph);
   for (int k = 0; k < 2; k++) {
-    if (s->snap[k]) (void)hipHostFree(s->snap[k]);
+    if (s->snap[k]) pool_host_ctrl_free(s->snap[k]);
     if (s->snap_ev[k]) (void)hipEventDestroy(s->snap_ev[k]);
     if (s->graph_exec[k]) (void)hipGraphExecDestroy(s->graph_exec[k]);
   }
@@ -1077,7 +1169,7 @@ int32_t sdplr_hip_reset_rank(S* s, int64_t new_r) {
   NEED_FINAL(s);
   if (new_r < 1 || s->n * new_r >= (1LL << 40)) return fail(s, SDPLR_ERR_INVALID_ARG, "reset_rank: bad rank");
   HIPCK(s, hipStreamSynchronize(s->stream));
-  if (s->arena.base) (void)hipFree(s->arena.base);
+  if (s->arena.base) pool_free(s->arena.base);
   s->arena.base = nullptr;
   for (int k = 0; k < 2; k++)
     if (s->graph_exec[k]) { (void)hipGraphExecDestroy(s->graph_exec[k]); s->graph_exec[k] = nullptr; }
@@ -1701,12 +1793,12 @@ int64_t sturm_below(const std::vector<double>& d, const double* e, int64_t k, do
 int ensure_lz_capacity(S* s, int64_t q) {
   if (q <= s->lz_cap) return SDPLR_OK;
   HIPCK(s, hipStreamSynchronize(s->stream));
-  if (s->lz_alpha) (void)hipFree(s->lz_alpha);
-  if (s->lz_beta) (void)hipFree(s->lz_beta);
+  if (s->lz_alpha) pool_free(s->lz_alpha);
+  if (s->lz_beta) pool_free(s->lz_beta);
   if (s->lz_graph) { (void)hipGraphExecDestroy(s->lz_graph); s->lz_graph = nullptr; }
   q = std::max<int64_t>(q, 4096);
-  HIPCK(s, hipMalloc((void**)&s->lz_alpha, q * sizeof(double)));
-  HIPCK(s, hipMalloc((void**)&s->lz_beta, q * sizeof(double)));
+  HIPCK(s, pool_malloc((void**)&s->lz_alpha, q * sizeof(double)));
+  HIPCK(s, pool_malloc((void**)&s->lz_beta, q * sizeof(double)));
   s->lz_cap = q;
   return SDPLR_OK;
 }

@@ -550,6 +550,26 @@ def test_concurrent_handles_match_serial(hip_abi):
     assert threaded == serial
 
 
+def test_recycled_device_blocks_do_not_leak_state(hip_abi):
+    """The library's device-memory pool hands the blocks of a destroyed handle to the next one of the same sizes
+    (BASELINE config 5 creates and destroys a handle per instance).  Solves of instance A, then B (same sizes, other
+    data), then A again on recycled blocks must reproduce A's first result bit for bit — for the structured path and
+    for a hub-row instance, whose extra arrays have other sizes."""
+    def solve(data, r):
+        res = sj.sdplr(data=data, r=r, printlevel=0, ptol=0.01, objtol=0.01, seed=0,
+                       prior_trace_bound=float(data.n), maxmajoriter=40)
+        return res["obj"], res["max_dual_value"], res["iter"], res["majoriter"]
+
+    A = problems.maxcut_data(problems.gnp_graph(400, 0.05, 7))
+    B = problems.maxcut_data(problems.gnp_graph(400, 0.05, 8))
+    H = problems.lovasz_theta_data(problems.chung_lu_graph(400, 6.0, 2.2, 5))
+    first = solve(A, 6)
+    other = solve(B, 6)
+    hub = solve(H, 6)
+    assert solve(A, 6) == first and solve(B, 6) == other and solve(H, 6) == hub
+    assert first != other
+
+
 @pytest.mark.parametrize("family,toggles", [
     ("maxcut", ["SDPLR_HIP_NO_FAST"]), ("maxcut", ["SDPLR_HIP_NO_FAST2"]), ("maxcut", ["SDPLR_HIP_NO_GRAPH"]),
     ("maxcut", ["SDPLR_HIP_NO_UPDFUSE"]), ("minimum_bisection", ["SDPLR_HIP_NO_UPDFUSE"]),
