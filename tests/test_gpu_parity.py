@@ -180,6 +180,42 @@ def test_inner_loop_trajectory(hip_abi, oracle_abi, family):
         s_.close()
 
 
+@pytest.mark.parametrize("name", ["relaxed_maxcut", "mu_conductance_reformulated", "mu_conductance_native"])
+@pytest.mark.parametrize("r", [3, 32])
+def test_experiment_builders_on_gpu(hip_abi, oracle_abi, name, r):
+    """The remaining builders of exps/problems.jl (:188-341) on the device: two-entry diagonal matrices over a 3n×3n
+    slack layout, a full diagonal matrix beside the general one, two singleton constraints per row with inequalities
+    (other classifications of the structured path than the five BASELINE families take).  Operators against dense
+    recomputation and the oracle, then the native inner loop against the oracle's."""
+    A = problems.gnp_graph(14, 0.4, 3)
+    ct = None
+    if name == "relaxed_maxcut":
+        C, As, bs = problems.relaxed_maxcut(A)
+    elif name == "mu_conductance_reformulated":
+        C, As, bs = problems.mu_conductance_reformulated(A, 0.05)
+    else:
+        C, As, bs, ct = problems.mu_conductance_native(A, 0.05)
+    data = sj.SDPData(C, As, bs, ct)
+    g, o = pair(hip_abi, oracle_abi, data, r, 4)
+    Lg, Lo = g.f(), o.f()
+    assert np.max(np.abs(g.primal_vio_raw - primal_vio_dense(C, As, bs, g.Rt))) < 1e-10
+    assert rel(g.primal_vio_raw, o.primal_vio_raw) < 1e-12 and abs(Lg - Lo) <= 1e-12 * max(1, abs(Lo))
+    g.g(); o.g()
+    assert rel(g.y, o.y) < 1e-13 and rel(g.Gt, o.Gt) < 1e-12
+    assert np.max(np.abs(g.Gt - 2 * S_dense(C, As, g.y) @ g.Rt)) < 1e-10 * (1 + np.max(np.abs(g.Gt)))
+    normC, normb = data.normC(), float(np.linalg.norm(data.b))
+    armijo = data.has_inequalities
+    sg, so = g.fg(normC, normb), o.fg(normC, normb)
+    for it in range(6):
+        rg = g.inner_loop(normC, normb, True, True, armijo, 0.0, -1e300, 1, 0.0, *sg)
+        ro = o.inner_loop(normC, normb, True, True, armijo, 0.0, -1e300, 1, 0.0, *so)
+        assert rg[4] == ro[4] == 1
+        assert np.allclose(rg[:3], ro[:3], rtol=1e-7, atol=1e-11), (it, rg, ro)
+        assert rel(g.Rt, o.Rt) < 1e-7
+        sg, so = rg[:3], ro[:3]
+    g.close(); o.close()
+
+
 def test_armijo_decision_at_the_bound(hip_abi, oracle_abi):
     """Which step the backtracking accepts when ℒ(α) sits at the Armijo bound (src/linesearch.jl:173-181).
     (1) an exact tie — dirt = 0 makes ℒ(α) = ℒ(0) for every α and the slope 0 — is accepted at once (`≤`, :177),
