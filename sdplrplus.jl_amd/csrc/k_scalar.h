@@ -474,8 +474,8 @@ k_ls_solve_fast(DevCtrl* __restrict__ c, int m, int gid_g, int n_extra, const in
   // else, into LDS (≤ SDPLR_LSF_LRW doubles of W, ≤ SDPLR_LSF_LRN matrices; larger sets take the global-memory route)
   __shared__ double lw[SDPLR_LSF_LRW];
   __shared__ int lr_p[SDPLR_LSF_LRN + 1], lr_g[SDPLR_LSF_LRN];
-  __shared__ double lr_rd[SDPLR_LSF_LRN], lr_dd[SDPLR_LSF_LRN];
-  const bool lr_lds = lr_tail && 2 * lr_ST * r <= SDPLR_LSF_LRW && lr_n <= SDPLR_LSF_LRN;
+  __shared__ double lr_rd[SDPLR_LSF_LRN], lr_dd[SDPLR_LSF_LRN], lr_dv[SDPLR_LSF_NT];
+  const bool lr_lds = lr_tail && 2 * lr_ST * r <= SDPLR_LSF_LRW && lr_n <= SDPLR_LSF_LRN && lr_ST <= SDPLR_LSF_NT;
   // Everything is requested into REGISTERS first and parked in LDS only after the partials below have been requested
   // as well: an LDS store of a loaded value makes the wave wait for that load at the store's place in the program — with
   // the stores up here the kernel paid three memory round trips (projections, extra slots, partials) instead of one
@@ -483,7 +483,11 @@ k_ls_solve_fast(DevCtrl* __restrict__ c, int m, int gid_g, int n_extra, const in
   constexpr int LWT = SDPLR_LSF_LRW / SDPLR_LSF_NT;
   double lw_r[LWT];
   int lrp_r = 0, lrg_r = 0;
+  double lrd_r = 0.0;
+  int lrc_r = 0;
   if (lr_lds) {
+    lrd_r = lr_D[min((int)threadIdx.x, lr_ST - 1)];
+    lrc_r = lr_col_gid[min((int)threadIdx.x, lr_ST - 1)];
 #pragma unroll
     for (int q = 0; q < LWT; q++) {
       const int t = (int)threadIdx.x + q * SDPLR_LSF_NT;
@@ -496,6 +500,8 @@ k_ls_solve_fast(DevCtrl* __restrict__ c, int m, int gid_g, int n_extra, const in
   // each alongside the partials: the serial part below then reads LDS instead of chaining global round trips
   __shared__ int ex_k[SDPLR_LSF_EXMAX];
   __shared__ double ex_v[SDPLR_LSF_EXMAX][4];   // λ, λ_ub, primal_vio_raw, lb
+  __shared__ double ex_y[SDPLR_LSF_EXMAX];      // y of the extra slots as committed below
+  __shared__ int lr_cg[SDPLR_LSF_NT];           // owner (constraint index) of each low-rank column
   const bool ex_mine = (int)threadIdx.x < n_extra && threadIdx.x < SDPLR_LSF_EXMAX;
   int ex_kr = eh.k[0];   // (every thread requests: unconditional loads, clamped — threads past n_extra repeat slot 0's)
   if (threadIdx.x == 1 && n_extra > 1) ex_kr = eh.k[1];
@@ -559,6 +565,10 @@ k_ls_solve_fast(DevCtrl* __restrict__ c, int m, int gid_g, int n_extra, const in
     }
     if ((int)threadIdx.x <= lr_n) lr_p[threadIdx.x] = lrp_r;
     if ((int)threadIdx.x < lr_n) lr_g[threadIdx.x] = lrg_r;
+    if ((int)threadIdx.x < lr_ST) {
+      lr_dv[threadIdx.x] = lrd_r;
+      lr_cg[threadIdx.x] = lrc_r;
+    }
   }
   if (ex_mine) {
     ex_k[threadIdx.x] = ex_kr;
@@ -587,8 +597,9 @@ k_ls_solve_fast(DevCtrl* __restrict__ c, int m, int gid_g, int n_extra, const in
           d0 += w0 * w1;
           d1 += w1 * w1;
         }
-        s0 += wave_sum(d0) * lr_D[cc];
-        s1 += wave_sum(d1) * lr_D[cc];
+        const double dc = lr_lds ? lr_dv[cc] : lr_D[cc];
+        s0 += wave_sum(d0) * dc;
+        s1 += wave_sum(d1) * dc;
       }
       if (lane == 0) {
         const int gid = lr_lds ? lr_g[t] : lr_mat_gid[t];
@@ -703,15 +714,17 @@ k_ls_solve_fast(DevCtrl* __restrict__ c, int m, int gid_g, int n_extra, const in
         extra_q(k, q1, q2);
         const double v = (st ? ex_v[t][2] : pv_raw[k]) + a * (a * q2 + q1);
         pv_raw[k] = v;
+        double yk = 1.0;
         if (k == m) {
           c->obj = v;
-          y[m] = 1.0;
         } else {
           const double pc = fmax(v, st ? ex_v[t][3] : lb[k]);
           pv[k] = pc;
           pv2 += pc * pc;
-          y[k] = -fmin(st ? ex_v[t][1] : lam_ub[k], (st ? ex_v[t][0] : lam[k]) - sigma * v);
+          yk = -fmin(st ? ex_v[t][1] : lam_ub[k], (st ? ex_v[t][0] : lam[k]) - sigma * v);
         }
+        y[k] = yk;
+        if (st) ex_y[t] = yk;   // read back by the low-rank tail below without a trip through global memory
       }
       c->pv2_extra = pv2;
     }
@@ -727,9 +740,28 @@ k_ls_solve_fast(DevCtrl* __restrict__ c, int m, int gid_g, int n_extra, const in
   if (sh_err != 0) return;
   const double a = sh_alpha;
   const int per = lr_ST * r;
+  const int n_st = min(n_extra, SDPLR_LSF_EXMAX);
   for (int t = threadIdx.x; t < per; t += SDPLR_LSF_NT) {  // W0 ← W0 + α·W1 = R_newᵀB ; WS = y·D·W0
-    const double w = lrW[t] + a * lrW[per + t];
+    const int cc = t / r;
+    double w, yc, dc;
+    if (lr_lds) {   // everything is at hand in LDS: the projections, D_c, the owner and — committed above — its y
+      w = lw[t] + a * lw[per + t];
+      dc = lr_dv[cc];
+      const int gid = lr_cg[cc];
+      bool found = false;
+      yc = 0.0;
+      for (int e = 0; e < n_st; e++)
+        if (ex_k[e] == gid) {
+          yc = ex_y[e];
+          found = true;
+        }
+      if (!found) yc = y[gid];
+    } else {
+      w = lrW[t] + a * lrW[per + t];
+      dc = lr_D[cc];
+      yc = y[lr_col_gid[cc]];
+    }
     lrW[t] = w;
-    lrWS[t] = y[lr_col_gid[t / r]] * lr_D[t / r] * w;
+    lrWS[t] = yc * dc * w;
   }
 }
