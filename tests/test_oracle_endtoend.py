@@ -81,6 +81,40 @@ def test_preprocess_matches_oracle(family):
             assert np.array_equal(getattr(a, k), getattr(b, k)), (family, seed, k)
 
 
+def test_preprocess_edge_cases():
+    """What the vectorised preprocessing must still do at the edges: repeated positions across matrices and unsorted
+    entries inside one (≡ the literal restatement), a lower-triangular entry without its mirror (the reference's
+    binary search at src/preprocess.jl:143-156 would fail: reported as an error), entries outside the matrix, and a
+    problem without sparse matrices."""
+    from sdplrplus_jl_amd.structs import SparseBatch
+    n = 6
+    # matrix 0: unsorted symmetric entries incl. a repeated diagonal position shared with matrix 1; matrix 2: one off-diagonal pair
+    I = np.array([4, 1, 1, 0, 3, 3, 1, 2, 5], dtype=np.int64)
+    J = np.array([1, 4, 1, 0, 3, 3, 1, 5, 2], dtype=np.int64)
+    V = np.array([2.0, 2.0, 1.0, -1.0, 0.5, 0.25, 3.0, 7.0, 7.0])
+    ent_ptr = np.array([0, 4, 7, 9], dtype=np.int64)
+    batch = SparseBatch(n, ent_ptr, I, J, V, np.array([0, 1, 2], dtype=np.int64))
+    a, b = sj.preprocess_sparsecons(batch), oracle.preprocess(batch)
+    for k in ("matptr", "nzind", "nzval_one", "nzval_two", "triu_colptr", "triu_rowval",
+              "full_colptr", "full_rowval", "mappedto_triu", "global_inds"):
+        assert np.array_equal(getattr(a, k), getattr(b, k)), k
+    # every full-pattern entry maps to the position of (min, max) in the upper-triangular pattern
+    cols = np.repeat(np.arange(n), np.diff(a.full_colptr))
+    tcols = np.repeat(np.arange(n), np.diff(a.triu_colptr))
+    assert np.array_equal(a.triu_rowval[a.mappedto_triu], np.minimum(a.full_rowval, cols))
+    assert np.array_equal(tcols[a.mappedto_triu], np.maximum(a.full_rowval, cols))
+    bad = SparseBatch(n, np.array([0, 1], dtype=np.int64), np.array([4]), np.array([1]), np.array([1.0]), np.array([0]))
+    with pytest.raises(ValueError, match="not symmetric"):
+        sj.preprocess_sparsecons(bad)
+    out = SparseBatch(n, np.array([0, 1], dtype=np.int64), np.array([6]), np.array([1]), np.array([1.0]), np.array([0]))
+    with pytest.raises(ValueError, match="outside"):
+        sj.preprocess_sparsecons(out)
+    empty = SparseBatch(n, np.array([0], dtype=np.int64), np.zeros(0, dtype=np.int64), np.zeros(0, dtype=np.int64),
+                        np.zeros(0), np.zeros(0, dtype=np.int64))
+    e = sj.preprocess_sparsecons(empty)
+    assert e.nnzT == 0 and e.nnzS == 0 and e.nnzAgg == 0 and np.array_equal(e.triu_colptr, np.zeros(n + 1, dtype=np.int64))
+
+
 def test_batched_builders_match_lists():
     """*_data builders produce the very same batch as the list-based reference builders."""
     A = problems.gnp_graph(60, 0.1, 3)
