@@ -1,0 +1,40 @@
+"""dev tool: randomized END-TO-END sweep — full solves (σ/λ schedule, dual bounds, rank updates) on the HIP library and on
+the oracle from the same seeds; prints where termination, objective or dual bound disagree beyond the tolerances asked for"""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import numpy as np
+import sdplrplus_jl_amd as sj
+from oracle import oracle
+from helpers import make_data, FAMILIES_EQ
+FAMS = list(FAMILIES_EQ) + ["ineq_0.05"]
+hip, ora = sj.load_hip(), oracle.abi()
+rng = np.random.Generator(np.random.PCG64(int(sys.argv[1]) if len(sys.argv) > 1 else 0))
+N = int(sys.argv[2]) if len(sys.argv) > 2 else 60
+rows = []
+for t in range(N):
+    fam = FAMS[int(rng.integers(len(FAMS)))]
+    n = int(rng.integers(8, 50)); p = float(rng.uniform(0.1, 0.5)); r = int(rng.choice([2, 3, 5, 8]))
+    tol = float(rng.choice([1e-2, 1e-3]))
+    try:
+        data, *_ = make_data(fam, int(rng.integers(1 << 30)), n, p)
+    except Exception:
+        continue
+    tb = 1.0 if fam == "lovasz_theta" else float(data.n)
+    kw = dict(r=r, printlevel=0, ptol=tol, objtol=tol, seed=t, prior_trace_bound=tb, maxmajoriter=40, maxiter=20000)
+    try:
+        a = sj.sdplr(data=data, abi=hip, **kw)
+        b = sj.sdplr(data=data, abi=ora, **kw)
+    except Exception as e:
+        print("EXC", fam, n, r, tol, repr(e)[:200]); continue
+    sc = max(1.0, abs(b["obj"]))
+    conv_a = a["primal_vio"] <= tol and a["min_duality_gap"] <= tol
+    conv_b = b["primal_vio"] <= tol and b["min_duality_gap"] <= tol
+    rows.append((abs(a["obj"] - b["obj"]) / sc, abs(a["max_dual_value"] - b["max_dual_value"]) / sc, fam, n, r, tol,
+                 a["iter"], b["iter"], a["majoriter"], b["majoriter"], a["r"], b["r"], conv_a, conv_b))
+rows.sort(reverse=True)
+print("cases", len(rows), " both converged:", sum(1 for x in rows if x[-1] and x[-2]), " termination differs:", sum(1 for x in rows if x[-1] != x[-2]))
+for x in rows[:8]:
+    print("  dobj %.2e ddual %.2e  %s n=%d r=%d tol=%g  iters %d/%d majors %d/%d rank %d/%d conv %s/%s" % x)
+bad = [x for x in rows if x[-1] and x[-2] and x[0] > 3 * x[5]]
+print("objective differs by more than 3·tol although both converged:", len(bad))
