@@ -89,6 +89,26 @@ def test_first_iterations_match_oracle_at_baseline_size(hip_abi, oracle_abi, whi
     assert abs(h["ritz"] - o["ritz"]) <= 1e-6 * scale, (h["ritz"], o["ritz"])
 
 
+def test_twenty_five_iterations_stay_within_the_north_star_tolerance(hip_abi, oracle_abi):
+    """Round-off differences between the two implementations (summation orders, the cubic's root finder) grow along the
+    L-BFGS trajectory by ≈ 1.5–1.6× per inner iteration on the north-star instance (measured: 3e-13 after 5 iterations,
+    1.5e-9 on ‖grad‖ after 25, decoupled trajectories after ≈ 60 — scripts/drift_vs_oracle.py): nonconvex descent is
+    that sensitive, on any pair of FP64 implementations.  25 iterations is as far as BASELINE.json's 1e-8 can be asked of
+    the STATE; beyond it the comparison is on what the solve returns (test_gpu_parity.py, scripts/stress_solve.py)."""
+    data, seed = _instance("maxcut_n1e5")
+    normC, normb = data.normC(), float(np.linalg.norm(data.b))
+    out = {}
+    for name, abi in (("hip", hip_abi), ("oracle", oracle_abi)):
+        s, _ = make_solver(abi, data, 32, seed=seed)
+        res = s.inner_loop(normC, normb, True, True, False, 0.0, -1e300, 25, 0.0, *s.fg(normC, normb))
+        assert res[4] == 25
+        out[name] = (np.array([res[0], res[1], res[2], s.obj]), s.Rt)
+        s.close()
+    (vh, Rh), (vo, Ro) = out["hip"], out["oracle"]
+    assert np.all(np.abs(vh - vo) <= TOL * np.abs(vo)), (vh, vo)
+    assert rel(Rh, Ro) < TOL
+
+
 def _batch_instances():
     z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "gset_G1_G9.npz"))
     graphs = [problems.graph_from_edges(int(z[f"G{k}_n"]), z[f"G{k}"]) for k in range(1, 10)]
