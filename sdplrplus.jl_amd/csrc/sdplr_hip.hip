@@ -475,20 +475,21 @@ int build_tiles(S* s) {
   std::vector<double> t_val;
   t_ent.reserve(g_col.size() + (size_t)nt * L / 2 + 128);
   t_val.reserve(g_col.size() + (size_t)nt * L / 2 + 128);
-  std::vector<std::pair<int, int>> tmp;  // (column, position in the CSR)
+  std::vector<unsigned long long> tmp;  // column << 32 | position in the tile's slice of the CSR
   std::vector<int> rowof;
   for (int64_t t = 0; t < nt; t++) {
     const int64_t r0 = t_row[t], r1 = t_row[t + 1];
     const int b = g_ptr[r0], e = g_ptr[r1];
-    tmp.clear();
-    for (int q = b; q < e; q++) tmp.push_back({g_col[q], q});
+    tmp.resize(e - b);
+    for (int q = b; q < e; q++) tmp[q - b] = ((unsigned long long)(unsigned)g_col[q] << 32) | (unsigned)(q - b);
     std::sort(tmp.begin(), tmp.end());  // by column, then by CSR position (= by row)
     int64_t row = r0;
     rowof.assign(e - b, 0);
     for (int q = b; q < e; q++) { while (q >= g_ptr[row + 1]) row++; rowof[q - b] = (int)(row - r0); }
     for (int q = 0; q < e - b; q++) {
-      t_ent.push_back((rowof[tmp[q].second - b] << SDPLR_TILE_COLBITS) | tmp[q].first);
-      t_val.push_back(g_val[tmp[q].second]);
+      const int col = (int)(tmp[q] >> 32), at = (int)(tmp[q] & 0xFFFFFFFFull);
+      t_ent.push_back((rowof[at] << SDPLR_TILE_COLBITS) | col);
+      t_val.push_back(g_val[b + at]);
     }
     while (t_ent.size() % L) { t_ent.push_back((K << SDPLR_TILE_COLBITS) | (int)r0); t_val.push_back(0.0); }
     t_ptr[t + 1] = (int)t_ent.size();
@@ -562,7 +563,18 @@ int build_band(S* s) {
       pos.push_back(make_int4(pp[0], pp[1], pp[2], pp[3]));
     }
   };
-  for (int b = 0; b < NB; b++)
+  // a row's entries are sorted by column, so its entries inside band b start where those of bands < b end
+  std::vector<int> band_first(n);
+  for (int64_t j = 0; j < n; j++) band_first[j] = cp[j];
+  {
+    size_t total = 0;
+    for (size_t t = 0; t < cnt.size(); t++) total += (size_t)(cnt[t] + 3) / 4;
+    cw.reserve((total + 1) * 64 + 64 * (size_t)NB * NC);
+    pos.reserve((total + 1) * 64 + 64 * (size_t)NB * NC);
+  }
+  for (int b = 0; b < NB; b++) {
+    if (b > 0)
+      for (int64_t j = 0; j < n; j++) band_first[j] += cnt[(size_t)(b - 1) * n + j];
     for (int c = 0; c < NC; c++) {
       const int64_t r0 = (int64_t)c * CH, r1 = std::min<int64_t>(r0 + CH, n);
       rows.clear();
@@ -572,18 +584,14 @@ int build_band(S* s) {
       for (size_t q0 = 0; q0 < rows.size(); q0 += 64) {
         const int nl = (int)std::min<size_t>(64, rows.size() - q0);
         const int len = cnt[(size_t)b * n + rows[q0]];
-        int first[64];   // first entry of each lane's row inside band b (a scan of the short row)
-        for (int l = 0; l < nl; l++) {
-          const int j = rows[q0 + l];
-          int p = cp[j];
-          while (rv[p] / BW != b) p++;
-          first[l] = p;
-        }
+        int first[64];   // first entry of each lane's row inside band b
+        for (int l = 0; l < nl; l++) first[l] = band_first[rows[q0 + l]];
         for (int k0 = 0; k0 < len; k0 += 4) push_group(first, rows.data() + q0, nl, k0, r0, b);
         slot_g.push_back((int)(cw.size() / 64));
       }
       blk_slot.push_back((int)slot_g.size() - 1);
     }
+  }
   const size_t n_groups = cw.size() / 64;
   if ((n_groups + 1) * 64 >= (size_t)1 << 31) return SDPLR_OK;
   push_group(nullptr, nullptr, 0, 0, 0, 0);   // the all-padding dummy group
