@@ -2074,7 +2074,26 @@ struct DevBand {
   const int4* pos;                // [groups·64] positions in sparse_S.nzval; −1 ⇒ padding
   double* tpart;                  // [NB][n] band partials of t = S·u
   double* textra;                 // [n] hub rows of t (k_spmv_long), zero elsewhere
+  // PALETTE form (structured problems: every off-diagonal entry of S is y_g·A_g[i,j], and A_g has ≤ 255 distinct
+  // off-diagonal values — unit or small-integer edge weights): an entry is a 2-byte column and a 1-byte value code,
+  // packed into the SAME 16-byte word per lane and four entries ({c0|c1, c2|c3, row|code0|code1, code2|code3}); no value
+  // arrays, no refill per run (the palette is static, y_g a scalar).  The diagonal — different in every row — is left
+  // out of the groups and rides band 0's partial (`sdiag`, refreshed once per Lanczos run).
+  int pal_mode, gid_g;
+  const double* pal;              // [256] pal[0] = 0 (padding), pal[c] the c-th distinct off-diagonal value of A_g
+  double* sdiag;                  // [n] S[k,k] (0 for hub rows: k_spmv_long has them whole)
+  const int* diagpos;             // [n] position of (k,k) in sparse_S.nzval, −1 ⇒ none / hub row
 };
+
+// sdiag[k] = S[k,k] of the S left by the last 𝒜t_preprocess! (palette form, once per Lanczos run)
+__global__ void __launch_bounds__(SDPLR_NT)
+k_lz_diag_fill(DevBand bd, int n, const double* __restrict__ nzval) {
+  const int stride = gridDim.x * SDPLR_NT;
+  for (int k = blockIdx.x * SDPLR_NT + threadIdx.x; k < n; k += stride) {
+    const int p = bd.diagpos[k];
+    bd.sdiag[k] = p >= 0 ? nzval[p] : 0.0;
+  }
+}
 
 __global__ void __launch_bounds__(SDPLR_NT)
 k_lz_band_fill(DevBand bd, const double* __restrict__ nzval) {
@@ -2105,12 +2124,14 @@ k_lz_band_fill(DevBand bd, const double* __restrict__ nzval) {
 // loads per lane for four entries (packed columns + row, two value pairs), the chunk's rows of u for the dot.  Slots
 // past the block's end and groups past a slot's end are skipped by a WAVE-UNIFORM branch (a slot belongs to one wave)
 // and stand in the registers as all-padding groups, so nothing in the sweep is conditional.
+template <bool PAL>
 __global__ void __launch_bounds__(SDPLR_LZB_NT)
 k_lz_band(DevBand bd, int n, DevCtrl* __restrict__ c, const double* __restrict__ u, DevLowRank lr,
           const double* __restrict__ yvec, const double* __restrict__ btx_part, int nb_prev,
           double* __restrict__ coef_out, double* __restrict__ beta_out, double* __restrict__ partials) {
   extern __shared__ double lzb_lds[];   // xs[BW] | ys[CH]
   __shared__ double shw[SDPLR_LZB_NT / 64];
+  __shared__ double pals[PAL ? 256 : 1];   // PAL: y_g·pal[code] = the S values themselves (fl(y_g·a), as assembled)
   constexpr int MAXS = SDPLR_LZB_MAXS, G0 = SDPLR_LZB_G0, NW = SDPLR_LZB_NT / 64;
   constexpr int NG = G0 + MAXS - 1;     // groups requested up front per lane
   double* xs = lzb_lds;
@@ -2187,7 +2208,12 @@ k_lz_band(DevBand bd, int n, DevCtrl* __restrict__ c, const double* __restrict__
     gend[q] = ok ? g1 : bd.n_groups;
   }
   uint4 cw[NG];
-  double2 va[NG], vb[NG];
+  double2 va[PAL ? 1 : NG], vb[PAL ? 1 : NG];
+  double palv = 0.0, ygv = 0.0;
+  if (PAL) {
+    palv = bd.pal[tid & 255];
+    ygv = yvec[bd.gid_g];
+  }
 #pragma unroll
   for (int j = 0; j < NG; j++) {
     const int q = j < G0 ? 0 : j - G0 + 1;
@@ -2195,11 +2221,13 @@ k_lz_band(DevBand bd, int n, DevCtrl* __restrict__ c, const double* __restrict__
     if (g < gend[q]) {     // wave-uniform (a scalar branch): slots and groups past the end are not requested at all
       const long long e = (long long)g * 64 + lane;
       cw[j] = bd.cw[e];
-      va[j] = bd.vA[e];
-      vb[j] = bd.vB[e];
+      if (!PAL) {
+        va[j] = bd.vA[e];
+        vb[j] = bd.vB[e];
+      }
     } else {
       cw[j] = make_uint4(0u, 0u, 0xFFFFu, 0u);
-      va[j].x = va[j].y = vb[j].x = vb[j].y = 0.0;
+      if (!PAL) va[j].x = va[j].y = vb[j].x = vb[j].y = 0.0;
     }
   }
   constexpr int XT = 16384 / 2 / SDPLR_LZB_NT;    // double2 per thread for the widest band
@@ -2211,6 +2239,11 @@ k_lz_band(DevBand bd, int n, DevCtrl* __restrict__ c, const double* __restrict__
   double ur[MAXS];   // the chunk's rows of u (CH ≤ 4096 = MAXS·1024)
 #pragma unroll
   for (int k = 0; k < MAXS; k++) ur[k] = u[min(row0 + tid + SDPLR_LZB_NT * k, n - 1)];
+  double sdr[PAL ? MAXS : 1];   // palette form: the rows' diagonal entries ride band 0's partial
+  if (PAL) {
+#pragma unroll
+    for (int k = 0; k < MAXS; k++) sdr[k] = (b == 0) ? bd.sdiag[min(row0 + tid + SDPLR_LZB_NT * k, n - 1)] : 0.0;
+  }
   if (dn) return;
   // ---- the band of x into LDS --------------------------------------------------------------------------------------
 #pragma unroll
@@ -2220,6 +2253,7 @@ k_lz_band(DevBand bd, int n, DevCtrl* __restrict__ c, const double* __restrict__
   }
   if ((ncol & 1) && tid == 0) xs[ncol - 1] = u[col0 + ncol - 1];
   for (int i = tid; i < nrow; i += SDPLR_LZB_NT) ys[i] = 0.0;
+  if (PAL && tid < 256) pals[tid] = ygv * palv;
   __syncthreads();
   // ---- the sweep: one row per lane and slot; a row's products are added in ascending column order ------------------
   auto fold = [&](double acc, const uint4& w, const double2& a, const double2& bb) {
@@ -2229,17 +2263,25 @@ k_lz_band(DevBand bd, int n, DevCtrl* __restrict__ c, const double* __restrict__
     acc += bb.y * xs[w.y >> 16];
     return acc;
   };
+  auto fold_pal = [&](double acc, const uint4& w) {
+    acc += pals[(w.z >> 16) & 0xFFu] * xs[w.x & 0xFFFFu];
+    acc += pals[w.z >> 24] * xs[w.x >> 16];
+    acc += pals[w.w & 0xFFu] * xs[w.y & 0xFFFFu];
+    acc += pals[(w.w >> 8) & 0xFFu] * xs[w.y >> 16];
+    return acc;
+  };
 #pragma unroll
   for (int q = 0; q < MAXS; q++) {
     double acc = 0.0;
     const int j0 = q == 0 ? 0 : G0 + q - 1, nj = q == 0 ? G0 : 1;
 #pragma unroll
-    for (int j = 0; j < nj; j++) acc = fold(acc, cw[j0 + j], va[j0 + j], vb[j0 + j]);
+    for (int j = 0; j < nj; j++) acc = PAL ? fold_pal(acc, cw[j0 + j]) : fold(acc, cw[j0 + j], va[PAL ? 0 : j0 + j], vb[PAL ? 0 : j0 + j]);
     for (int g = gfirst[q] + nj; g < gend[q]; g++) {      // rows longer than the up-front groups (rare)
       const long long e = (long long)g * 64 + lane;
-      acc = fold(acc, bd.cw[e], bd.vA[e], bd.vB[e]);
+      if (PAL) acc = fold_pal(acc, bd.cw[e]);
+      else acc = fold(acc, bd.cw[e], bd.vA[e], bd.vB[e]);
     }
-    const unsigned lrow = cw[j0].z;
+    const unsigned lrow = cw[j0].z & 0xFFFFu;
     if (lrow != 0xFFFFu) ys[lrow] = acc;
   }
   __syncthreads();
@@ -2249,7 +2291,8 @@ k_lz_band(DevBand bd, int n, DevCtrl* __restrict__ c, const double* __restrict__
   for (int k = 0; k < MAXS; k++) {
     const int i = tid + SDPLR_LZB_NT * k;
     if (i < nrow) {
-      const double t = ys[i];
+      double t = ys[i];
+      if (PAL) t += sdr[k] * ur[k];
       tp[i] = t;
       dot += ur[k] * t;
     }

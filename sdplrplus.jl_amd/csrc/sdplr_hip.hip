@@ -531,9 +531,52 @@ int build_band(S* s) {
   if (const char* e = getenv("SDPLR_HIP_LZBAND_NC")) NC = std::max(NC, atoi(e));
   if ((int64_t)NB * NC > 1024) return SDPLR_OK;
   const int CH = (int)((n + NC - 1) / NC);
-  const std::vector<int>&cp = s->h_fcp, &rv = s->h_frv;
   const int thresh = s->sp.long_thresh;
-  auto is_hub = [&](int64_t j) { return s->sp.n_long_rows > 0 && cp[j + 1] - cp[j] > thresh; };
+  auto is_hub = [&](int64_t j) { return s->sp.n_long_rows > 0 && s->h_fcp[j + 1] - s->h_fcp[j] > thresh; };
+  // PALETTE form (k_sparse.h, DevBand): on the structured path every off-diagonal entry of S is y_g·A_g[i,j]; with
+  // ≤ 255 distinct off-diagonal values in A_g an entry shrinks from 12 bytes (2-byte column, 8-byte value + padding
+  // share) to 3, and the per-run refill of the values disappears.  The plan is then built on the pattern WITHOUT its
+  // diagonal (ocp/orv, codes oc); the diagonal rides band 0's partial from `sdiag`.
+  bool pal = s->fast && !s->h_gptr.empty() && getenv("SDPLR_HIP_NO_LZPAL") == nullptr;
+  std::vector<double> palv(1, 0.0);
+  std::vector<int> ocp, orv, diagpos;
+  std::vector<unsigned char> oc;
+  if (pal) {   // distinct off-diagonal values of A_g, ascending; more than 255 ⇒ the value-array form
+    std::vector<double> all;
+    for (int64_t j = 0; j < n && pal; j++)
+      for (int q = s->h_gptr[j]; q < s->h_gptr[j + 1]; q++) {
+        if (s->h_gcol[q] == (int)j) continue;
+        const double v = s->h_gval[q];
+        auto it = std::lower_bound(all.begin(), all.end(), v);
+        if (it != all.end() && *it == v) continue;
+        if (!(v == v) || all.size() >= 255) { pal = false; break; }
+        all.insert(it, v);
+      }
+    if (pal) palv.insert(palv.end(), all.begin(), all.end());
+  }
+  if (pal) {
+    ocp.assign(n + 1, 0);
+    diagpos.assign(n, -1);
+    orv.reserve(s->h_frv.size());
+    oc.reserve(s->h_frv.size());
+    for (int64_t j = 0; j < n && pal; j++) {
+      int q = s->h_gptr[j];   // A_g's row j and the full pattern's row j are both sorted by column
+      for (int p = s->h_fcp[j]; p < s->h_fcp[j + 1]; p++) {
+        const int col = s->h_frv[p];
+        if (col == (int)j) {
+          if (!is_hub(j)) diagpos[j] = p;
+          continue;
+        }
+        while (q < s->h_gptr[j + 1] && s->h_gcol[q] < col) q++;
+        if (q >= s->h_gptr[j + 1] || s->h_gcol[q] != col) { pal = false; break; }   // an off-diagonal entry A_g does not hold
+        const int code = (int)(std::lower_bound(palv.begin() + 1, palv.end(), s->h_gval[q]) - palv.begin());
+        orv.push_back(col);
+        oc.push_back((unsigned char)code);
+      }
+      ocp[j + 1] = (int)orv.size();
+    }
+  }
+  const std::vector<int>&cp = pal ? ocp : s->h_fcp, &rv = pal ? orv : s->h_frv;
   // entries of row j that fall into band b, in ascending column order: counted, then filled
   std::vector<int> cnt((size_t)NB * n, 0);
   for (int64_t j = 0; j < n; j++) {
@@ -546,7 +589,7 @@ int build_band(S* s) {
   std::vector<int> rows;
   auto push_group = [&](const int* first, const int* rowsp, int nl, int k0, int64_t r0, int b) {
     for (int l = 0; l < 64; l++) {
-      unsigned cc[4] = {0, 0, 0, 0};
+      unsigned cc[4] = {0, 0, 0, 0}, code[4] = {0, 0, 0, 0};
       int pp[4] = {-1, -1, -1, -1};
       unsigned lrow = 0xFFFFu;
       if (l < nl) {
@@ -557,10 +600,15 @@ int build_band(S* s) {
             const int p = first[l] + k0 + k;
             cc[k] = (unsigned)(rv[p] - b * BW);
             pp[k] = p;
+            if (pal) code[k] = oc[p];
           }
       }
-      cw.push_back(make_uint4(cc[0] | (cc[1] << 16), cc[2] | (cc[3] << 16), lrow, 0u));
-      pos.push_back(make_int4(pp[0], pp[1], pp[2], pp[3]));
+      if (pal) {
+        cw.push_back(make_uint4(cc[0] | (cc[1] << 16), cc[2] | (cc[3] << 16), lrow | (code[0] << 16) | (code[1] << 24), code[2] | (code[3] << 8)));
+      } else {
+        cw.push_back(make_uint4(cc[0] | (cc[1] << 16), cc[2] | (cc[3] << 16), lrow, 0u));
+        pos.push_back(make_int4(pp[0], pp[1], pp[2], pp[3]));
+      }
     }
   };
   // a row's entries are sorted by column, so its entries inside band b start where those of bands < b end
@@ -570,7 +618,7 @@ int build_band(S* s) {
     size_t total = 0;
     for (size_t t = 0; t < cnt.size(); t++) total += (size_t)(cnt[t] + 3) / 4;
     cw.reserve((total + 1) * 64 + 64 * (size_t)NB * NC);
-    pos.reserve((total + 1) * 64 + 64 * (size_t)NB * NC);
+    if (!pal) pos.reserve((total + 1) * 64 + 64 * (size_t)NB * NC);
   }
   for (int b = 0; b < NB; b++) {
     if (b > 0)
@@ -602,15 +650,26 @@ int build_band(S* s) {
   if ((rc = upload(s, &bd.blk_slot, blk_slot))) return rc;
   if ((rc = upload(s, &bd.slot_g, slot_g))) return rc;
   if ((rc = upload(s, &bd.cw, cw))) return rc;
-  if ((rc = upload(s, &bd.pos, pos))) return rc;
-  if ((rc = dalloc(s, &bd.vA, cw.size()))) return rc;
-  if ((rc = dalloc(s, &bd.vB, cw.size()))) return rc;
-  HIPCK(s, hipMemsetAsync(bd.vA, 0, cw.size() * sizeof(double2), s->stream));
-  HIPCK(s, hipMemsetAsync(bd.vB, 0, cw.size() * sizeof(double2), s->stream));
+  if (pal) {
+    palv.resize(256, 0.0);
+    bd.pal_mode = 1;
+    bd.gid_g = s->ff.gid_g;
+    if ((rc = upload(s, &bd.pal, palv))) return rc;
+    if ((rc = upload(s, &bd.diagpos, diagpos))) return rc;
+    if ((rc = dzero(s, &bd.sdiag, (size_t)n))) return rc;
+  } else {
+    if ((rc = upload(s, &bd.pos, pos))) return rc;
+    if ((rc = dalloc(s, &bd.vA, cw.size()))) return rc;
+    if ((rc = dalloc(s, &bd.vB, cw.size()))) return rc;
+    HIPCK(s, hipMemsetAsync(bd.vA, 0, cw.size() * sizeof(double2), s->stream));
+    HIPCK(s, hipMemsetAsync(bd.vB, 0, cw.size() * sizeof(double2), s->stream));
+  }
   if ((rc = dzero(s, &bd.tpart, (size_t)NB * n))) return rc;
   if ((rc = dzero(s, &bd.textra, (size_t)n))) return rc;
   // more than 64 KB of dynamic LDS has to be asked for
-  HIPCK(s, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lz_band), hipFuncAttributeMaxDynamicSharedMemorySize,
+  HIPCK(s, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lz_band<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)((size_t)(BW + CH) * sizeof(double))));
+  HIPCK(s, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lz_band<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                (int)((size_t)(BW + CH) * sizeof(double))));
   s->use_band = true;
   return SDPLR_OK;
@@ -853,8 +912,6 @@ int32_t sdplr_hip_finalize(S* s) {
   };
   lap("uploads (layout)");
   if ((rc = plan_long(s->h_fcp, sp))) return rc;
-  if ((rc = build_band(s))) return rc;
-  lap("band plan");
   if ((rc = dzero(s, &sp.nzval, s->nnzS))) return rc;
   if ((rc = dzero(s, &sp.triu_nzval, s->nnzT))) return rc;
   if ((rc = dzero(s, &sp.UVt0, s->nnzT))) return rc;
@@ -1130,6 +1187,8 @@ int32_t sdplr_hip_finalize(S* s) {
     }
   }
   lap("classification / edge plan");
+  if ((rc = build_band(s))) return rc;   // (after the classification: the palette form needs to know A_g)
+  lap("band plan");
   if ((rc = alloc_factors(s))) return rc;
   lap("factors");
   s->nb_m = blocks_for(m + 1, SDPLR_NT, 256);
@@ -1885,7 +1944,8 @@ void enq_lz_step(S* s, double* uprev, double* u, double* t) {
     {
       ProfScope ps(s, "lz_spmv");
       // (+ 1: the grid's last block closes the previous step and does nothing else)
-      k_lz_band<<<nbk + 1, SDPLR_LZB_NT, (size_t)(bd.BW + bd.CH) * sizeof(double), s->stream>>>(bd, (int)s->n, s->ctrl, u, s->lr, s->y, s->lr_btx_part, s->nb_n, s->lr_coef, s->lz_beta, s->partials);
+      if (bd.pal_mode) k_lz_band<true><<<nbk + 1, SDPLR_LZB_NT, (size_t)(bd.BW + bd.CH) * sizeof(double), s->stream>>>(bd, (int)s->n, s->ctrl, u, s->lr, s->y, s->lr_btx_part, s->nb_n, s->lr_coef, s->lz_beta, s->partials);
+      else k_lz_band<false><<<nbk + 1, SDPLR_LZB_NT, (size_t)(bd.BW + bd.CH) * sizeof(double), s->stream>>>(bd, (int)s->n, s->ctrl, u, s->lr, s->y, s->lr_btx_part, s->nb_n, s->lr_coef, s->lz_beta, s->partials);
       if (nbl > 0) {
         DevLowRank none{};
         k_spmv_long<<<nbl, SDPLR_NT, 0, s->stream>>>(s->sp, u, bd.textra, none, s->lr_coef, SLOT_LZ_A, nbk, s->partials, stop);
@@ -1929,7 +1989,8 @@ int run_lanczos(S* s, int64_t q, const double* v0, double* alpha, double* beta, 
   double *b0 = s->lz_buf[0], *b1 = s->lz_buf[1], *b2 = s->lz_buf[2];
   if (s->use_band) {   // S is fixed for the q steps: the band layout's values are gathered once per run
     ProfScope ps(s, "lanczos_init");
-    k_lz_band_fill<<<blocks_for((long long)(s->band.n_groups + 1) * 64, SDPLR_NT, 2048), SDPLR_NT, 0, s->stream>>>(s->band, s->sp.nzval);
+    if (s->band.pal_mode) k_lz_diag_fill<<<s->nb_n, SDPLR_NT, 0, s->stream>>>(s->band, (int)n, s->sp.nzval);
+    else k_lz_band_fill<<<blocks_for((long long)(s->band.n_groups + 1) * 64, SDPLR_NT, 2048), SDPLR_NT, 0, s->stream>>>(s->band, s->sp.nzval);
   }
   HIPCK(s, hipMemcpyAsync(b1, v0, n * sizeof(double), hipMemcpyHostToDevice, s->stream));   // u_1 = v0
   HIPCK(s, hipMemsetAsync(b0, 0, n * sizeof(double), s->stream));                            // u_0 = 0

@@ -823,6 +823,47 @@ def test_eigval_and_dimacs_on_gpu(hip_abi):
     _check_eigval_and_dimacs(hip_abi)
 
 
+@pytest.mark.parametrize("n_weights", [1, 3, 255, 400])
+def test_lanczos_palette_form_matches_value_form(hip_abi, monkeypatch, n_weights):
+    """Band plan with 3-byte entries (2-byte column + 1-byte code into the ≤ 255 distinct off-diagonal values of the one
+    general matrix, S[i,j] = y_g·A_g[i,j]; the diagonal apart) against the 12-byte value form (SDPLR_HIP_NO_LZPAL=1) on
+    weighted MaxCut instances: same α, β to 1e-12 of ‖S‖ — and NOT bit-identical while the palette is in use (another
+    summation order), bit-identical once the number of distinct weights exceeds 255 and the library falls back."""
+    rng = np.random.Generator(np.random.PCG64(9))
+    A = problems.gnp_graph(300, 0.08, 21).tocoo()
+    up = A.row < A.col
+    w = rng.integers(1, n_weights + 1, size=int(up.sum())).astype(float) * (0.5 if n_weights > 1 else 1.0)
+    if n_weights >= 255:
+        w[:n_weights] = 0.5 * np.arange(1, n_weights + 1)    # every weight present
+    W = sp.coo_matrix((np.concatenate([w, w]), (np.concatenate([A.row[up], A.col[up]]), np.concatenate([A.col[up], A.row[up]]))),
+                      shape=A.shape).tocsc()
+    data = problems.maxcut_data(W)
+    v0 = rng.standard_normal(data.n)
+    y = rng.standard_normal(data.m + 1)
+    monkeypatch.setenv("SDPLR_HIP_LZBAND_MIN_N", "1")
+    monkeypatch.setenv("SDPLR_HIP_LZBAND_BW", "128")
+    monkeypatch.setenv("SDPLR_HIP_LZBAND_CH", "40")
+    runs = []
+    for no_pal in (False, True):
+        if no_pal:
+            monkeypatch.setenv("SDPLR_HIP_NO_LZPAL", "1")
+        s_, _ = make_solver(hip_abi, data, 4, seed=3)
+        s_.y = y
+        s_.At_preprocess()
+        al, be, k = s_.lanczos(40, v0)
+        # S·x through the operator API (gather form) for a direct check of the first step: α₁ = v'Sv
+        v = v0 / np.linalg.norm(v0)
+        assert al[0] == pytest.approx(float(v @ s_.At_right(v.reshape(-1, 1)).ravel()), rel=1e-12)
+        runs.append((al, be, k))
+        s_.close()
+    (a1, b1, k1), (a2, b2, k2) = runs
+    assert k1 == k2 == 40
+    scale = np.max(np.abs(a2))
+    assert np.allclose(a1[:8], a2[:8], rtol=0, atol=1e-11 * scale) and np.allclose(b1[:8], b2[:8], rtol=0, atol=1e-11 * scale)
+    same = np.array_equal(a1, a2) and np.array_equal(b1, b2)
+    assert same == (n_weights > 255)
+
+
 @pytest.mark.parametrize("family,bw,ch,hub", [("maxcut", 64, 16, None), ("minimum_bisection", 64, 7, None),
                                               ("lovasz_theta", 128, 32, 8), ("mu_conductance_0.05", 64, 1000, None),
                                               ("maxcut", 16384, 4096, 8)])
