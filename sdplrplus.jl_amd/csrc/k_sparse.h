@@ -2128,7 +2128,8 @@ template <bool PAL>
 __global__ void __launch_bounds__(SDPLR_LZB_NT)
 k_lz_band(DevBand bd, int n, DevCtrl* __restrict__ c, const double* __restrict__ u, DevLowRank lr,
           const double* __restrict__ yvec, const double* __restrict__ btx_part, int nb_prev,
-          double* __restrict__ coef_out, double* __restrict__ beta_out, double* __restrict__ partials) {
+          double* __restrict__ coef_out, double* __restrict__ beta_out, double* __restrict__ partials,
+          DevSparse sp, int nb_hub) {
   extern __shared__ double lzb_lds[];   // xs[BW] | ys[CH]
   __shared__ double shw[SDPLR_LZB_NT / 64];
   __shared__ double pals[PAL ? 256 : 1];   // PAL: y_g·pal[code] = the S values themselves (fl(y_g·a), as assembled)
@@ -2191,6 +2192,37 @@ k_lz_band(DevBand bd, int n, DevCtrl* __restrict__ c, const double* __restrict__
   }
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  if ((int)blockIdx.x >= bd.NB * bd.NC) {
+    // Hub rows (left out of the band plan): the nb_hub blocks between the sweeping blocks and the closing one take them
+    // whole from the assembled S, as k_spmv_long does — in this grid, so that a power-law instance does not pay a
+    // third launch per step.  t goes to `textra`, the block's share of u·t to the partial slot behind the sweepers'.
+    if (dn) return;
+    const int hb = (int)blockIdx.x - bd.NB * bd.NC, quarter = tid >> 8, qt = tid & 255;   // four rows per block and trip
+    double dot = 0.0;
+    for (int l0 = hb * 4; l0 < sp.n_long_rows; l0 += nb_hub * 4) {
+      const int lrow = l0 + quarter;
+      const bool have = lrow < sp.n_long_rows;
+      const long long j = sp.long_rows[have ? lrow : l0];
+      double t = 0.0;
+      if (have)
+        for (int p = sp.colptr[j] + qt; p < sp.colptr[j + 1]; p += 256) t += sp.nzval[p] * u[sp.rowval[p]];
+      t = wave_sum(t);
+      __syncthreads();
+      if (lane == 0) shw[wave] = t;
+      __syncthreads();
+      if (qt == 0 && have) {
+        const double tt = ((shw[4 * quarter] + shw[4 * quarter + 1]) + shw[4 * quarter + 2]) + shw[4 * quarter + 3];
+        bd.textra[j] = tt;
+        dot += u[j] * tt;
+      }
+    }
+    // the block's share of u·t: its four quarter sums in a fixed order
+    __syncthreads();
+    if (qt == 0) shw[quarter] = dot;
+    __syncthreads();
+    if (tid == 0) slot_partials(partials, SLOT_LZ_A)[blockIdx.x] = ((shw[0] + shw[1]) + shw[2]) + shw[3];
+    return;
+  }
   const int b = blockIdx.x / bd.NC, ch = blockIdx.x % bd.NC;
   const int col0 = b * bd.BW, ncol = max(0, min(bd.BW, n - col0));
   const int row0 = ch * bd.CH, nrow = max(0, min(bd.CH, n - row0));

@@ -527,7 +527,9 @@ int build_band(S* s) {
   const int NB = (int)((n + BWMAX - 1) / BWMAX);
   if (NB > 16) return SDPLR_OK;
   const int BW = (int)(((n + NB - 1) / NB + 63) / 64 * 64);
-  int NC = std::max<int>((int)((n + CHMAX - 1) / CHMAX), 256 / NB);
+  // one resident round of blocks (256 CUs, one 1024-thread block each): the sweeping blocks, the hub-row blocks, the closer
+  const int hub_blocks = s->sp.n_long_rows > 0 ? std::min((s->sp.n_long_rows + 3) / 4, 64) : 0;
+  int NC = std::max<int>((int)((n + CHMAX - 1) / CHMAX), std::max(1, (256 - hub_blocks - (hub_blocks > 0 ? 1 : 0)) / NB));
   if (const char* e = getenv("SDPLR_HIP_LZBAND_NC")) NC = std::max(NC, atoi(e));
   if ((int64_t)NB * NC > 1024) return SDPLR_OK;
   const int CH = (int)((n + NC - 1) / NC);
@@ -1935,21 +1937,22 @@ void note_capture_failure(S* s, const char* what) {
   }
 }
 
+// hub-row blocks inside k_lz_band's grid: four rows per 1024-thread block, at most 64 blocks (the band plan leaves
+// them room in the one resident round of blocks: build_band)
+int lz_hub_blocks(const S* s) { return s->sp.n_long_rows > 0 ? std::min((s->sp.n_long_rows + 3) / 4, 64) : 0; }
+
 // one Lanczos step = k_lz_spmv (+ hub rows) + k_lz_step on the buffer triple (uprev, u, t)
 void enq_lz_step(S* s, double* uprev, double* u, double* t) {
   const int* stop = &s->ctrl->lz_done;
   if (s->use_band) {   // LDS-band form (k_sparse.h, DevBand): partial t per (band, chunk), summed by the recurrence kernel
     const DevBand& bd = s->band;
-    const int nbk = bd.NB * bd.NC, nbl = s->sp.n_long_rows > 0 ? std::min(s->sp.n_long_rows, 256) : 0;
+    const int nbk = bd.NB * bd.NC, nbl = lz_hub_blocks(s);
     {
       ProfScope ps(s, "lz_spmv");
       // (+ 1: the grid's last block closes the previous step and does nothing else)
-      if (bd.pal_mode) k_lz_band<true><<<nbk + 1, SDPLR_LZB_NT, (size_t)(bd.BW + bd.CH) * sizeof(double), s->stream>>>(bd, (int)s->n, s->ctrl, u, s->lr, s->y, s->lr_btx_part, s->nb_n, s->lr_coef, s->lz_beta, s->partials);
-      else k_lz_band<false><<<nbk + 1, SDPLR_LZB_NT, (size_t)(bd.BW + bd.CH) * sizeof(double), s->stream>>>(bd, (int)s->n, s->ctrl, u, s->lr, s->y, s->lr_btx_part, s->nb_n, s->lr_coef, s->lz_beta, s->partials);
-      if (nbl > 0) {
-        DevLowRank none{};
-        k_spmv_long<<<nbl, SDPLR_NT, 0, s->stream>>>(s->sp, u, bd.textra, none, s->lr_coef, SLOT_LZ_A, nbk, s->partials, stop);
-      }
+      // grid: nbk sweeping blocks, nbl hub-row blocks, and the last block, which only closes the previous step
+      if (bd.pal_mode) k_lz_band<true><<<nbk + nbl + 1, SDPLR_LZB_NT, (size_t)(bd.BW + bd.CH) * sizeof(double), s->stream>>>(bd, (int)s->n, s->ctrl, u, s->lr, s->y, s->lr_btx_part, s->nb_n, s->lr_coef, s->lz_beta, s->partials, s->sp, nbl);
+      else k_lz_band<false><<<nbk + nbl + 1, SDPLR_LZB_NT, (size_t)(bd.BW + bd.CH) * sizeof(double), s->stream>>>(bd, (int)s->n, s->ctrl, u, s->lr, s->y, s->lr_btx_part, s->nb_n, s->lr_coef, s->lz_beta, s->partials, s->sp, nbl);
     }
     ProfScope ps(s, "lz_step");
     k_lz_step_band<<<s->nb_n, SDPLR_NT, 0, s->stream>>>((int)s->n, s->ctrl, bd, nbl > 0 ? 1 : 0, uprev, u, t, s->lr, s->lr_coef, s->lr_btx_part, nbk + nbl, s->lz_alpha, s->partials);
