@@ -111,6 +111,19 @@ int32_t sdplr_hip_set_sparse(sdplr_hip_solver* s, int64_t index_base, int64_t n_
                              int64_t nnzS, const int64_t* full_colptr,
                              const int64_t* full_rowval, const int64_t* mappedto_triu);
 
+/* The same layout built INSIDE the library: preprocess_sparsecons (src/preprocess.jl:24-169) on the sparse matrices
+ * themselves, given as concatenated COO triplets in findnz order (src/preprocess.jl:66-67): matrix k owns entries
+ * ent_ptr[k] .. ent_ptr[k+1]-1 of (I, J, V), both triangles present as in the reference's input; global_inds as above.
+ * Replaces the reference's host-side preprocessing call (src/structs.jl:331-339).  Use instead of set_sparse.         */
+int32_t sdplr_hip_set_sparse_coo(sdplr_hip_solver* s, int64_t index_base, int64_t n_sparse,
+                                 const int64_t* ent_ptr, const int64_t* I, const int64_t* J,
+                                 const double* V, const int64_t* global_inds);
+/* The aggregated layout held between set_sparse[_coo] and finalize, 0-based (SolverAuxiliary's fields,
+ * src/structs.jl:278-288).  which: 0 matptr, 1 nzind, 2 global_inds, 3 triu_colptr, 4 triu_rowval, 5 full_colptr,
+ * 6 full_rowval, 7 mappedto_triu (→ out_i); 8 nzval_one, 9 nzval_two (→ out_f).  Copies min(*len, cap) entries.       */
+int32_t sdplr_hip_get_layout(const sdplr_hip_solver* s, int32_t which, int64_t* out_i, double* out_f,
+                             int64_t cap, int64_t* len);
+
 /* One SymLowRankMatrix B·D·Bᵀ (src/structs.jl:11-24): B is n×s column-major, D the s diagonal
  * entries; global_ind indexes the (m+1)-vectors (m+1 ⇒ the cost matrix C), in index_base.      */
 int32_t sdplr_hip_add_symlowrank(sdplr_hip_solver* s, int64_t index_base, int64_t global_ind,
@@ -248,7 +261,9 @@ int32_t sdplr_hip_factor_dot(sdplr_hip_solver* s, int32_t slot_a, int32_t slot_b
  * good — visible here, never silent), out[2] captures skipped because the process-wide capture lock was busy
  * (that call ran eagerly; the next one tries again), out[3] inner-loop batches replayed from a graph,
  * out[4] inner-loop batches launched eagerly, out[5] Lanczos graph replays, out[6] Lanczos rounds launched
- * eagerly, out[7] inner iterations run.  Writes min(cap, 8) entries, *n_written says how many.            */
+ * eagerly, out[7] inner iterations run, out[8] inner loops run as ONE resident launch (small instances: one
+ * workgroup owns the instance for the whole loop), out[9] Lanczos runs as one resident launch, out[10] fg! calls as
+ * one resident launch.  Writes min(cap, 11) entries, *n_written says how many.                             */
 int32_t sdplr_hip_get_stats(const sdplr_hip_solver* s, int64_t* out, int32_t cap, int32_t* n_written);
 
 /* ---- per-kernel device timing (hipEvent pairs on the handle's stream) ------------------------ */

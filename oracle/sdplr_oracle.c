@@ -1237,6 +1237,58 @@ void sdplr_oracle_layout_free(sdplr_oracle_layout* l) {
   memset(l, 0, sizeof *l);
 }
 
+/* set_sparse_coo of the shared ABI: preprocess_sparsecons (the literal restatement above) + set_sparse */
+int32_t sdplr_oracle_set_sparse_coo(S* s, int64_t base, int64_t n_sparse, const int64_t* ent_ptr, const int64_t* I,
+                                    const int64_t* J, const double* V, const int64_t* gids) {
+  if (!s || s->finalized) return fail(s, ERR_STATE, "set_sparse_coo: bad state");
+  if (base != 0 && base != 1) return fail(s, ERR_INVALID, "set_sparse_coo: index_base must be 0 or 1");
+  int64_t* ptr0 = ialloc(n_sparse + 1);
+  for (int64_t k = 0; k <= n_sparse; k++) ptr0[k] = ent_ptr[k] - base;
+  sdplr_oracle_layout L;
+  int32_t rc = sdplr_oracle_preprocess(s->n, n_sparse, base, ptr0, I, J, V, &L);
+  free(ptr0);
+  if (rc != OK) return fail(s, rc, "set_sparse_coo: constraint entry outside the n×n matrix");
+  for (int64_t p = 0; p < L.nnzS; p++)
+    if (L.mappedto_triu[p] < 0) {
+      sdplr_oracle_layout_free(&L);
+      return fail(s, ERR_INVALID, "set_sparse_coo: a constraint matrix is not symmetric: a lower-triangular entry has no "
+                                  "upper-triangular mirror in the aggregated pattern");
+    }
+  int64_t* g0 = ialloc(n_sparse);
+  for (int64_t k = 0; k < n_sparse; k++) g0[k] = gids[k] - base;
+  rc = sdplr_oracle_set_sparse(s, 0, n_sparse, L.matptr, L.nzind, L.nzval_one, L.nzval_two, g0, L.nnzT, L.triu_colptr,
+                               L.triu_rowval, L.nnzS, L.full_colptr, L.full_rowval, L.mappedto_triu);
+  free(g0);
+  sdplr_oracle_layout_free(&L);
+  return rc;
+}
+int32_t sdplr_oracle_get_layout(const S* s, int32_t which, int64_t* out_i, double* out_f, int64_t cap, int64_t* len) {
+  if (!s) return ERR_INVALID;
+  if (s->finalized || !s->matptr) return ERR_STATE;
+  const int64_t* vi = NULL;
+  const double* vf = NULL;
+  int64_t L = 0;
+  switch (which) {
+    case 0: vi = s->matptr; L = s->n_sparse + 1; break;
+    case 1: vi = s->nzind; L = s->nnzAgg; break;
+    case 2: vi = s->gids; L = s->n_sparse; break;
+    case 3: vi = s->triu_colptr; L = s->n + 1; break;
+    case 4: vi = s->triu_rowval; L = s->nnzT; break;
+    case 5: vi = s->colptr; L = s->n + 1; break;
+    case 6: vi = s->rowval; L = s->nnzS; break;
+    case 7: vi = s->mapped; L = s->nnzS; break;
+    case 8: vf = s->nzval_one; L = s->nnzAgg; break;
+    case 9: vf = s->nzval_two; L = s->nnzAgg; break;
+    default: return ERR_INVALID;
+  }
+  if (len) *len = L;
+  for (int64_t k = 0; k < (L < cap ? L : cap); k++) {
+    if (vi && out_i) out_i[k] = vi[k];
+    if (vf && out_f) out_f[k] = vf[k];
+  }
+  return OK;
+}
+
 /* norm(A::SymLowRankMatrix, p) src/structs.jl:61-82 */
 int32_t sdplr_oracle_symlowrank_norm(int64_t n, int64_t sc, const double* B, const double* D,
                                      int32_t p_is_inf, double* out) {

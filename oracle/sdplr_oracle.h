@@ -62,6 +62,11 @@ int32_t sdplr_oracle_get_dims(const sdplr_oracle_solver* s, int64_t* n, int64_t*
                               int64_t* h, int64_t* nnzT, int64_t* nnzS, int64_t* nnzAgg);
 
 int32_t sdplr_oracle_A(sdplr_oracle_solver* s, int32_t u_slot, int32_t v_slot, int32_t out_vec);
+int32_t sdplr_oracle_set_sparse_coo(sdplr_oracle_solver* s, int64_t index_base, int64_t n_sparse,
+                                    const int64_t* ent_ptr, const int64_t* I, const int64_t* J,
+                                    const double* V, const int64_t* global_inds);
+int32_t sdplr_oracle_get_layout(const sdplr_oracle_solver* s, int32_t which, int64_t* out_i, double* out_f,
+                                int64_t cap, int64_t* len);
 int32_t sdplr_oracle_At_preprocess(sdplr_oracle_solver* s);
 int32_t sdplr_oracle_At_left(sdplr_oracle_solver* s, int32_t y_slot, int32_t x_slot);
 int32_t sdplr_oracle_At_right(sdplr_oracle_solver* s, const double* x_host, double* y_host,

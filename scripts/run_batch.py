@@ -76,16 +76,22 @@ def main():
     assert all(e["problem"] == e0["problem"] and e["rank"] == e0["rank"] and e["ptol"] == e0["ptol"] for e in entries)
     graphs = [load_graph(e["graph"]) for e in entries]
     abi.device_synchronize()   # the HIP context (≈ 0.15 s, once per process) is created before the clock starts
+    # The reference's clock (`totaltime`, src/sdplr.jl:127-131,416) starts at the sdplr() call: the problem (C, As, b —
+    # exps/test.jl:166-176 builds it before) is an input; preprocessing, the solve and the dual bounds are inside.
+    tb0 = time.perf_counter()
+    mine = set(batch.assign(len(graphs), world)[rank])
+    datas = [builders[e0["problem"]](g) if k in mine else None for k, g in enumerate(graphs)]
+    build_s = time.perf_counter() - tb0
     t0 = time.perf_counter()
-    conc = int(os.environ.get("SDPLR_BATCH_CONCURRENCY", "8"))
+    conc = int(os.environ.get("SDPLR_BATCH_CONCURRENCY", "16"))
     tb = 1.0 if e0["problem"] == "LovaszTheta" else float(max(g.shape[0] for g in graphs))     # exps/test.jl:166-176
-    local = batch.solve_local(graphs, rank, world, e0["rank"], concurrency=conc, make_data=builders[e0["problem"]],
+    local = batch.solve_local(datas, rank, world, e0["rank"], concurrency=conc,
                               ptol=e0["ptol"], objtol=e0["objtol"], seed=e0["seed"], prior_trace_bound=tb)
     res = batch.gather(local, len(graphs), dist, device)
     dt = time.perf_counter() - t0
     if rank == 0:
-        print(json.dumps({"instances": len(graphs), "n_gpus": world, "wall_s": dt,
-                          "instances_per_s": len(graphs) / dt,
+        print(json.dumps({"instances": len(graphs), "n_gpus": world, "wall_s": dt, "problem_build_s": build_s,
+                          "in_flight_per_gpu": conc, "instances_per_s": len(graphs) / dt,
                           "objectives": [round(x, 4) for x in res[:, 1]],
                           "dual_bounds": [round(x, 4) for x in res[:, 2]],
                           "iterations": [int(x) for x in res[:, 3]]}))

@@ -7,7 +7,7 @@ import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc", "sdplr_hip.hip")
-DEPS = [os.path.join(HERE, "csrc", f) for f in ("common.h", "k_dense.h", "k_sparse.h", "k_scalar.h", "k_eig.h")]
+DEPS = [os.path.join(HERE, "csrc", f) for f in ("common.h", "k_dense.h", "k_sparse.h", "k_scalar.h", "k_eig.h", "k_resident.h")]
 DEPS.append(os.path.join(os.path.dirname(HERE), "include", "sdplr_hip.h"))
 OUT = os.path.join(HERE, "lib", "libsdplr_hip.so")
 
@@ -35,6 +35,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
            "-Wall", "-Wno-unused-function", "-o", OUT, SRC]
     if verbose:
         cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
+    for flag in os.environ.get("SDPLR_HIP_EXTRA_CFLAGS", "").split():   # dev builds (-DSDPLR_RS_STAMPS, -DSDPLR_STAMPS …)
+        cmd.insert(1, flag)
     subprocess.check_call(cmd)
     return OUT
 

@@ -26,7 +26,8 @@ F_RT, F_GT, F_DIRT, F_LBFGS_S, F_LBFGS_Y, F_SCRATCH = 0, 1, 2, 100, 200, 300
 (V_LAMBDA, V_LAMBDA_UB, V_B, V_Y, V_PV_RAW, V_PV_LB, V_PV, V_A_RD, V_A_DD, V_LBFGS_RHO, V_LBFGS_A,
  V_UVT, V_TRIU_S_NZVAL, V_S_NZVAL, V_SCRATCH) = range(15)
 STAT_NAMES = ("graph_captures", "graph_capture_failures", "graph_capture_skipped", "graph_batches",
-              "eager_batches", "lanczos_graph_replays", "lanczos_eager_rounds", "inner_iterations")
+              "eager_batches", "lanczos_graph_replays", "lanczos_eager_rounds", "inner_iterations",
+              "resident_loops", "resident_lanczos", "resident_fg")
 S_SIGMA, S_OBJ, S_LBFGS_LATEST = 0, 1, 2
 
 _i32, _i64, _f64, _vp = C.c_int32, C.c_int64, C.c_double, C.c_void_p
@@ -43,6 +44,8 @@ SIGNATURES = {
     "create": [_i64, _i64, _i64, _i64, C.POINTER(_vp)],
     "set_sparse": [_vp, _i64, _i64, _pi64, _pi64, _pf64, _pf64, _pi64, _i64, _pi64, _pi64, _i64,
                    _pi64, _pi64, _pi64],
+    "set_sparse_coo": [_vp, _i64, _i64, _pi64, _pi64, _pi64, _pf64, _pi64],
+    "get_layout": [_vp, _i32, _pi64, _pf64, _i64, _pi64],
     "add_symlowrank": [_vp, _i64, _i64, _i64, _pf64, _pf64],
     "finalize": [_vp],
     "destroy": [_vp],
@@ -197,6 +200,30 @@ class DeviceSolver:
                                      _pd(a[2]), _pd(a[3]), _pl(a[4]), int(a[6].size), _pl(a[5]),
                                      _pl(a[6]), int(a[8].size), _pl(a[7]), _pl(a[8]), _pl(a[9])))
 
+    def set_sparse_coo(self, batch, index_base: int = 0):
+        """preprocess_sparsecons (src/preprocess.jl:24-169) inside the library, from the batched COO form of the sparse
+        matrices (``structs.SparseBatch``: findnz order, both triangles)."""
+        a = [_i64c(batch.ent_ptr), _i64c(batch.I), _i64c(batch.J), _f64c(batch.V), _i64c(batch.global_inds)]
+        self._ck(self.abi.set_sparse_coo(self._h, index_base, int(batch.n_matrices), _pl(a[0]), _pl(a[1]), _pl(a[2]),
+                                         _pd(a[3]), _pl(a[4])))
+
+    def get_layout(self):
+        """The aggregated layout the library holds between set_sparse[_coo] and finalize → AggregatedLayout (0-based)."""
+        from .preprocess import AggregatedLayout
+        out = []
+        for which in range(10):
+            L = C.c_int64(0)
+            self._ck(self.abi.get_layout(self._h, which, None, None, 0, C.byref(L)))
+            if which < 8:
+                buf = np.zeros(max(L.value, 1), dtype=np.int64)
+                self._ck(self.abi.get_layout(self._h, which, _pl(buf), None, L.value, C.byref(L)))
+            else:
+                buf = np.zeros(max(L.value, 1), dtype=np.float64)
+                self._ck(self.abi.get_layout(self._h, which, None, _pd(buf), L.value, C.byref(L)))
+            out.append(buf[: L.value])
+        matptr, nzind, gids, tcp, trv, fcp, frv, mapped, one, two = out
+        return AggregatedLayout(self.n, int(gids.size), matptr, nzind, one, two, gids, tcp, trv, fcp, frv, mapped)
+
     def add_symlowrank(self, global_ind: int, A, index_base: int = 0):
         B = np.asfortranarray(A.B, dtype=np.float64)  # n×s column-major
         D = _f64c(A.D)
@@ -321,9 +348,9 @@ class DeviceSolver:
 
     def stats(self) -> dict:
         """Library counters (include/sdplr_hip.h, sdplr_hip_get_stats)."""
-        out = (C.c_int64 * 8)()
+        out = (C.c_int64 * len(STAT_NAMES))()
         k = C.c_int32(0)
-        self._ck(self.abi.get_stats(self._h, out, 8, C.byref(k)))
+        self._ck(self.abi.get_stats(self._h, out, len(STAT_NAMES), C.byref(k)))
         return {STAT_NAMES[i]: int(out[i]) for i in range(k.value)}
 
     def f(self) -> float:

@@ -1,0 +1,1077 @@
+// k_resident.h — the RESIDENT route for small instances (BASELINE config 5: n = 800, rank 10 MaxCut, the
+// reference's own batch protocol, exps/batch_test.txt:1-9).
+//
+// On an instance whose factor is a few tens of KB every kernel of the multi-launch routes is a launch seam: ten
+// launches of ≈ 4.5 µs per inner iteration with 255 of 256 CUs idle.  Here ONE workgroup owns the instance for a whole
+// call of the inner `while` (src/sdplr.jl:190-278): one launch runs up to max_iters iterations, every exit test is
+// taken on the device, and the host reads the control block once at the end.  A batch of instances is then a set of
+// independent single-CU launches on their own streams — 64 instances occupy 64 CUs at the same time.
+//
+//   * the direction D lives in LDS (n·r doubles — the SpMM W = A_g·D gathers ≈ 48 rows of it per row at LDS speed);
+//     R, G, P, W and the 2h history arrays stay in global memory, which for ≤ 1 MB of state means the XCD's L2;
+//   * the SpMM runs one ROW PER LANE over a sliced-ELL copy of A_g (RsEll: 64 rows per slice, entry k of the 64 rows in
+//     one 256-byte line, 4 bytes per entry): per entry a lane issues one coalesced load, the LDS reads of the gathered
+//     row and the multiply-adds — no index hand-offs, no row pointers.  (The first version gave a row to 8 lanes, as
+//     the multi-launch kernels do: every entry then cost a wave ≈ 15 instructions for 8 entries and a dependent global
+//     round trip per 32 — 137 µs of a 171 µs iteration on Gset G1.)  W is kept chunk-major inside this kernel
+//     (Wt[c][j]: chunk c of all rows contiguous) so that the row-per-lane writer and the lanes-per-row readers both
+//     touch whole lines;
+//   * per-row quantities (⟨R_j,D_j⟩, ‖D_j‖², the diagonal coefficient d_j of S) are LDS vectors; the data of the
+//     one singleton constraint attached to a row (λ, λ_ub, lb, primal_vio_raw, value) sit in the registers of the
+//     thread that owns the row for the whole call;
+//   * the control block is staged in LDS; thread 0 runs the same serial code as the seam kernel (k_dense.h:
+//     seam_serial[_small]) and the scalar stage of the exact line search (k_scalar.h: quartic_argmin);
+//   * all sums are formed in a fixed order (lane → wave → block): two runs are bit-identical.
+//
+// Applies to the singleton form of the structured fast path (k_sparse.h) without low-rank matrices and with at most one
+// singleton constraint per row (MaxCut, CutNorm): S(y) = y_g·A_g + Diag(d(y)).  Phases of one iteration, separated by
+// workgroup barriers (reference lines as in DESIGN.md §1):
+//   SEAM   fold Gram sums / norms, loop tests, two-loop coefficients, descent test        lbfgs.jl:93-113, sdplr.jl:190,201-202,224-241,272-277
+//   DIR    D = ∓(G − Σ α_l y_l + Σ γ_l s_l)  → LDS                                         lbfgs.jl:77-120, sdplr.jl:203-204
+//   SPMM   W = A_g·D, ⟨R_j,D_j⟩, ‖D_j‖², partials of ⟨R,W⟩, ⟨D,W⟩                           coreop.jl:153-203, linesearch.jl:10-16
+//   LSSUM  the eight line-search sums over the row-attached constraints                   linesearch.jl:36-56
+//   SOLVE  quartic, α*, ℒ(α*), relative-decrease test, commit of A_g's slot               linesearch.jl:58-124, sdplr.jl:238
+//   COMMIT primal_vio_raw, primal_vio, y of the row-attached constraints, d_j              linesearch.jl:118-124, coreop.jl:229-236
+//   STEP   R += αD, P += αW, G = 2(y_g·P + d∘R), ‖G‖², lbfgs_update! with its Gram dots      sdplr.jl:219-234, lbfgs.jl:129-149
+//
+// k_rs_lanczos is the same idea for approx_mineigval_lanczos (src/coreop.jl:461-500): the three Lanczos vectors live
+// in LDS, one launch runs all q steps on the assembled S.
+#pragma once
+#include "common.h"
+#include "k_dense.h"
+#include "k_scalar.h"
+#include "k_sparse.h"
+
+#ifndef SDPLR_RS_NT
+#define SDPLR_RS_NT 512        /* threads of the resident workgroup (8 waves: 256 VGPRs per lane) */
+#endif
+#define SDPLR_RS_NW (SDPLR_RS_NT / 64)
+#define SDPLR_RS_RPT 2         /* rows whose constraint data a thread keeps in registers (n ≤ RPT·NT) */
+#ifndef SDPLR_RS_ELL_PF
+#define SDPLR_RS_ELL_PF 8      /* entries of a row in flight per lane in the SpMM (a register ring) */
+#endif
+
+
+// sums of K values over the workgroup, delivered to thread 0 only (fixed order: lanes by DPP, then waves 0..NW−1)
+template <int K>
+__device__ __forceinline__ void rs_sum_to0(double (&v)[K], double* sh) {
+  const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+#pragma unroll
+  for (int k = 0; k < K; k++) v[k] = wave_sum(v[k]);
+  __syncthreads();
+  if (l == 0) {
+#pragma unroll
+    for (int k = 0; k < K; k++) sh[k * SDPLR_RS_NW + w] = v[k];
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+      double t = 0.0;
+#pragma unroll
+      for (int i = 0; i < SDPLR_RS_NW; i++) t += sh[k * SDPLR_RS_NW + i];
+      v[k] = t;
+    }
+  }
+}
+
+// A_g for the resident route: sliced ELL, one row per lane.  Rows are taken in order of decreasing off-diagonal count
+// (perm), 64 rows per slice; entry k of a slice's 64 rows is one contiguous 256-byte line: the k-th off-diagonal entry
+// of each row in ascending column order: its column, and its value in `val` unless all off-diagonal entries of A_g share
+// ONE value (unit-weight graphs: 4 bytes per entry instead of 12).  The diagonal of A_g is a vector of its own.
+// (A palette of ≤ 255 values looked up in LDS per entry was tried for the weighted case: the look-ups in front of the
+// gathers made the compiler keep every entry of the register ring's trip in flight — 256 VGPRs and scratch.)
+struct RsEll {
+  int n_slices;
+  const int* perm;        // [64·n_slices] row of (slice, lane), −1 past the end
+  const int* len;         // [64·n_slices] its number of off-diagonal entries
+  const int* sptr;        // [n_slices + 1] first 64-entry line of each slice
+  const unsigned* ent;    // [64·sptr[n_slices]]
+  const double* val;      // same shape, or null: every off-diagonal entry has the value `one`
+  double one;
+  const double* gdiag;    // [n]
+};
+
+// NCH chunks (VEC doubles each, from chunk c0) of Y_j = Σ_k a_jk·X_k for the 64 rows of one slice, X in LDS (row-major):
+// the products of a row are summed by increasing column, the diagonal last.  MODE 0: one off-diagonal value, 2: value
+// array.  Lanes whose row is shorter than the slice's longest multiply row 0 by zero.
+template <int VEC, int MODE, int NCH>
+__device__ __forceinline__ void rs_ell_pass(const unsigned* __restrict__ ep, const double* __restrict__ vp, int width, int len,
+                                            double one, const double* Xl, int r, int c0, int j, double gd,
+                                            vecd<VEC> (&w)[NCH]) {
+#pragma unroll
+  for (int c = 0; c < NCH; c++)
+#pragma unroll
+    for (int q = 0; q < VEC; q++) w[c].v[q] = 0.0;
+  // A lane's entries come in through a register ring of PF lines: the loads of the next PF entries are issued before
+  // the current PF are consumed (the compiler does not pipeline the loop by itself: with two entries per trip the
+  // SpMM of Gset G1 waited 215 k cycles per iteration on ≈ 40 dependent round trips per wave).
+  constexpr int PF = SDPLR_RS_ELL_PF;
+  unsigned er[PF];
+  double vr[MODE == 2 ? PF : 1];
+#pragma unroll
+  for (int q = 0; q < PF; q++) {
+    const int kc = min(q, width - 1);
+    er[q] = ep[(size_t)kc * 64];
+    if (MODE == 2) vr[q] = vp[(size_t)kc * 64];
+  }
+#pragma nounroll
+  for (int k0 = 0; k0 < width; k0 += PF) {
+    unsigned ec[PF];
+    double vc[MODE == 2 ? PF : 1];
+#pragma unroll
+    for (int q = 0; q < PF; q++) {
+      ec[q] = er[q];
+      if (MODE == 2) vc[q] = vr[q];
+    }
+#pragma unroll
+    for (int q = 0; q < PF; q++) {   // (clamped: the last trip re-reads the slice's last line)
+      const int kc = min(k0 + PF + q, width - 1);
+      er[q] = ep[(size_t)kc * 64];
+      if (MODE == 2) vr[q] = vp[(size_t)kc * 64];
+    }
+#pragma unroll
+    for (int q = 0; q < PF; q++) {
+      const int k = k0 + q;
+      const bool on = k < len;     // (len ≤ width: also false past the slice's end)
+      const unsigned e = ec[q];
+      const int col = on ? (int)(e & 0xFFFFu) : 0;
+      double v;
+      if (MODE == 0) v = on ? one : 0.0;
+      else v = on ? vc[q] : 0.0;
+      const double* xr = Xl + (long long)col * r + c0 * VEC;
+#pragma unroll
+      for (int c = 0; c < NCH; c++) {
+        const vecd<VEC> x = ldrow<VEC>(xr + c * VEC);
+#pragma unroll
+        for (int qq = 0; qq < VEC; qq++) w[c].v[qq] += x.v[qq] * v;
+      }
+      // (entries are consumed two at a time: left to itself the scheduler hoists the LDS reads of all PF entries —
+      // PF·NCH·VEC doubles of registers — and the kernel spills)
+      if (q & 1) __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  const double* xj = Xl + (long long)j * r + c0 * VEC;
+#pragma unroll
+  for (int c = 0; c < NCH; c++) {
+    const vecd<VEC> x = ldrow<VEC>(xj + c * VEC);
+#pragma unroll
+    for (int q = 0; q < VEC; q++) w[c].v[q] += x.v[q] * gd;
+  }
+}
+// Y = X·A_g for all rows, chunks [c0, c0 + NCH): one slice per wave and trip.  TO_P: Y row-major (P = A_g·R, strided
+// 16-byte stores — once per call at most); otherwise chunk-major (Wt[(c·n + j)·VEC]: chunk c of the 64 rows of a wave is a
+// few whole lines).
+template <int VEC, int MODE, bool TO_P, int NCH>
+__device__ __forceinline__ void rs_ell_spmm_chunks(const RsEll& E, const double* Xl, int n, int r, int c0, double* out) {
+  const int wave = threadIdx.x >> 6, wl = threadIdx.x & 63;
+  const double one = E.one;
+#pragma nounroll
+  for (int sl = wave; sl < E.n_slices; sl += SDPLR_RS_NW) {
+    const int idx = sl * 64 + wl;
+    const int jp = E.perm[idx];
+    const int len = E.len[idx];
+    const int l0 = E.sptr[sl], width = E.sptr[sl + 1] - l0;
+    const unsigned* ep = E.ent + (size_t)l0 * 64 + wl;
+    const double* vp = (MODE == 2) ? E.val + (size_t)l0 * 64 + wl : nullptr;
+    const int j = max(jp, 0);
+    const double gd = (jp >= 0) ? E.gdiag[j] : 0.0;
+    vecd<VEC> w[NCH];
+    rs_ell_pass<VEC, MODE, NCH>(ep, vp, width, len, one, Xl, r, c0, j, gd, w);
+    if (jp >= 0) {
+#pragma unroll
+      for (int c = 0; c < NCH; c++) {
+        if (TO_P) strow<VEC>(out + (long long)j * r + (c0 + c) * VEC, w[c]);
+        else strow<VEC>(out + ((long long)(c0 + c) * n + j) * VEC, w[c]);
+      }
+    }
+  }
+}
+// (the dispatch on the number of chunks sits OUTSIDE the slice loop: with the switch inside it the compiler merged the
+// heads of all its cases and the kernel needed 256 VGPRs and scratch; each case by itself takes 56–101)
+template <int VEC, int MODE, bool TO_P>
+__device__ __forceinline__ void rs_ell_spmm(const RsEll& E, const double* Xl, int n, int r, double* out) {
+  const int NC = r / VEC;   // (VEC = 2 only for even r)
+#pragma nounroll
+  for (int c0 = 0; c0 < NC; c0 += 8) {
+    switch (min(NC - c0, 8)) {
+      case 1: rs_ell_spmm_chunks<VEC, MODE, TO_P, 1>(E, Xl, n, r, c0, out); break;
+      case 2: rs_ell_spmm_chunks<VEC, MODE, TO_P, 2>(E, Xl, n, r, c0, out); break;
+      case 3: rs_ell_spmm_chunks<VEC, MODE, TO_P, 3>(E, Xl, n, r, c0, out); break;
+      case 4: rs_ell_spmm_chunks<VEC, MODE, TO_P, 4>(E, Xl, n, r, c0, out); break;
+      case 5: rs_ell_spmm_chunks<VEC, MODE, TO_P, 5>(E, Xl, n, r, c0, out); break;
+      case 6: rs_ell_spmm_chunks<VEC, MODE, TO_P, 6>(E, Xl, n, r, c0, out); break;
+      case 7: rs_ell_spmm_chunks<VEC, MODE, TO_P, 7>(E, Xl, n, r, c0, out); break;
+      default: rs_ell_spmm_chunks<VEC, MODE, TO_P, 8>(E, Xl, n, r, c0, out); break;
+    }
+  }
+}
+template <int VEC, bool TO_P>
+__device__ __forceinline__ void rs_ell_spmm_any(const RsEll& E, const double* Xl, int n, int r, double* out) {
+  if (E.val == nullptr) rs_ell_spmm<VEC, 0, TO_P>(E, Xl, n, r, out);
+  else rs_ell_spmm<VEC, 2, TO_P>(E, Xl, n, r, out);
+}
+
+struct RsLoopArgs {
+  int n, m, r, h;
+  int gid_g;                            // slot of A_g in the (m+1)-vectors
+  const int* row_k;                     // [n] the one singleton constraint attached to row j (−1: none) …
+  const double* row_v;                  // [n] … and its value
+  RsEll E;                              // A_g
+  FactorArena A;                        // R, G, D, s_*, y_*
+  double *P, *W;
+  double *y, *pv_raw, *pv, *A_RD, *A_DD;
+  const double *lam, *lam_ub, *lb;
+  DevCtrl* c;
+  int refresh_P;                        // P = A_g·R from scratch before the first iteration
+  long long budget_ticks;               // wall_clock64() ticks this call may run (≤ 0: no limit), src/sdplr.jl:272-277
+};
+
+// constraint data of the rows a thread owns (row j = tid + q·NT): registers for q < RPT, global memory beyond
+struct RsRow {
+  int k;
+  double v, lam, lub, lb, pvr;
+};
+__device__ __forceinline__ RsRow rs_load_row(const RsLoopArgs& a, int j) {
+  RsRow o;
+  o.k = a.row_k[j];
+  o.v = a.row_v[j];
+  const int kc = (o.k >= 0 && o.k < a.m) ? o.k : 0;
+  const bool has = o.k >= 0 && o.k < a.m && a.m > 0;
+  o.lam = has ? a.lam[kc] : 0.0;
+  o.lub = has ? a.lam_ub[kc] : 0.0;
+  o.lb = has ? a.lb[kc] : 0.0;
+  o.pvr = (o.k >= 0) ? a.pv_raw[o.k] : 0.0;
+  return o;
+}
+
+template <int LPR, int VEC, int HM>
+__global__ void __launch_bounds__(SDPLR_RS_NT)
+k_rs_loop(RsLoopArgs a) {
+  extern __shared__ __attribute__((aligned(16))) double rs_lds[];   // (16-byte LDS reads: an 8-byte-aligned base behind the static LDS made every ds_read_b128 a misaligned access — 5× slower)
+  __shared__ SeamLds gd;
+  __shared__ double sred[(5 * HM + 2 > 10 ? 5 * HM + 2 : 10) * SDPLR_RS_NW];
+  __shared__ double sh_alpha, sh_yg, sh_p1, sh_p2;
+  __shared__ int sh_err, sh_upd;
+  static_assert(sizeof(SeamLds) + sizeof(double) * ((5 * HM + 2 > 10 ? 5 * HM + 2 : 10) * SDPLR_RS_NW + 8) <= 10 * 1024,
+                "static LDS of the resident loop: the host budgets 150 KB of dynamic LDS next to it");
+  constexpr int NT = SDPLR_RS_NT, G = NT / LPR;
+  const int tid0 = threadIdx.x;
+  int tid = tid0, grp = tid / LPR, lane = tid % LPR;
+  const int n = a.n, m = a.m, r = a.r, h = a.h;
+  const long long N = (long long)n * r;
+  const long long Npad = (N + 1) & ~1LL;
+  double* Dl = rs_lds;                 // [Npad] the direction (or R while P is being refreshed)
+  double* rdl = Dl + Npad;             // [n] ⟨R_j, D_j⟩
+  double* ddl = rdl + n;               // [n] ‖D_j‖²
+  double* djl = ddl + n;               // [n] d_j = v_j·y[k_j]
+  int ch0 = lane * VEC;
+  bool act = ch0 < r;
+  double* const R = aslot(a.A, AS_R);
+  double* const Gm = aslot(a.A, AS_G);
+  // the control block → LDS (one coalesced load)
+  for (int t = tid; t < (int)(sizeof(DevCtrl) / 8); t += NT)
+    reinterpret_cast<unsigned long long*>(&gd.c)[t] = reinterpret_cast<const unsigned long long*>(a.c)[t];
+  const long long t_start = (long long)wall_clock64();
+  // constraint data of this thread's rows: constant over the call except primal_vio_raw, which the thread owns
+  RsRow rw_[SDPLR_RS_RPT];
+#pragma unroll
+  for (int q = 0; q < SDPLR_RS_RPT; q++) {
+    const int j = tid + q * NT;
+    if (j < n) rw_[q] = rs_load_row(a, j);
+    else { rw_[q].k = -1; rw_[q].v = rw_[q].lam = rw_[q].lub = rw_[q].lb = rw_[q].pvr = 0.0; }
+  }
+  if (a.refresh_P) {   // P = A_g·R (entry of the loop: R was written outside, or the incremental P is due for a refresh)
+    for (long long e = tid; e < N; e += NT) Dl[e] = R[e];
+    __syncthreads();
+    rs_ell_spmm_any<VEC, true>(a.E, Dl, n, r, a.P);
+  }
+  __syncthreads();
+  bool have_upd = false, have_norms = false;
+  bool dir_ran = false;
+#ifdef SDPLR_RS_STAMPS
+  unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_last = __builtin_amdgcn_s_memtime();
+#define RS_STAMP(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); stamp_acc[i] += t_ - stamp_last; stamp_last = t_; } while (0)
+#else
+#define RS_STAMP(i) do { } while (0)
+#endif
+  for (;;) {
+    // (opaque to the optimiser: per-thread addresses are re-derived in every iteration instead of being hoisted out
+    // of the persistent loop, where two dozen 64-bit address pairs would stay live across all phases — 256 VGPRs and
+    // 116 bytes of scratch per lane without this, 217 and none with it)
+    tid = tid0;
+    asm volatile("" : "+v"(tid));
+    grp = tid / LPR;
+    lane = tid % LPR;
+    ch0 = lane * VEC;
+    act = ch0 < r;
+    // ================= SEAM =================
+    // (the Gram sums and the norms of the iteration that just ended were folded into gd.red / gd.nrm by STEP)
+    if (tid == 0) {
+      switch (h) {
+        case 1: seam_serial_small<1>(gd, 0, 1, 1, 1, have_upd, have_norms, 1); break;
+        case 2: seam_serial_small<2>(gd, 0, 1, 1, 1, have_upd, have_norms, 1); break;
+        case 3: seam_serial_small<3>(gd, 0, 1, 1, 1, have_upd, have_norms, 1); break;
+        case 4: seam_serial_small<4>(gd, 0, 1, 1, 1, have_upd, have_norms, 1); break;
+        default: seam_serial(gd, h, 0, 1, 1, 1, have_upd, have_norms, 1);
+      }
+      // time budget (src/sdplr.jl:272-277): tested where the iteration budget is; the device's own exits win
+      if (!gd.c.done && a.budget_ticks > 0 && (long long)wall_clock64() - t_start > a.budget_ticks) {
+        gd.c.iters -= 1;
+        gd.c.done = 1;
+        gd.c.exit_reason = EXIT_TIME;
+      }
+    }
+    __syncthreads();
+    RS_STAMP(0);
+    if (gd.c.done) break;
+    // ================= DIR =================
+    const int latest = gd.c.latest;
+    const int fb = gd.c.fallback;
+    const int jslot = latest % h;
+    {
+      double ca[HM], cg[HM];
+      const double* yp[HM];
+      const double* sp_[HM];
+      int j = latest - 1;
+#pragma unroll
+      for (int i = 0; i < HM; i++) {
+        const int slot = (i < h) ? j : 0;
+        ca[i] = (i < h) ? gd.c.c_alpha[slot] : 0.0;
+        cg[i] = (i < h) ? gd.c.c_gamma[slot] : 0.0;
+        yp[i] = aslot(a.A, as_y0(a.A) + slot);
+        sp_[i] = aslot(a.A, AS_S0 + slot);
+        j = (j <= 0) ? h - 1 : j - 1;
+      }
+      dir_ran = true;
+#pragma unroll 2
+      for (long long e = tid; e < N; e += NT) {
+        const double g = Gm[e];
+        double yv[HM], sv[HM];
+#pragma unroll
+        for (int k = 0; k < HM; k++) {
+          yv[k] = yp[k][e];
+          sv[k] = sp_[k][e];
+        }
+        double rr = g;
+#pragma unroll
+        for (int k = 0; k < HM; k++) rr -= ca[k] * yv[k];          // newest → oldest (lbfgs.jl:94-102)
+#pragma unroll
+        for (int k = HM - 1; k >= 0; k--) rr += cg[k] * sv[k];     // oldest → newest (:104-113)
+        double d = -rr;                                            // (:116-118)
+        if (fb) {                                                  // src/sdplr.jl:202-205
+          d = -g;
+          Gm[e] = d;
+        }
+        Dl[e] = d;
+      }
+    }
+    __syncthreads();
+    RS_STAMP(1);
+    // ================= SPMM =================
+    rs_ell_spmm_any<VEC, false>(a.E, Dl, n, r, a.W);     // Wt = A_g·D, one row per lane
+    __syncthreads();
+    RS_STAMP(7);
+    // row dots, LPR lanes per row: ⟨R_j,D_j⟩, ‖D_j‖², partials of ⟨R,W⟩ (= ⟨P,D⟩: A_g symmetric) and ⟨D,W⟩
+    double acc[10];
+#pragma unroll
+    for (int k = 0; k < 10; k++) acc[k] = 0.0;
+    // (four rows per group and trip: twelve independent loads in flight per lane instead of a round trip per row)
+#pragma nounroll
+    for (int j0 = grp; j0 < n; j0 += 4 * G) {
+      vecd<VEC> xr[4], xd[4], w[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int j = min(j0 + u * G, n - 1);
+#pragma unroll
+        for (int k = 0; k < VEC; k++) xr[u].v[k] = xd[u].v[k] = w[u].v[k] = 0.0;
+        if (act) {
+          xr[u] = ldrow<VEC>(R + (long long)j * r + ch0);
+          xd[u] = ldrow<VEC>(Dl + (long long)j * r + ch0);
+          w[u] = ldrow<VEC>(a.W + ((long long)lane * n + j) * VEC);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int j = j0 + u * G;
+        const bool ok = j < n;    // (group-uniform)
+        double rd = 0.0, dd = 0.0;
+#pragma unroll
+        for (int k = 0; k < VEC; k++) {
+          rd += xr[u].v[k] * xd[u].v[k];
+          dd += xd[u].v[k] * xd[u].v[k];
+          if (ok) {
+            acc[8] += xr[u].v[k] * w[u].v[k];
+            acc[9] += xd[u].v[k] * w[u].v[k];
+          }
+        }
+        rd = group_sum<LPR>(rd);
+        dd = group_sum<LPR>(dd);
+        if (lane == 0 && ok) {
+          rdl[j] = rd;
+          ddl[j] = dd;
+        }
+      }
+    }
+    __syncthreads();
+    RS_STAMP(2);
+    // ================= LSSUM =================
+    {
+      const double sigma = gd.c.sigma;
+      auto ls_row = [&](int j, const RsRow& rw) {
+        if (rw.k < 0) return;
+        const double rd = rdl[j], dd = ddl[j];
+        const double q1 = rw.v * (rd + rd), q2 = rw.v * dd;
+        a.A_RD[rw.k] = q1;
+        a.A_DD[rw.k] = q2;
+        if (rw.k < m) {
+          const double l = rw.lam, nq0 = rw.pvr;
+          acc[0] += l * nq0;
+          acc[1] += nq0 * nq0;
+          acc[2] += l * q1;
+          acc[3] += nq0 * q1;
+          acc[4] += (l - sigma * nq0) * q2;
+          acc[5] += q1 * q1;
+          acc[6] += q1 * q2;
+          acc[7] += q2 * q2;
+        } else {          // the cost slot attached to a row
+          sh_p1 = q1;
+          sh_p2 = q2;
+        }
+      };
+#pragma unroll
+      for (int q = 0; q < SDPLR_RS_RPT; q++)
+        if (tid + q * NT < n) ls_row(tid + q * NT, rw_[q]);
+      for (int j = tid + SDPLR_RS_RPT * NT; j < n; j += NT) ls_row(j, rs_load_row(a, j));
+    }
+    rs_sum_to0<10>(acc, sred);
+    RS_STAMP(3);
+    // ================= SOLVE =================
+    if (tid == 0) {
+      DevCtrl& c = gd.c;
+      const double sigma = c.sigma;
+      const int kg = a.gid_g;
+      const double g_rd = acc[8] + acc[8], g_dd = acc[9];
+      a.A_RD[kg] = g_rd;   // ⟨A_g, RDᵀ+DRᵀ⟩ = 2⟨P, D⟩
+      a.A_DD[kg] = g_dd;   // ⟨A_g, DDᵀ⟩ = ⟨D, W⟩
+      double pvg = a.pv_raw[kg], lg = 0.0, lubg = 0.0, lbg = 0.0;
+      if (kg < m) {
+        lg = a.lam[kg];
+        lubg = a.lam_ub[kg];
+        lbg = a.lb[kg];
+        acc[0] += lg * pvg;
+        acc[1] += pvg * pvg;
+        acc[2] += lg * g_rd;
+        acc[3] += pvg * g_rd;
+        acc[4] += (lg - sigma * pvg) * g_dd;
+        acc[5] += g_rd * g_rd;
+        acc[6] += g_rd * g_dd;
+        acc[7] += g_dd * g_dd;
+      }
+      const double p0 = c.obj, p1 = (kg == m) ? g_rd : sh_p1, p2 = (kg == m) ? g_dd : sh_p2;
+      double bq[5];
+      bq[0] = p0 - acc[0] + sigma * acc[1] / 2;
+      bq[1] = p1 - acc[2] + sigma * acc[3];
+      bq[2] = p2 - acc[4] + sigma * acc[5] / 2;
+      bq[3] = sigma * acc[6];
+      bq[4] = sigma * acc[7] / 2;
+      for (int k = 0; k < 5; k++) c.biquad[k] = bq[k];
+      double al = 0.0, f = bq[0];
+      const int rc = quartic_argmin(bq, c.alpha_max, &al, &f);
+      sh_err = rc;
+      sh_alpha = al;
+      if (rc != 0) {
+        c.err = rc;
+        c.done = 1;
+      } else {
+        c.alpha = al;
+        c.L = f;
+        const double last = c.lastval;
+        const double rel_delta = (last - f) / fmax(1.0, fmax(fabs(f), fabs(last)));
+        c.reldelta_exit = (rel_delta < c.fprec_eps) ? 1 : 0;
+        sh_upd = c.reldelta_exit ? 0 : 1;
+        // commit of A_g's slot (src/linesearch.jl:118-124, src/coreop.jl:229-236)
+        const double v = pvg + al * (al * g_dd + g_rd);
+        a.pv_raw[kg] = v;
+        double yk = 1.0, pv2 = 0.0;
+        if (kg == m) {
+          c.obj = v;
+        } else {
+          const double pc = fmax(v, lbg);
+          a.pv[kg] = pc;
+          pv2 = pc * pc;
+          yk = -fmin(lubg, lg - sigma * v);
+        }
+        a.y[kg] = yk;
+        sh_yg = yk;
+        c.pv2_extra = pv2;
+      }
+    }
+    __syncthreads();
+    RS_STAMP(4);
+    if (sh_err != 0) break;
+    const double al = sh_alpha, yg = sh_yg;
+    const bool upd = sh_upd != 0;
+    // ================= COMMIT =================
+    double red[5 * HM + 2];   // Gram sums of lbfgs_update!, then ‖G‖², ‖pv‖²
+#pragma unroll
+    for (int k = 0; k < 5 * HM + 2; k++) red[k] = 0.0;
+    double* const gram = red;
+    double* const nrm = red + 5 * HM;
+    {
+      const double sigma = gd.c.sigma;
+      auto commit_row = [&](int j, RsRow& rw) {
+        double dj = 0.0;
+        if (rw.k >= 0) {
+          const double rd = rdl[j], dd = ddl[j];
+          const double q1 = rw.v * (rd + rd), q2 = rw.v * dd;
+          const double v = rw.pvr + al * (al * q2 + q1);     // src/linesearch.jl:118
+          rw.pvr = v;
+          a.pv_raw[rw.k] = v;
+          double yk;
+          if (rw.k < m) {
+            yk = -fmin(rw.lub, rw.lam - sigma * v);           // src/coreop.jl:233
+            const double pc = fmax(v, rw.lb);                 // src/linesearch.jl:122-124
+            a.pv[rw.k] = pc;
+            nrm[1] += pc * pc;
+          } else {
+            yk = 1.0;                                         // the cost slot, src/coreop.jl:235
+            gd.c.obj = v;
+          }
+          a.y[rw.k] = yk;
+          dj = rw.v * yk;
+        }
+        djl[j] = dj;
+      };
+#pragma unroll
+      for (int q = 0; q < SDPLR_RS_RPT; q++)
+        if (tid + q * NT < n) commit_row(tid + q * NT, rw_[q]);
+      for (int j = tid + SDPLR_RS_RPT * NT; j < n; j += NT) {
+        RsRow rw = rs_load_row(a, j);
+        commit_row(j, rw);
+      }
+    }
+    __syncthreads();
+    RS_STAMP(5);
+    // ================= STEP =================
+    {
+      // y_j = G_new − G_old: G_old is still in the G array (sign-flipped if the fallback negated it)
+      const double gs = fb ? 1.0 : -1.0;
+      double* const Sj = aslot(a.A, AS_S0 + jslot);
+      double* const Yj = aslot(a.A, as_y0(a.A) + jslot);
+      const double* slp[HM];
+      const double* ylp[HM];
+#pragma unroll
+      for (int l = 0; l < HM; l++) {
+        slp[l] = aslot(a.A, AS_S0 + ((l < h) ? l : 0));
+        ylp[l] = aslot(a.A, as_y0(a.A) + ((l < h) ? l : 0));
+      }
+      if (act) {
+#pragma nounroll
+        for (int j = grp; j < n; j += G) {
+          const long long e = (long long)j * r + ch0;
+          const vecd<VEC> x0 = ldrow<VEC>(R + e), p0 = ldrow<VEC>(a.P + e), gold = ldrow<VEC>(Gm + e);
+          const vecd<VEC> w = ldrow<VEC>(a.W + ((long long)lane * n + j) * VEC);
+          const vecd<VEC> d = ldrow<VEC>(Dl + e);
+          vecd<VEC> sv[HM], yv[HM];
+          if (upd) {
+#pragma unroll
+            for (int l = 0; l < HM; l++) {
+              sv[l] = ldrow<VEC>(slp[l] + e);
+              yv[l] = ldrow<VEC>(ylp[l] + e);
+            }
+          }
+          const double dj = djl[j];
+          vecd<VEC> x, pp, g;
+#pragma unroll
+          for (int q = 0; q < VEC; q++) {
+            x.v[q] = x0.v[q] + al * d.v[q];                 // src/sdplr.jl:219
+            pp.v[q] = p0.v[q] + al * w.v[q];
+            g.v[q] = pp.v[q] * yg + x.v[q] * dj;
+            g.v[q] *= 2.0;                                  // src/coreop.jl:315
+            nrm[0] += g.v[q] * g.v[q];
+          }
+          strow<VEC>(R + e, x);
+          strow<VEC>(a.P + e, pp);
+          strow<VEC>(Gm + e, g);
+          if (!upd) {   // relative-decrease exit: no update, y_next = −G_old as lbfgs_dir! leaves it (lbfgs.jl:121-123)
+            vecd<VEC> go;
+#pragma unroll
+            for (int q = 0; q < VEC; q++) go.v[q] = gs * gold.v[q];
+            strow<VEC>(Yj + e, go);
+          } else {
+            vecd<VEC> sn, yn;
+#pragma unroll
+            for (int q = 0; q < VEC; q++) {
+              sn.v[q] = al * d.v[q];                        // BLAS.scal!(stepsize, dir)  (lbfgs.jl:142)
+              yn.v[q] = gs * gold.v[q] + g.v[q];            // y_j = −G_old + G_new  (:122,145)
+            }
+            strow<VEC>(Sj + e, sn);                         // copy!(s_j, dir)  (:143)
+            strow<VEC>(Yj + e, yn);
+#pragma unroll
+            for (int l = 0; l < HM; l++)
+              if (l < h) {
+                const vecd<VEC> sl = (l == jslot) ? sn : sv[l];
+                const vecd<VEC> yl = (l == jslot) ? yn : yv[l];
+#pragma unroll
+                for (int q = 0; q < VEC; q++) {
+                  gram[0 * HM + l] += sn.v[q] * yl.v[q];
+                  gram[1 * HM + l] += sl.v[q] * yn.v[q];
+                  gram[2 * HM + l] += yn.v[q] * yl.v[q];
+                  gram[3 * HM + l] += sl.v[q] * g.v[q];
+                  gram[4 * HM + l] += yl.v[q] * g.v[q];
+                }
+              }
+          }
+        }
+      }
+    }
+    rs_sum_to0<5 * HM + 2>(red, sred);
+    if (tid == 0) {
+#pragma unroll
+      for (int q = 0; q < 5; q++)
+#pragma unroll
+        for (int l = 0; l < HM; l++) gd.red[q * SDPLR_HMAX + l] = red[q * HM + l];
+      gd.nrm[0] = red[5 * HM];
+      gd.nrm[1] = red[5 * HM + 1];
+    }
+    have_upd = upd;
+    have_norms = true;
+    __syncthreads();
+    RS_STAMP(6);
+  }
+#ifdef SDPLR_RS_STAMPS
+  if (tid0 == 0 && gd.c.iters > 20)
+    printf("[rs_loop] iters %lld  cycles/iter: seam %llu dir %llu spmm %llu rowdots %llu lssum %llu solve %llu commit %llu step %llu\n", gd.c.iters,
+           stamp_acc[0] / gd.c.iters, stamp_acc[1] / gd.c.iters, stamp_acc[7] / gd.c.iters, stamp_acc[2] / gd.c.iters, stamp_acc[3] / gd.c.iters,
+           stamp_acc[4] / gd.c.iters, stamp_acc[5] / gd.c.iters, stamp_acc[6] / gd.c.iters);
+#endif
+  // dirt as the last lbfgs_dir! left it (the host overwrites it with s_latest unless the loop left through the
+  // relative-decrease exit, which skips lbfgs_update!: sdplr_hip_inner_loop)
+  __syncthreads();
+  if (dir_ran) {
+    double* const Dg = aslot(a.A, AS_D);
+    for (long long e = tid; e < N; e += NT) Dg[e] = Dl[e];
+  }
+  // the control block goes back whole (done / exit_reason / iters / L / norms / Gram data / latest …)
+  if (tid == 0) {
+    gd.c.gram_pending = 0;
+    gd.c.norms_pending = 0;
+  }
+  __syncthreads();
+  for (int t = tid; t < (int)(sizeof(DevCtrl) / 8); t += NT)
+    reinterpret_cast<unsigned long long*>(a.c)[t] = reinterpret_cast<const unsigned long long*>(&gd.c)[t];
+}
+
+// ---- approx_mineigval_lanczos's recurrence (src/coreop.jl:473-500) in one launch -----------------------------------
+// v, v_pre, Av in LDS; S = the assembled full pattern (column j of the CSC = row j: S is symmetric) + the low-rank
+// terms y[gid]·D_c·B_c B_cᵀ.  The raw coefficients go to alpha_out / beta_out, the number of steps to c->lz_steps.
+struct RsLzArgs {
+  int n, q;
+  const int *colptr, *rowval;
+  const double* nzval;
+  DevLowRank lr;
+  const double* yvec;
+  const double* v0;
+  double *alpha_out, *beta_out;
+  DevCtrl* c;
+};
+#define SDPLR_RS_LZ_LPR 8
+__global__ void __launch_bounds__(SDPLR_RS_NT)
+k_rs_lanczos(RsLzArgs a) {
+  extern __shared__ __attribute__((aligned(16))) double rs_lds[];   // (16-byte LDS reads: an 8-byte-aligned base behind the static LDS made every ds_read_b128 a misaligned access — 5× slower)
+  __shared__ double sred[2 * SDPLR_RS_NW];
+  __shared__ double sh_s[2];
+  constexpr int NT = SDPLR_RS_NT, LPR = SDPLR_RS_LZ_LPR, G = NT / LPR;
+  const int tid = threadIdx.x, grp = tid / LPR, lane = tid % LPR;
+  const int n = a.n;
+  double* v = rs_lds;
+  double* vpre = v + n;
+  double* av = vpre + n;
+  auto bsum = [&](double x) -> double {   // block sum, every thread gets it (fixed order)
+    x = wave_sum(x);
+    __syncthreads();
+    if ((tid & 63) == 0) sred[tid >> 6] = x;
+    __syncthreads();
+    double t = 0.0;
+#pragma unroll
+    for (int i = 0; i < SDPLR_RS_NW; i++) t += sred[i];
+    return t;
+  };
+  {   // v = v0/‖v0‖  (:473-474)
+    double s = 0.0;
+    for (int i = tid; i < n; i += NT) {
+      const double x = a.v0[i];
+      v[i] = x;
+      vpre[i] = 0.0;
+      s += x * x;
+    }
+    const double nv = sqrt(bsum(s));
+    for (int i = tid; i < n; i += NT) v[i] = v[i] / nv;
+  }
+  __syncthreads();
+  double beta_prev = 0.0;
+  int steps = 0;
+  const double tiny = sqrt((double)n) * 2.220446049250313e-16;
+  for (int it = 0; it < a.q; it++) {
+    // low-rank coefficients y[gid]·D_c·⟨B_c, v⟩ (src/structs.jl:117-127)
+    double coef[SDPLR_LRMAX];
+#pragma unroll
+    for (int cc = 0; cc < SDPLR_LRMAX; cc++) {
+      coef[cc] = 0.0;
+      if (cc < a.lr.ST) {
+        double s = 0.0;
+        for (int i = tid; i < n; i += NT) s += a.lr.Bcat[(long long)cc * n + i] * v[i];
+        coef[cc] = a.yvec[a.lr.col_gid[cc]] * a.lr.Dcat[cc] * bsum(s);
+      }
+    }
+    // Av = S·v  (:483)
+    double dot = 0.0;
+    for (int j = grp; j < n; j += G) {
+      const int beg = a.colptr[j], end = a.colptr[j + 1];
+      double tj = 0.0;
+      for (int p = beg + lane; p < end; p += LPR) tj += a.nzval[p] * v[a.rowval[p]];
+      tj = group_sum<LPR>(tj);
+      if (lane == 0) {
+#pragma unroll
+        for (int cc = 0; cc < SDPLR_LRMAX; cc++)
+          if (cc < a.lr.ST) tj += coef[cc] * a.lr.Bcat[(long long)cc * n + j];
+        av[j] = tj;
+        dot += v[j] * tj;
+      }
+    }
+    const double al = bsum(dot);                                  // alpha[i] = v'·Av  (:484)
+    double nn = 0.0;
+    for (int i = tid; i < n; i += NT) {
+      double x = av[i];
+      if (it == 0) x -= al * v[i];                                // (:486-490)
+      else x -= al * v[i] + beta_prev * vpre[i];
+      av[i] = x;
+      nn += x * x;
+    }
+    const double be = sqrt(bsum(nn));                             // beta[i] = ‖Av‖  (:492)
+    steps = it + 1;
+    if (tid == 0) {
+      a.alpha_out[it] = al;
+      a.beta_out[it] = be;
+    }
+    if (fabs(be) < tiny) break;                                   // (:494-496)
+    for (int i = tid; i < n; i += NT) av[i] = av[i] / be;         // (:497)
+    __syncthreads();
+    double* t = vpre;                                             // (:498-499) as a rotation
+    vpre = v;
+    v = av;
+    av = t;
+    beta_prev = be;
+  }
+  if (tid == 0) {
+    a.c->lz_steps = steps;
+    a.c->lz_beta_prev = beta_prev;
+    sh_s[0] = 0.0;
+  }
+}
+
+// ---- the same recurrence on the structured form of S (instances of the resident loop) ------------------------------
+// S(y) = y_g·A_g + Diag(d(y)): the off-diagonal part is the sliced ELL of A_g (one row per lane, RsEll), the diagonal
+// sdiag_j = y_g·A_g[j,j] + v_j·y[k_j] a vector formed once per run — no assembled S is read.  With unit weights and room
+// in LDS (ELL_LDS) the columns are packed two to a dword into LDS by the prologue and the q steps never leave the CU:
+// per entry one half of a 4-byte LDS read and one 8-byte LDS gather of v.
+struct RsLzEllArgs {
+  int n, q;
+  RsEll E;
+  int gid_g;
+  const int* row_k;
+  const double* row_v;
+  const double* yvec;
+  const double* v0;
+  double *alpha_out, *beta_out;
+  DevCtrl* c;
+};
+template <bool ELL_LDS>
+__global__ void __launch_bounds__(SDPLR_RS_NT)
+k_rs_lanczos_ell(RsLzEllArgs a) {
+  extern __shared__ __attribute__((aligned(16))) double rs_lds[];
+  __shared__ double sred[SDPLR_RS_NW];
+  __shared__ int lp[1026];     // ELL_LDS: first pair-line of each slice in the packed copy
+  constexpr int NT = SDPLR_RS_NT, PF = SDPLR_RS_ELL_PF;
+  const int tid = threadIdx.x, wave = tid >> 6, wl = tid & 63;
+  const int n = a.n;
+  double* v = rs_lds;
+  double* vpre = v + n;
+  double* av = vpre + n;
+  double* sdiag = av + n;
+  unsigned* ell = reinterpret_cast<unsigned*>(sdiag + n);
+  auto bsum = [&](double x) -> double {   // block sum, every thread gets it (fixed order)
+    x = wave_sum(x);
+    __syncthreads();
+    if (wl == 0) sred[wave] = x;
+    __syncthreads();
+    double t = 0.0;
+#pragma unroll
+    for (int i = 0; i < SDPLR_RS_NW; i++) t += sred[i];
+    return t;
+  };
+  const double yg = a.yvec[a.gid_g];
+  const bool uniform = a.E.val == nullptr;
+  const double s_off = yg * a.E.one;         // the value every off-diagonal entry of S has (unit weights)
+  {   // v = v0/‖v0‖ (:473-474); the diagonal of S
+    double s = 0.0;
+    for (int i = tid; i < n; i += NT) {
+      const double x = a.v0[i];
+      v[i] = x;
+      vpre[i] = 0.0;
+      s += x * x;
+      const int k = a.row_k[i];
+      sdiag[i] = (k >= 0 ? a.row_v[i] * a.yvec[k] : 0.0) + a.E.gdiag[i] * yg;
+    }
+    if (ELL_LDS) {
+      if (tid == 0) {
+        int t = 0;
+        for (int sl = 0; sl < a.E.n_slices; sl++) {
+          lp[sl] = t;
+          t += (a.E.sptr[sl + 1] - a.E.sptr[sl] + 1) >> 1;
+        }
+        lp[a.E.n_slices] = t;
+      }
+    }
+    const double nv = sqrt(bsum(s));
+    for (int i = tid; i < n; i += NT) v[i] = v[i] / nv;
+    if (ELL_LDS) {
+      for (int sl = wave; sl < a.E.n_slices; sl += SDPLR_RS_NW) {
+        const int l0 = a.E.sptr[sl], width = a.E.sptr[sl + 1] - l0;
+        const unsigned* ep = a.E.ent + (size_t)l0 * 64 + wl;
+        unsigned* dst = ell + (size_t)lp[sl] * 64 + wl;
+        for (int kp = 0; 2 * kp < width; kp++) {
+          const unsigned c0 = ep[(size_t)(2 * kp) * 64];
+          const unsigned c1 = (2 * kp + 1 < width) ? ep[(size_t)(2 * kp + 1) * 64] : 0u;
+          dst[(size_t)kp * 64] = (c0 & 0xFFFFu) | (c1 << 16);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  double beta_prev = 0.0;
+  int steps = 0;
+  const double tiny = sqrt((double)n) * 2.220446049250313e-16;
+  for (int it = 0; it < a.q; it++) {
+    // Av = S·v  (:483), one row per lane
+    double dot = 0.0;
+#pragma nounroll
+    for (int sl = wave; sl < a.E.n_slices; sl += SDPLR_RS_NW) {
+      const int idx = sl * 64 + wl;
+      const int jp = a.E.perm[idx];
+      const int len = a.E.len[idx];
+      const int l0 = a.E.sptr[sl], width = a.E.sptr[sl + 1] - l0;
+      double acc = 0.0;
+      if (ELL_LDS) {
+        const unsigned* el = ell + (size_t)lp[sl] * 64 + wl;
+#pragma unroll 4
+        for (int kp = 0; 2 * kp < width; kp++) {
+          const unsigned u = el[(size_t)kp * 64];
+          const double x0 = v[(2 * kp < len) ? (u & 0xFFFFu) : 0u], x1 = v[(2 * kp + 1 < len) ? (u >> 16) : 0u];
+          acc += ((2 * kp < len) ? s_off : 0.0) * x0;
+          acc += ((2 * kp + 1 < len) ? s_off : 0.0) * x1;
+        }
+      } else {
+        const unsigned* ep = a.E.ent + (size_t)l0 * 64 + wl;
+        const double* vp = uniform ? nullptr : a.E.val + (size_t)l0 * 64 + wl;
+        unsigned er[PF];
+        double vr[PF];
+#pragma unroll
+        for (int q = 0; q < PF; q++) {
+          const int kc = min(q, width - 1);
+          er[q] = ep[(size_t)kc * 64];
+          vr[q] = uniform ? 0.0 : vp[(size_t)kc * 64];
+        }
+#pragma nounroll
+        for (int k0 = 0; k0 < width; k0 += PF) {
+          unsigned ec[PF];
+          double vc[PF];
+#pragma unroll
+          for (int q = 0; q < PF; q++) {
+            ec[q] = er[q];
+            vc[q] = vr[q];
+          }
+#pragma unroll
+          for (int q = 0; q < PF; q++) {
+            const int kc = min(k0 + PF + q, width - 1);
+            er[q] = ep[(size_t)kc * 64];
+            vr[q] = uniform ? 0.0 : vp[(size_t)kc * 64];
+          }
+#pragma unroll
+          for (int q = 0; q < PF; q++) {
+            const bool on = k0 + q < len;
+            const double sv = uniform ? s_off : vc[q] * yg;      // S[j,k] = y_g·A_g[j,k]  (src/coreop.jl:221)
+            acc += (on ? sv : 0.0) * v[on ? (ec[q] & 0xFFFFu) : 0u];
+          }
+        }
+      }
+      if (jp >= 0) {
+        const double vj = v[jp];
+        const double t = acc + sdiag[jp] * vj;
+        av[jp] = t;
+        dot += vj * t;
+      }
+    }
+    const double al = bsum(dot);                                  // alpha[i] = v'·Av  (:484)
+    double nn = 0.0;
+    for (int i = tid; i < n; i += NT) {
+      double x = av[i];
+      if (it == 0) x -= al * v[i];                                // (:486-490)
+      else x -= al * v[i] + beta_prev * vpre[i];
+      av[i] = x;
+      nn += x * x;
+    }
+    const double be = sqrt(bsum(nn));                             // beta[i] = ‖Av‖  (:492)
+    steps = it + 1;
+    if (tid == 0) {
+      a.alpha_out[it] = al;
+      a.beta_out[it] = be;
+    }
+    if (fabs(be) < tiny) break;                                   // (:494-496)
+    for (int i = tid; i < n; i += NT) av[i] = av[i] / be;         // (:497)
+    __syncthreads();
+    double* t = vpre;                                             // (:498-499) as a rotation
+    vpre = v;
+    v = av;
+    av = t;
+    beta_prev = be;
+  }
+  if (tid == 0) {
+    a.c->lz_steps = steps;
+    a.c->lz_beta_prev = beta_prev;
+  }
+}
+
+// ---- fg! (src/coreop.jl:323-349) as one launch on the instances of the resident loop ----------------------------------
+// f! (:11-31): primal_vio_raw = 𝒜(RRᵀ) − b with 𝒜 row-local — v_j·‖R_j‖² for the constraint attached to row j, ⟨R, P⟩ for
+// A_g's slot, P = A_g·R by the ELL SpMM (left in place: the loop that follows starts from a fresh P) — then obj, the capped
+// violation, ℒ; g! (:305-317): y, G = 2(y_g·P + d(y)∘R), ‖G‖; the two norms of :334-347.
+struct RsFgArgs {
+  int n, m, r;
+  int gid_g;
+  const int* row_k;
+  const double* row_v;
+  RsEll E;
+  const double* R;
+  double *G, *P;
+  double *y, *pv_raw, *pv;
+  const double *lam, *lam_ub, *lb, *b;
+  DevCtrl* c;
+};
+template <int LPR, int VEC>
+__global__ void __launch_bounds__(SDPLR_RS_NT)
+k_rs_fg(RsFgArgs a) {
+  extern __shared__ __attribute__((aligned(16))) double rs_lds[];
+  __shared__ double sred[3 * SDPLR_RS_NW];
+  __shared__ double sh_yg, sh_obj_row;
+  __shared__ int sh_has_obj_row;
+  constexpr int NT = SDPLR_RS_NT, G = NT / LPR;
+  const int tid = threadIdx.x, grp = tid / LPR, lane = tid % LPR;
+  const int n = a.n, m = a.m, r = a.r;
+  const long long N = (long long)n * r;
+  const long long Npad = (N + 1) & ~1LL;
+  double* Rl = rs_lds;          // [Npad] R
+  double* rrl = Rl + Npad;      // [n] ‖R_j‖²
+  double* djl = rrl + n;        // [n] d_j = v_j·y[k_j]
+  const int ch0 = lane * VEC;
+  const bool act = ch0 < r;
+  const double sigma = a.c->sigma, normC = a.c->normC, normb = a.c->normb;
+  const int grel = a.c->grel, prel = a.c->prel;
+  if (tid == 0) sh_has_obj_row = 0;
+  for (long long e = tid; e < N; e += NT) Rl[e] = a.R[e];
+  __syncthreads();
+  rs_ell_spmm_any<VEC, true>(a.E, Rl, n, r, a.P);     // P = A_g·R
+  __syncthreads();
+  double acc[3] = {0.0, 0.0, 0.0};   // ⟨R, P⟩; then Σ(ỹ² − λ²)/(2σ), ‖pv‖²; then ‖G‖²
+#pragma nounroll
+  for (int j = grp; j < n; j += G) {
+    double rr = 0.0;
+    if (act) {
+      const vecd<VEC> x = ldrow<VEC>(Rl + (long long)j * r + ch0), p = ldrow<VEC>(a.P + (long long)j * r + ch0);
+#pragma unroll
+      for (int k = 0; k < VEC; k++) {
+        rr += x.v[k] * x.v[k];
+        acc[0] += x.v[k] * p.v[k];
+      }
+    }
+    rr = group_sum<LPR>(rr);
+    if (lane == 0) rrl[j] = rr;
+  }
+  rs_sum_to0<1>(reinterpret_cast<double(&)[1]>(acc[0]), sred);
+  __syncthreads();
+  double fs = 0.0, pn = 0.0;
+  if (tid == 0) {   // A_g's slot
+    const int kg = a.gid_g;
+    double v = acc[0];
+    double yk = 1.0;
+    if (kg < m) {
+      v -= a.b[kg];                                          // (:20)
+      const double pc = fmax(v, a.lb[kg]);                   // (:22)
+      a.pv[kg] = pc;
+      pn += pc * pc;
+      const double l = a.lam[kg], yt = fmin(a.lam_ub[kg], l - sigma * v);   // (:27)
+      fs += (yt * yt - l * l) / (2 * sigma);                 // (:28)
+      yk = -yt;                                              // src/coreop.jl:233
+    }
+    a.pv_raw[kg] = v;
+    a.y[kg] = yk;
+    sh_yg = yk;
+  }
+  for (int j = tid; j < n; j += NT) {
+    const int k = a.row_k[j];
+    double dj = 0.0;
+    if (k >= 0) {
+      const double rv = a.row_v[j];
+      double v = rv * rrl[j];
+      double yk = 1.0;
+      if (k < m) {
+        v -= a.b[k];
+        const double pc = fmax(v, a.lb[k]);
+        a.pv[k] = pc;
+        pn += pc * pc;
+        const double l = a.lam[k], yt = fmin(a.lam_ub[k], l - sigma * v);
+        fs += (yt * yt - l * l) / (2 * sigma);
+        yk = -yt;
+      } else {            // the cost matrix as a row-attached entry
+        sh_obj_row = v;
+        sh_has_obj_row = 1;
+      }
+      a.pv_raw[k] = v;
+      a.y[k] = yk;
+      dj = rv * yk;
+    }
+    djl[j] = dj;
+  }
+  double two[2] = {fs, pn};
+  rs_sum_to0<2>(two, sred);
+  __syncthreads();
+  const double yg = sh_yg;
+  double gn = 0.0;
+#pragma nounroll
+  for (int j = grp; j < n; j += G) {
+    if (act) {
+      const long long e = (long long)j * r + ch0;
+      const vecd<VEC> x = ldrow<VEC>(Rl + e), p = ldrow<VEC>(a.P + e);
+      const double dj = djl[j];
+      vecd<VEC> g;
+#pragma unroll
+      for (int k = 0; k < VEC; k++) {
+        g.v[k] = p.v[k] * yg + x.v[k] * dj;
+        g.v[k] *= 2.0;                                        // src/coreop.jl:315
+        gn += g.v[k] * g.v[k];
+      }
+      strow<VEC>(a.G + e, g);
+    }
+  }
+  double one[1] = {gn};
+  rs_sum_to0<1>(one, sred);
+  if (tid == 0) {
+    const double obj = (a.gid_g == m) ? acc[0] : (sh_has_obj_row ? sh_obj_row : a.pv_raw[m]);
+    a.c->obj = obj;                                           // (:16)
+    a.c->L = obj + two[0];                                    // (:25-30)
+    const double g2 = sqrt(one[0]), p2 = sqrt(two[1]);
+    a.c->gnorm = grel ? g2 / normC : g2;                      // (:334-338)
+    a.c->pvnorm = prel ? p2 / normb : p2;                     // (:340-347)
+  }
+}

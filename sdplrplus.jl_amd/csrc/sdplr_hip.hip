@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstddef>
@@ -26,6 +27,7 @@
 #include "k_scalar.h"
 #include "k_sparse.h"
 #include "k_eig.h"
+#include "k_resident.h"
 
 namespace {
 
@@ -73,6 +75,14 @@ struct sdplr_hip_solver {
   std::vector<LowRankHost> h_lr;
 
   // ---- device state ----
+  // finalize's small uploads and zero-fills are sub-allocated from chunks that go to the device in ONE copy each (a small
+  // instance made ≈ 70 synchronous hipMemcpy / hipMemset calls: 1.3 ms alone, 16 ms with 16 handles being built at once)
+  struct UploadArena {
+    bool on = false;
+    char* dev = nullptr;
+    size_t cap = 0, used = 0;
+    std::vector<char> host;
+  } up;
   std::vector<void*> allocs;
   DevSparse sp{};
   DevLowRank lr{};
@@ -104,6 +114,12 @@ struct sdplr_hip_solver {
   std::vector<double> h_gval;
   std::vector<void*> tile_allocs;
   bool fast_singleton = false;   // every diagonal-only matrix has exactly one entry (k_sparse.h, singleton form)
+  // resident route (k_resident.h): singleton form, no low-rank matrices, at most one singleton constraint per row
+  bool rs_ok = false;
+  const int* rs_row_k = nullptr;     // [n] the constraint attached to row j (−1: none)
+  const double* rs_row_v = nullptr;  // [n] its value
+  RsEll rs_ell{};                    // A_g as a sliced ELL, one row per lane
+  size_t rs_ell_pair_lines = 0;      // Σ over slices of ⌈width/2⌉: 256-byte lines of the two-columns-per-dword copy (Lanczos, LDS)
   const int* extra_slots = nullptr;  // slots not attached to a row: A_g and the low-rank matrices
   int n_extra = 0;
   FactorArena arena{};
@@ -112,6 +128,7 @@ struct sdplr_hip_solver {
          *pv_lb = nullptr, *pv = nullptr, *A_RD = nullptr, *A_DD = nullptr;
   DevCtrl* ctrl = nullptr;   // device
   DevCtrl* hc = nullptr;     // pinned host shadow
+  bool hc_valid = false;     // the shadow equals the device block: nothing was enqueued since the last pull / push
   DevCtrl* snap[2] = {nullptr, nullptr};   // pinned snapshots of the control block, one per queued batch
   hipEvent_t snap_ev[2] = {nullptr, nullptr};
   double* partials = nullptr;
@@ -140,6 +157,11 @@ struct sdplr_hip_solver {
   // written outside the loop or after SDPLR_P_REFRESH_ITERS incremental updates (drift control).  The loop leaves y
   // current but not the assembled S: whoever reads S next assembles it first (ensure_S).
   bool P_valid = false, S_stale = false;
+  // S (assembled, or still to be assembled: S_stale) is S(y) of the device's y.  Cleared when the host writes y or the
+  // S values themselves: the Lanczos forms that take S from y and the fixed structure (palette bands, resident ELL)
+  // are then skipped in favour of the ones that read the assembled values.
+  bool S_from_y = true;
+  bool lz_band_now = false;          // this Lanczos run uses the band plan
   int64_t P_age = 0;
 
   // scratch arrays for operator calls on the caller's own matrices / vectors (SDPLR_F_SCRATCH, SDPLR_V_SCRATCH)
@@ -147,7 +169,7 @@ struct sdplr_hip_solver {
   double* scratchV = nullptr;
   // counters (sdplr_hip_get_stats)
   int64_t st_captures = 0, st_capture_failed = 0, st_capture_skipped = 0, st_graph_batches = 0,
-          st_eager_batches = 0, st_lz_graph = 0, st_lz_eager = 0, st_iters = 0;
+          st_eager_batches = 0, st_lz_graph = 0, st_lz_eager = 0, st_iters = 0, st_rs_loops = 0, st_rs_lz = 0, st_rs_fg = 0;
 
   // profiling
   bool prof_on = false;
@@ -179,6 +201,12 @@ int fail(S* s, int code, const std::string& msg) {
     if (!(s)) return fail(nullptr, SDPLR_ERR_INVALID_ARG, "null handle");        \
     if (!(s)->finalized) return fail((s), SDPLR_ERR_STATE, "not finalized");     \
   } while (0)
+// entry points that enqueue kernels: the host shadow of the control block is stale until the next pull
+#define NEED_FINAL_RW(s)       \
+  do {                         \
+    NEED_FINAL(s);             \
+    (s)->hc_valid = false;     \
+  } while (0)
 
 int have_device() {
   int c = 0;
@@ -198,6 +226,10 @@ struct DevPool {
   std::map<std::pair<int, size_t>, std::vector<void*>> free_blocks;
   std::unordered_map<void*, std::pair<int, size_t>> live;
   std::vector<void*> pinned_free;   // pinned host blocks of sizeof(DevCtrl)
+  // streams and events of destroyed handles: hipStreamCreate / hipStreamDestroy cost 1–2 ms each, more than the rest of
+  // finalize on a small instance (a batch creates and destroys a handle per instance)
+  std::map<int, std::vector<hipStream_t>> streams_free;
+  std::vector<hipEvent_t> events_free;
   size_t cached = 0;
   const bool off = getenv("SDPLR_HIP_NO_POOL") != nullptr;
   static constexpr size_t MAX_BLOCK = (size_t)16 << 20, MAX_CACHED = (size_t)512 << 20;
@@ -272,6 +304,63 @@ void pool_host_ctrl_free(void* p) {
   (void)hipHostFree(p);
 }
 
+hipError_t pool_stream(hipStream_t* out) {
+  DevPool& P = pool();
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (!P.off) {
+    std::lock_guard<std::mutex> g(P.mu);
+    auto& v = P.streams_free[dev];
+    if (!v.empty()) {
+      *out = v.back();
+      v.pop_back();
+      return hipSuccess;
+    }
+  }
+  return hipStreamCreateWithFlags(out, hipStreamNonBlocking);
+}
+void pool_stream_free(hipStream_t st) {   // (drained by the caller)
+  if (!st) return;
+  DevPool& P = pool();
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (!P.off) {
+    std::lock_guard<std::mutex> g(P.mu);
+    auto& v = P.streams_free[dev];
+    if (v.size() < 64) {
+      v.push_back(st);
+      return;
+    }
+  }
+  (void)hipStreamDestroy(st);
+}
+hipError_t pool_event(hipEvent_t* out) {
+  DevPool& P = pool();
+  if (!P.off) {
+    std::lock_guard<std::mutex> g(P.mu);
+    if (!P.events_free.empty()) {
+      *out = P.events_free.back();
+      P.events_free.pop_back();
+      return hipSuccess;
+    }
+  }
+  // (blocking: a host thread waiting for a resident loop — milliseconds — sleeps instead of spinning; with 16 instances in
+  // flight the spinning waiters starved the threads that were setting their own instances up)
+  return hipEventCreateWithFlags(out, hipEventDisableTiming | hipEventBlockingSync);
+}
+void pool_event_free(hipEvent_t e) {
+  if (!e) return;
+  DevPool& P = pool();
+  if (!P.off) {
+    std::lock_guard<std::mutex> g(P.mu);
+    if (P.events_free.size() < 256) {
+      P.events_free.push_back(e);
+      return;
+    }
+  }
+  (void)hipEventDestroy(e);
+}
+
 template <typename T>
 int dalloc(S* s, T** p, size_t count) {
   void* q = nullptr;
@@ -281,17 +370,58 @@ int dalloc(S* s, T** p, size_t count) {
   *p = (T*)q;
   return SDPLR_OK;
 }
+constexpr size_t ARENA_ITEM_MAX = (size_t)256 << 10, ARENA_CHUNK = (size_t)4 << 20;
+int arena_commit(S* s) {   // the pending chunk → device (zero-filled where nothing was uploaded)
+  S::UploadArena& u = s->up;
+  if (u.dev && u.used > 0) {
+    HIPCK(s, hipMemcpyAsync(u.dev, u.host.data(), u.used, hipMemcpyHostToDevice, s->stream));
+    HIPCK(s, hipStreamSynchronize(s->stream));
+  }
+  u.dev = nullptr;
+  u.cap = u.used = 0;
+  return SDPLR_OK;
+}
+// room for `bytes` in the current chunk (src == nullptr: zeros); *out = nullptr ⇒ not an arena item
+int arena_take(S* s, size_t bytes, const void* src, void** out) {
+  *out = nullptr;
+  S::UploadArena& u = s->up;
+  const size_t b = (std::max<size_t>(bytes, 1) + 255) / 256 * 256;
+  if (!u.on || b > ARENA_ITEM_MAX) return SDPLR_OK;
+  if (u.used + b > u.cap) {
+    int rc = arena_commit(s);
+    if (rc) return rc;
+    void* q = nullptr;
+    hipError_t e = pool_malloc(&q, ARENA_CHUNK);
+    if (e != hipSuccess) return fail(s, SDPLR_ERR_ALLOC, std::string("hipMalloc: ") + hipGetErrorString(e));
+    s->allocs.push_back(q);
+    u.dev = (char*)q;
+    u.cap = ARENA_CHUNK;
+    u.host.assign(ARENA_CHUNK, 0);
+  }
+  if (src && bytes) memcpy(u.host.data() + u.used, src, bytes);
+  *out = u.dev + u.used;
+  u.used += b;
+  return SDPLR_OK;
+}
 template <typename T>
 int upload(S* s, const T** dst, const std::vector<T>& v) {
+  void* a = nullptr;
+  int rc = arena_take(s, v.size() * sizeof(T), v.data(), &a);
+  if (rc) return rc;
+  if (a) { *dst = (const T*)a; return SDPLR_OK; }
   T* p = nullptr;
-  int rc = dalloc(s, &p, v.size());
+  rc = dalloc(s, &p, v.size());
   if (rc) return rc;
   if (!v.empty()) HIPCK(s, hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
   *dst = p;
   return SDPLR_OK;
 }
 int dzero(S* s, double** p, size_t count) {
-  int rc = dalloc(s, p, count);
+  void* a = nullptr;
+  int rc = arena_take(s, count * sizeof(double), nullptr, &a);
+  if (rc) return rc;
+  if (a) { *p = (double*)a; return SDPLR_OK; }
+  rc = dalloc(s, p, count);
   if (rc) return rc;
   // zero-fill ON THE SOLVER'S STREAM: a legacy-stream hipMemset is not ordered with this non-blocking
   // stream, so a late zero-fill could wipe an upload issued after it (seen with 8 concurrent handles)
@@ -353,12 +483,24 @@ void prof_drain(S* s) {
 int pull(S* s) {
   HIPCK(s, hipMemcpyAsync(s->hc, s->ctrl, sizeof(DevCtrl), hipMemcpyDeviceToHost, s->stream));
   HIPCK(s, hipStreamSynchronize(s->stream));
+  s->hc_valid = true;
   return SDPLR_OK;
 }
+// the same, for waits that are long (a resident loop, a resident Lanczos run): the host thread sleeps on a blocking event
+int pull_blocking(S* s) {
+  HIPCK(s, hipMemcpyAsync(s->hc, s->ctrl, sizeof(DevCtrl), hipMemcpyDeviceToHost, s->stream));
+  HIPCK(s, hipEventRecord(s->snap_ev[0], s->stream));
+  HIPCK(s, hipEventSynchronize(s->snap_ev[0]));
+  s->hc_valid = true;
+  return SDPLR_OK;
+}
+// the shadow, fetched only if something may have changed the device block since it was last seen (a small solve makes
+// ≈ 40 scalar reads / writes: each was a device round trip)
+int pull_if_stale(S* s) { return s->hc_valid ? SDPLR_OK : pull(s); }
 int push(S* s) {
   HIPCK(s, hipMemcpyAsync(s->ctrl, s->hc, sizeof(DevCtrl), hipMemcpyHostToDevice, s->stream));
   HIPCK(s, hipStreamSynchronize(s->stream));
-  return SDPLR_OK;
+  return SDPLR_OK;   // (hc_valid is left as it is: a caller that enqueues kernels after this clears it at its entry)
 }
 int sync_check(S* s) {
   HIPCK(s, hipGetLastError());
@@ -416,6 +558,11 @@ void choose_shape(S* s) {
 // and the arrays end with 2·64 more entries so that the kernel's look-ahead stays in bounds.
 int build_tiles(S* s) {
   const int64_t n = s->n;
+  struct ArenaOff {   // (the tile arrays are released one by one when the rank changes: never arena items)
+    S* s; bool was;
+    explicit ArenaOff(S* s_) : s(s_), was(s_->up.on) { s->up.on = false; }
+    ~ArenaOff() { s->up.on = was; }
+  } arena_off(s);
   for (void* p : s->tile_allocs) {
     pool_free(p);
     s->allocs.erase(std::remove(s->allocs.begin(), s->allocs.end(), p), s->allocs.end());
@@ -677,6 +824,63 @@ int build_band(S* s) {
   return SDPLR_OK;
 }
 
+// A_g as the resident route's sliced ELL (k_resident.h, RsEll), from its symmetric CSR (rows sorted by column).  Only for
+// instances the resident kernels can take at some rank: n < 2¹⁶ (16-bit columns) and a factor of rank 1 within the LDS
+// budget.  Sets rs_ok.
+int build_rs_ell(S* s, const std::vector<int>& g_ptr, const std::vector<int>& g_col, const std::vector<double>& g_val) {
+  const int64_t n = s->n;
+  if (n >= (1 << 16) || (size_t)4 * n * sizeof(double) > (size_t)150 * 1024 || getenv("SDPLR_HIP_NO_RESIDENT") != nullptr) return SDPLR_OK;
+  std::vector<int> len(n, 0);
+  std::vector<double> gdiag(n, 0.0);
+  bool uniform = true, have_one = false;   // every off-diagonal entry the same value?
+  double one = 0.0;
+  for (int64_t j = 0; j < n; j++)
+    for (int q = g_ptr[j]; q < g_ptr[j + 1]; q++) {
+      if (g_col[q] == (int)j) { gdiag[j] += g_val[q]; continue; }
+      len[j]++;
+      if (!have_one) { one = g_val[q]; have_one = true; }
+      else if (!(g_val[q] == one)) uniform = false;
+    }
+  std::vector<int> order(n);
+  for (int64_t j = 0; j < n; j++) order[j] = (int)j;
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return len[a] > len[b]; });
+  const int S_ = (int)((n + 63) / 64);
+  std::vector<int> perm((size_t)S_ * 64, -1), plen((size_t)S_ * 64, 0), sptr(S_ + 1, 0);
+  for (int64_t t = 0; t < n; t++) { perm[t] = order[t]; plen[t] = len[order[t]]; }
+  for (int sl = 0; sl < S_; sl++) sptr[sl + 1] = sptr[sl] + plen[(size_t)sl * 64];   // the slice's first row is its longest
+  s->rs_ell_pair_lines = 0;
+  for (int sl = 0; sl < S_; sl++) s->rs_ell_pair_lines += (size_t)(sptr[sl + 1] - sptr[sl] + 1) / 2;
+  std::vector<unsigned> ent((size_t)std::max(sptr[S_], 1) * 64, 0u);
+  std::vector<double> val;
+  if (!uniform) val.assign(ent.size(), 0.0);
+  for (int sl = 0; sl < S_; sl++)
+    for (int l = 0; l < 64; l++) {
+      const int j = perm[(size_t)sl * 64 + l];
+      if (j < 0) continue;
+      int k = 0;
+      for (int q = g_ptr[j]; q < g_ptr[j + 1]; q++) {
+        if (g_col[q] == j) continue;
+        const size_t at = ((size_t)sptr[sl] + k) * 64 + l;
+        if (!uniform) val[at] = g_val[q];
+        ent[at] = (unsigned)g_col[q];
+        k++;
+      }
+    }
+  RsEll& E = s->rs_ell;
+  E = RsEll{};
+  E.n_slices = S_;
+  E.one = one;
+  int rc;
+  if ((rc = upload(s, &E.perm, perm))) return rc;
+  if ((rc = upload(s, &E.len, plen))) return rc;
+  if ((rc = upload(s, &E.sptr, sptr))) return rc;
+  if ((rc = upload(s, &E.ent, ent))) return rc;
+  if (!uniform && (rc = upload(s, &E.val, val))) return rc;
+  if ((rc = upload(s, &E.gdiag, gdiag))) return rc;
+  s->rs_ok = true;
+  return SDPLR_OK;
+}
+
 // lbfgs_update! rides k_fast_step2 (structured fast paths) for h ≤ 4 and 32-bit row offsets
 bool step_fuses_update(const S* s) {
   return s->h >= 1 && s->h <= 4 && s->n * s->r * 8 < (1LL << 32) && !s->no_updfuse;
@@ -814,6 +1018,137 @@ int32_t sdplr_hip_set_sparse(S* s, int64_t base, int64_t n_sparse, const int64_t
   return SDPLR_OK;
 }
 
+// preprocess_sparsecons (src/preprocess.jl:24-169) inside the library: the same aggregated layout set_sparse takes,
+// built from the matrices themselves — counting passes and per-column sorts of short lists instead of the reference's
+// per-matrix walk, a binary search only where the reference has one (:110-119, :143-156).
+int32_t sdplr_hip_set_sparse_coo(S* s, int64_t base, int64_t n_sparse, const int64_t* ent_ptr, const int64_t* I,
+                                 const int64_t* J, const double* V, const int64_t* gids) {
+  ApiShared api_guard;
+  if (!s) return fail(nullptr, SDPLR_ERR_INVALID_ARG, "null handle");
+  if (s->finalized || s->have_sparse) return fail(s, SDPLR_ERR_STATE, "set_sparse_coo: already set / finalized");
+  if (base != 0 && base != 1) return fail(s, SDPLR_ERR_INVALID_ARG, "set_sparse_coo: index_base must be 0 or 1");
+  if (n_sparse < 0 || !ent_ptr || (n_sparse > 0 && !gids)) return fail(s, SDPLR_ERR_INVALID_ARG, "set_sparse_coo: bad sizes / null arrays");
+  const int64_t n = s->n, lim = (1LL << 31) - 2;
+  const int64_t E = ent_ptr[n_sparse] - base;
+  if (ent_ptr[0] - base != 0 || E < 0 || E > lim || n_sparse > lim) return fail(s, SDPLR_ERR_INVALID_ARG, "set_sparse_coo: bad ent_ptr");
+  if (E > 0 && (!I || !J || !V)) return fail(s, SDPLR_ERR_INVALID_ARG, "set_sparse_coo: null entry arrays");
+  for (int64_t k = 0; k < n_sparse; k++) {
+    if (ent_ptr[k + 1] < ent_ptr[k]) return fail(s, SDPLR_ERR_INVALID_ARG, "set_sparse_coo: ent_ptr not monotone");
+    const int64_t g = gids[k] - base;
+    if (g < 0 || g > s->m) return fail(s, SDPLR_ERR_INVALID_ARG, "set_sparse_coo: global index out of range");
+  }
+  // ---- the aggregated full pattern sparse(all_I, all_J, ones) (:87): entries bucketed by column, each column's rows
+  // sorted and made unique; its upper triangle (:90) is a prefix-free filter of the same lists ----
+  std::vector<int> cnt(n + 1, 0);
+  int64_t n_upper = 0;
+  for (int64_t e = 0; e < E; e++) {
+    const int64_t i = I[e] - base, j = J[e] - base;
+    if (i < 0 || i >= n || j < 0 || j >= n) return fail(s, SDPLR_ERR_INVALID_ARG, "set_sparse_coo: constraint entry outside the n×n matrix");
+    cnt[j + 1]++;
+    n_upper += (i <= j);
+  }
+  for (int64_t j = 0; j < n; j++) cnt[j + 1] += cnt[j];
+  std::vector<int> rows(E);
+  {
+    std::vector<int> fill(cnt.begin(), cnt.end() - 1);
+    for (int64_t e = 0; e < E; e++) rows[fill[J[e] - base]++] = (int)(I[e] - base);
+  }
+  std::vector<int>&fcp = s->h_fcp, &frv = s->h_frv, &tcp = s->h_tcp, &trv = s->h_trv;
+  fcp.assign(n + 1, 0);
+  tcp.assign(n + 1, 0);
+  frv.clear(); frv.reserve(E);
+  trv.clear(); trv.reserve(n_upper);
+  for (int64_t j = 0; j < n; j++) {
+    int* b = rows.data() + cnt[j];
+    int* e = rows.data() + cnt[j + 1];
+    if (!std::is_sorted(b, e)) std::sort(b, e);
+    int last = -1;
+    for (int* p = b; p < e; p++) {
+      if (*p == last) continue;
+      last = *p;
+      frv.push_back(last);
+      if (last <= (int)j) trv.push_back(last);
+    }
+    fcp[j + 1] = (int)frv.size();
+    tcp[j + 1] = (int)trv.size();
+  }
+  const int64_t nnzS = (int64_t)frv.size(), nnzT = (int64_t)trv.size();
+  auto find_triu = [&](int col, int row) -> int {   // position of (row, col) in the triu pattern, −1 if absent
+    const int* b = trv.data() + tcp[col];
+    const int* e = trv.data() + tcp[col + 1];
+    const int* p = std::lower_bound(b, e, row);
+    return (p < e && *p == row) ? (int)(p - trv.data()) : -1;
+  };
+  // ---- per-matrix segments over the upper-triangular entries (:97-132) ----
+  s->h_matptr.assign(n_sparse + 1, 0);
+  s->h_nzind.resize(n_upper); s->h_one.resize(n_upper); s->h_two.resize(n_upper);
+  s->h_gids.resize(n_sparse);
+  int64_t cum = 0;
+  for (int64_t k = 0; k < n_sparse; k++) {
+    s->h_matptr[k] = (int)cum;
+    s->h_gids[k] = (int)(gids[k] - base);
+    for (int64_t e = ent_ptr[k] - base; e < ent_ptr[k + 1] - base; e++) {
+      const int i = (int)(I[e] - base), j = (int)(J[e] - base);
+      if (i > j) continue;                                   // triu keeps i ≤ j (:9)
+      s->h_nzind[cum] = find_triu(j, i);
+      s->h_one[cum] = V[e];
+      s->h_two[cum] = (i == j) ? V[e] : 2.0 * V[e];           // off-diagonal entries count twice (:121-128)
+      cum++;
+    }
+  }
+  s->h_matptr[n_sparse] = (int)cum;
+  // ---- full pattern → position of (min, max) in the upper-triangular pattern (:135-156): the upper entries of column j
+  // ARE column j of the triu pattern, in order; a lower entry (i > j) is searched in column i ----
+  s->h_mapped.resize(nnzS);
+  for (int64_t j = 0; j < n; j++) {
+    int up = tcp[j];
+    for (int p = fcp[j]; p < fcp[j + 1]; p++) {
+      const int i = frv[p];
+      if (i <= (int)j) { s->h_mapped[p] = up++; continue; }
+      const int q = find_triu(i, (int)j);
+      if (q < 0) {
+        s->h_matptr.clear(); s->h_nzind.clear(); s->h_one.clear(); s->h_two.clear(); s->h_gids.clear();
+        fcp.clear(); frv.clear(); tcp.clear(); trv.clear(); s->h_mapped.clear();
+        return fail(s, SDPLR_ERR_INVALID_ARG, "set_sparse_coo: a constraint matrix is not symmetric: a lower-triangular entry has no "
+                                              "upper-triangular mirror in the aggregated pattern");
+      }
+      s->h_mapped[p] = q;
+    }
+  }
+  s->n_sparse = n_sparse; s->nnzT = nnzT; s->nnzS = nnzS; s->nnzAgg = n_upper;
+  s->have_sparse = true;
+  return SDPLR_OK;
+}
+
+// The aggregated layout as the library holds it between set_sparse[_coo] and finalize (0-based), for callers that want
+// to keep it (SolverAuxiliary's fields, src/structs.jl:278-288) and for the parity tests of the native preprocessing.
+// which: 0 matptr [n_sparse+1], 1 nzind [nnzAgg], 2 global_inds [n_sparse], 3 triu_colptr [n+1], 4 triu_rowval [nnzT],
+// 5 full_colptr [n+1], 6 full_rowval [nnzS], 7 mappedto_triu [nnzS] → out_i; 8 nzval_one, 9 nzval_two [nnzAgg] → out_f.
+int32_t sdplr_hip_get_layout(const S* s, int32_t which, int64_t* out_i, double* out_f, int64_t cap, int64_t* len) {
+  if (!s) return SDPLR_ERR_INVALID_ARG;
+  if (!s->have_sparse || s->finalized) return SDPLR_ERR_STATE;
+  const std::vector<int>* vi = nullptr;
+  const std::vector<double>* vf = nullptr;
+  switch (which) {
+    case 0: vi = &s->h_matptr; break;
+    case 1: vi = &s->h_nzind; break;
+    case 2: vi = &s->h_gids; break;
+    case 3: vi = &s->h_tcp; break;
+    case 4: vi = &s->h_trv; break;
+    case 5: vi = &s->h_fcp; break;
+    case 6: vi = &s->h_frv; break;
+    case 7: vi = &s->h_mapped; break;
+    case 8: vf = &s->h_one; break;
+    case 9: vf = &s->h_two; break;
+    default: return SDPLR_ERR_INVALID_ARG;
+  }
+  const int64_t L = vi ? (int64_t)vi->size() : (int64_t)vf->size();
+  if (len) *len = L;
+  if (vi && out_i) for (int64_t k = 0; k < std::min(L, cap); k++) out_i[k] = (*vi)[k];
+  if (vf && out_f) for (int64_t k = 0; k < std::min(L, cap); k++) out_f[k] = (*vf)[k];
+  return SDPLR_OK;
+}
+
 int32_t sdplr_hip_add_symlowrank(S* s, int64_t base, int64_t gid, int64_t sc, const double* B, const double* D) {
   ApiShared api_guard;
   if (!s) return fail(nullptr, SDPLR_ERR_INVALID_ARG, "null handle");
@@ -831,9 +1166,10 @@ int32_t sdplr_hip_finalize(S* s) {
   ApiShared api_guard;
   if (!s) return fail(nullptr, SDPLR_ERR_INVALID_ARG, "null handle");
   if (s->finalized) return fail(s, SDPLR_ERR_STATE, "finalize: already finalized");
-  HIPCK(s, hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+  HIPCK(s, pool_stream(&s->stream));
   const int64_t n = s->n, m = s->m;
   int rc;
+  s->up.on = getenv("SDPLR_HIP_NO_UPLOAD_ARENA") == nullptr;
   // SDPLR_HIP_TIMING=1: where the set-up time goes (stderr)
   const bool timing = getenv("SDPLR_HIP_TIMING") != nullptr;
   auto t_last = std::chrono::steady_clock::now();
@@ -942,9 +1278,7 @@ int32_t sdplr_hip_finalize(S* s) {
   }
   // ---- vectors ----
   if ((rc = dzero(s, &s->lambda, m))) return rc;
-  if ((rc = dzero(s, &s->lambda_ub, m))) return rc;
   if ((rc = dzero(s, &s->b, m))) return rc;
-  if ((rc = dzero(s, &s->pv_lb, m))) return rc;
   if ((rc = dzero(s, &s->pv, m))) return rc;
   if ((rc = dzero(s, &s->y, m + 1))) return rc;
   if ((rc = dzero(s, &s->pv_raw, m + 1))) return rc;
@@ -952,12 +1286,11 @@ int32_t sdplr_hip_finalize(S* s) {
   if ((rc = dzero(s, &s->A_DD, m + 1))) return rc;
   {  // all-equality defaults (src/structs.jl:266-268, :247)
     std::vector<double> inf(m, std::numeric_limits<double>::infinity()), ninf(m, -std::numeric_limits<double>::infinity());
-    if (m > 0) {
-      // same stream as the zero-fills above, and drained before the host vectors go out of scope
-      HIPCK(s, hipMemcpyAsync(s->lambda_ub, inf.data(), m * sizeof(double), hipMemcpyHostToDevice, s->stream));
-      HIPCK(s, hipMemcpyAsync(s->pv_lb, ninf.data(), m * sizeof(double), hipMemcpyHostToDevice, s->stream));
-      HIPCK(s, hipStreamSynchronize(s->stream));
-    }
+    const double *ub = nullptr, *lb = nullptr;
+    if ((rc = upload(s, &ub, inf))) return rc;
+    if ((rc = upload(s, &lb, ninf))) return rc;
+    s->lambda_ub = const_cast<double*>(ub);
+    s->pv_lb = const_cast<double*>(lb);
   }
   if ((rc = dzero(s, &s->partials, (size_t)SDPLR_NSLOT * SDPLR_MAXNB))) return rc;
   for (int k = 0; k < 3; k++)
@@ -980,7 +1313,7 @@ int32_t sdplr_hip_finalize(S* s) {
     HIPCK(s, hipStreamSynchronize(s->stream));
     for (int k = 0; k < 2; k++) {
       HIPCK(s, pool_host_ctrl((void**)&s->snap[k]));
-      HIPCK(s, hipEventCreateWithFlags(&s->snap_ev[k], hipEventDisableTiming));
+      HIPCK(s, pool_event(&s->snap_ev[k]));
     }
   }
   lap("vectors + control block");
@@ -1114,6 +1447,18 @@ int32_t sdplr_hip_finalize(S* s) {
       for (size_t t = 0; t < 4; t++) s->extra_head.k[t] = t < extra.size() ? extra[t] : 0;
       s->n_extra = (int)extra.size();
       s->fast_singleton = single && s->spg.n_long_rows == 0 && getenv("SDPLR_HIP_NO_FAST2") == nullptr;
+      // resident route for small instances (k_resident.h): row-local constraint data, one constraint per row at most
+      bool one_per_row = s->fast_singleton && s->h_lr.empty();
+      for (int64_t i = 0; i < n && one_per_row; i++) one_per_row = d_ptr[i + 1] - d_ptr[i] <= 1;
+      if (one_per_row) {
+        std::vector<int> row_k(n, -1);
+        std::vector<double> row_v(n, 0.0);
+        for (int64_t i = 0; i < n; i++)
+          if (d_ptr[i + 1] > d_ptr[i]) { row_k[i] = d_gid[d_ptr[i]]; row_v[i] = d_val[d_ptr[i]]; }
+        if ((rc = upload(s, &s->rs_row_k, row_k))) return rc;
+        if ((rc = upload(s, &s->rs_row_v, row_v))) return rc;
+        if ((rc = build_rs_ell(s, g_ptr, g_col, g_val))) return rc;
+      }
     }
   }
   // ---- edge path: disjoint supports (every pattern position owned by at most one sparse matrix) and at most one
@@ -1198,6 +1543,9 @@ int32_t sdplr_hip_finalize(S* s) {
   s->nb_nnzT = blocks_for(s->nnzT, SDPLR_NT, 4096);
   s->nb_nnzS = blocks_for(s->nnzS, SDPLR_NT, 4096);
   s->nb_n = blocks_for(n, SDPLR_NT, 1024);
+  if ((rc = arena_commit(s))) return rc;
+  s->up.on = false;
+  std::vector<char>().swap(s->up.host);
   // low-rank scratch depends on r: allocated for the largest rank seen (reset_rank re-allocates)
   if ((rc = dzero(s, &s->lr_part, (size_t)std::max(s->nb_lr, SDPLR_MAXNB) * 2 * std::max(lr.ST, 1) * s->r))) return rc;
   if ((rc = dzero(s, &s->lr_W, (size_t)2 * std::max(lr.ST, 1) * s->r))) return rc;
@@ -1225,17 +1573,17 @@ int32_t sdplr_hip_destroy(S* s) {
   if (s->lz_graph) (void)hipGraphExecDestroy(s->lz_graph);
   for (int k = 0; k < 2; k++) {
     if (s->snap[k]) pool_host_ctrl_free(s->snap[k]);
-    if (s->snap_ev[k]) (void)hipEventDestroy(s->snap_ev[k]);
+    if (s->snap_ev[k]) pool_event_free(s->snap_ev[k]);
     if (s->graph_exec[k]) (void)hipGraphExecDestroy(s->graph_exec[k]);
   }
-  if (s->stream) (void)hipStreamDestroy(s->stream);
+  if (s->stream) { (void)hipStreamSynchronize(s->stream); pool_stream_free(s->stream); }
   delete s;
   return SDPLR_OK;
 }
 
 int32_t sdplr_hip_reset_rank(S* s, int64_t new_r) {
   ApiShared api_guard;
-  NEED_FINAL(s);
+  NEED_FINAL_RW(s);
   if (new_r < 1 || s->n * new_r >= (1LL << 40)) return fail(s, SDPLR_ERR_INVALID_ARG, "reset_rank: bad rank");
   HIPCK(s, hipStreamSynchronize(s->stream));
   if (s->arena.base) pool_free(s->arena.base);
@@ -1328,13 +1676,18 @@ int32_t sdplr_hip_set_vec(S* s, int32_t which, const double* h, int64_t len) {
   if (L < 0 || len != L || (!h && L > 0)) return fail(s, SDPLR_ERR_INVALID_ARG, "set_vec: bad slot/length");
   if (L == 0) return SDPLR_OK;
   if (in_ctrl) {
-    int rc = pull(s);
+    int rc = pull_if_stale(s);
     if (rc) return rc;
     memcpy(p, h, L * sizeof(double));
     return push(s);
   }
   HIPCK(s, hipMemcpyAsync(p, h, L * sizeof(double), hipMemcpyHostToDevice, s->stream));
   HIPCK(s, hipStreamSynchronize(s->stream));
+  if (which == SDPLR_V_Y) s->S_from_y = false;   // until the next 𝒜t_preprocess!
+  if (which == SDPLR_V_S_NZVAL || which == SDPLR_V_TRIU_S_NZVAL) {
+    s->S_from_y = false;
+    s->S_stale = false;                          // the caller's values stand: nothing may re-assemble over them
+  }
   return SDPLR_OK;
 }
 int32_t sdplr_hip_get_vec(S* s, int32_t which, double* h, int64_t len) {
@@ -1346,7 +1699,7 @@ int32_t sdplr_hip_get_vec(S* s, int32_t which, double* h, int64_t len) {
   if (which == SDPLR_V_S_NZVAL || which == SDPLR_V_TRIU_S_NZVAL) ensure_S(s);
   if (L == 0) return SDPLR_OK;
   if (in_ctrl) {
-    int rc = pull(s);
+    int rc = pull_if_stale(s);
     if (rc) return rc;
     memcpy(h, p, L * sizeof(double));
     return SDPLR_OK;
@@ -1358,7 +1711,7 @@ int32_t sdplr_hip_get_vec(S* s, int32_t which, double* h, int64_t len) {
 int32_t sdplr_hip_set_scalar(S* s, int32_t which, double v) {
   ApiShared api_guard;
   NEED_FINAL(s);
-  int rc = pull(s);
+  int rc = pull_if_stale(s);
   if (rc) return rc;
   if (which == SDPLR_S_SIGMA) s->hc->sigma = v;
   else if (which == SDPLR_S_OBJ) s->hc->obj = v;
@@ -1373,7 +1726,7 @@ int32_t sdplr_hip_get_scalar(S* s, int32_t which, double* v) {
   ApiShared api_guard;
   NEED_FINAL(s);
   if (!v) return fail(s, SDPLR_ERR_INVALID_ARG, "get_scalar: null");
-  int rc = pull(s);
+  int rc = pull_if_stale(s);
   if (rc) return rc;
   if (which == SDPLR_S_SIGMA) *v = s->hc->sigma;
   else if (which == SDPLR_S_OBJ) *v = s->hc->obj;
@@ -1473,6 +1826,7 @@ void enq_A(S* s, const double* U, const double* V, int mode, double* out0, doubl
 }
 
 void enq_At_preprocess(S* s, int chk) {
+  s->S_from_y = true;
   if (s->n_sparse <= 0) return;
   {
     ProfScope ps(s, "assemble_triu");
@@ -1846,6 +2200,79 @@ void enq_iteration_fast2(S* s) {
   if (!upd_fused) enq_lbfgs_update(s, 1);                                             // :244-246
 }
 
+// ---- resident route for small instances (k_resident.h) ----------------------------------------------------------
+// One workgroup owns the instance for a whole inner loop / Lanczos run: one launch per call.
+constexpr size_t RS_LDS_MAX = 150 * 1024;   // dynamic LDS of a resident kernel (≈ 9.6 KB more are static: control block, reduction scratch, palette)
+double wall_clock_hz() {   // rate of wall_clock64() on this device
+  static const double hz = [] {
+    int dev = 0, khz = 0;
+    (void)hipGetDevice(&dev);
+    if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) != hipSuccess || khz <= 0) khz = 100000;
+    return 1e3 * (double)khz;
+  }();
+  return hz;
+}
+size_t rs_loop_lds(const S* s) {
+  const size_t N = (size_t)s->n * (size_t)s->r;
+  return (((N + 1) & ~(size_t)1) + 3 * (size_t)s->n) * sizeof(double);
+}
+// SDPLR_HIP_FORCE_GRAPH ("treat this instance as a large one": the tests' default) and SDPLR_HIP_NO_RESIDENT keep an
+// instance on the multi-launch routes.
+bool rs_loop_applies(const S* s, int armijo) {
+  if (!s->rs_ok || armijo || s->h < 1 || s->h > 4 || s->r > (int64_t)s->LPR * s->VEC || s->prof_on) return false;
+  if (s->force_graph || getenv("SDPLR_HIP_NO_RESIDENT") != nullptr) return false;
+  return rs_loop_lds(s) <= RS_LDS_MAX;
+}
+// the structured form: the instances of the resident loop (any rank), S = S(y) of the device's y
+bool rs_lanczos_ell_applies(const S* s) {
+  if (!s->rs_ok || !s->S_from_y || s->prof_on) return false;
+  if (s->force_graph || getenv("SDPLR_HIP_NO_RESIDENT") != nullptr || getenv("SDPLR_HIP_CLASSIC_LANCZOS") != nullptr) return false;
+  return (size_t)4 * s->n * sizeof(double) <= RS_LDS_MAX;
+}
+bool rs_fg_applies(const S* s) {
+  if (!s->rs_ok || s->r > (int64_t)s->LPR * s->VEC || s->prof_on) return false;
+  if (s->force_graph || getenv("SDPLR_HIP_NO_RESIDENT") != nullptr) return false;
+  return rs_loop_lds(s) <= RS_LDS_MAX;
+}
+bool rs_lanczos_applies(const S* s) {
+  if (s->force_graph || getenv("SDPLR_HIP_NO_RESIDENT") != nullptr || getenv("SDPLR_HIP_CLASSIC_LANCZOS") != nullptr) return false;
+  if (s->prof_on || !s->have_sparse || s->lr.ST > SDPLR_LRMAX) return false;
+  int64_t max_nnz = 1 << 14;   // (12 bytes per entry from L2 at ≈ 67 GB/s per CU: beyond this two launches per step are faster)
+  if (const char* e = getenv("SDPLR_HIP_RESIDENT_LZ_NNZ")) max_nnz = atoll(e);
+  return s->nnzS <= max_nnz && (size_t)3 * s->n * sizeof(double) <= RS_LDS_MAX;
+}
+// more than 64 KB of dynamic LDS has to be asked for: a per-function, process-wide attribute — set once per
+// instantiation, to the fixed upper bound
+#define RS_SET_ATTR(kernel)                                                                                          \
+  do {                                                                                                               \
+    static std::atomic<int> attr_done{0};                                                                            \
+    if (!attr_done.load(std::memory_order_acquire)) {                                                                \
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&kernel), hipFuncAttributeMaxDynamicSharedMemorySize,   \
+                              (int)RS_LDS_MAX) == hipSuccess)                                                       \
+        attr_done.store(1, std::memory_order_release);                                                               \
+    }                                                                                                                \
+  } while (0)
+
+int enq_resident_loop(S* s, double time_budget_s, bool refresh_P) {
+  RsLoopArgs a{};
+  a.n = (int)s->n; a.m = (int)s->m; a.r = (int)s->r; a.h = (int)s->h;
+  a.gid_g = s->ff.gid_g;
+  a.row_k = s->rs_row_k; a.row_v = s->rs_row_v;
+  a.E = s->rs_ell;
+  a.A = s->arena;
+  a.P = aslot(s->arena, 3 + 2 * (int)s->h); a.W = aslot(s->arena, 3 + 2 * (int)s->h + 1);
+  a.y = s->y; a.pv_raw = s->pv_raw; a.pv = s->pv; a.A_RD = s->A_RD; a.A_DD = s->A_DD;
+  a.lam = s->lambda; a.lam_ub = s->lambda_ub; a.lb = s->pv_lb;
+  a.c = s->ctrl;
+  a.refresh_P = refresh_P ? 1 : 0;
+  a.budget_ticks = time_budget_s > 0 ? std::max<long long>(1, (long long)(time_budget_s * wall_clock_hz())) : 0;
+  const size_t lds = rs_loop_lds(s);
+  LV_DISPATCH(({ RS_SET_ATTR((k_rs_loop<LPR, VEC, 4>)); k_rs_loop<LPR, VEC, 4><<<1, SDPLR_RS_NT, lds, s->stream>>>(a); }))
+  HIPCK(s, hipGetLastError());
+  s->st_rs_loops++;
+  return SDPLR_OK;
+}
+
 // host restatement of the Sturm bisection for the Lanczos tridiagonal
 int64_t sturm_below(const std::vector<double>& d, const double* e, int64_t k, double x) {
   int64_t cnt = 0;
@@ -1944,7 +2371,7 @@ int lz_hub_blocks(const S* s) { return s->sp.n_long_rows > 0 ? std::min((s->sp.n
 // one Lanczos step = k_lz_spmv (+ hub rows) + k_lz_step on the buffer triple (uprev, u, t)
 void enq_lz_step(S* s, double* uprev, double* u, double* t) {
   const int* stop = &s->ctrl->lz_done;
-  if (s->use_band) {   // LDS-band form (k_sparse.h, DevBand): partial t per (band, chunk), summed by the recurrence kernel
+  if (s->lz_band_now) {   // LDS-band form (k_sparse.h, DevBand): partial t per (band, chunk), summed by the recurrence kernel
     const DevBand& bd = s->band;
     const int nbk = bd.NB * bd.NC, nbl = lz_hub_blocks(s);
     {
@@ -1985,12 +2412,55 @@ int run_lanczos(S* s, int64_t q, const double* v0, double* alpha, double* beta, 
   if (q < 1) return fail(s, SDPLR_ERR_INVALID_ARG, "lanczos: q < 1 (needs n ≥ 2)");
   int rc = ensure_lz_capacity(s, q);
   if (rc) return rc;
+  if (rs_lanczos_ell_applies(s) || rs_lanczos_applies(s)) {   // resident route (k_resident.h): all q steps in one launch, the vectors in LDS
+    HIPCK(s, hipMemcpyAsync(s->lz_v0, v0, n * sizeof(double), hipMemcpyHostToDevice, s->stream));
+    HIPCK(s, hipMemsetAsync(s->lz_alpha, 0, q * sizeof(double), s->stream));
+    HIPCK(s, hipMemsetAsync(s->lz_beta, 0, q * sizeof(double), s->stream));
+    if (rs_lanczos_ell_applies(s)) {   // S(y) = y_g·A_g + Diag(d(y)) straight from the ELL of A_g and y: no assembled S is read
+      RsLzEllArgs a{};
+      a.n = (int)n; a.q = (int)q;
+      a.E = s->rs_ell; a.gid_g = s->ff.gid_g; a.row_k = s->rs_row_k; a.row_v = s->rs_row_v;
+      a.yvec = s->y; a.v0 = s->lz_v0;
+      a.alpha_out = s->lz_alpha; a.beta_out = s->lz_beta; a.c = s->ctrl;
+      const size_t base = (size_t)4 * n * sizeof(double), packed = s->rs_ell_pair_lines * 64 * sizeof(unsigned);
+      if (s->rs_ell.val == nullptr && base + packed <= RS_LDS_MAX && getenv("SDPLR_HIP_RESIDENT_LZ_STREAM") == nullptr) {
+        RS_SET_ATTR(k_rs_lanczos_ell<true>);
+        k_rs_lanczos_ell<true><<<1, SDPLR_RS_NT, base + packed, s->stream>>>(a);
+      } else {
+        RS_SET_ATTR(k_rs_lanczos_ell<false>);
+        k_rs_lanczos_ell<false><<<1, SDPLR_RS_NT, base, s->stream>>>(a);
+      }
+      HIPCK(s, hipGetLastError());
+      s->st_rs_lz++;
+      HIPCK(s, hipMemcpyAsync(alpha, s->lz_alpha, q * sizeof(double), hipMemcpyDeviceToHost, s->stream));
+      HIPCK(s, hipMemcpyAsync(beta, s->lz_beta, q * sizeof(double), hipMemcpyDeviceToHost, s->stream));
+      if ((rc = pull_blocking(s))) return rc;
+      *steps = s->hc->lz_steps;
+      return SDPLR_OK;
+    }
+    RsLzArgs a{};
+    a.n = (int)n; a.q = (int)q;
+    a.colptr = s->sp.colptr; a.rowval = s->sp.rowval; a.nzval = s->sp.nzval;
+    a.lr = s->lr; a.yvec = s->y; a.v0 = s->lz_v0;
+    a.alpha_out = s->lz_alpha; a.beta_out = s->lz_beta; a.c = s->ctrl;
+    RS_SET_ATTR(k_rs_lanczos);
+    k_rs_lanczos<<<1, SDPLR_RS_NT, (size_t)3 * n * sizeof(double), s->stream>>>(a);
+    HIPCK(s, hipGetLastError());
+    s->st_rs_lz++;
+    HIPCK(s, hipMemcpyAsync(alpha, s->lz_alpha, q * sizeof(double), hipMemcpyDeviceToHost, s->stream));
+    HIPCK(s, hipMemcpyAsync(beta, s->lz_beta, q * sizeof(double), hipMemcpyDeviceToHost, s->stream));
+    if ((rc = pull(s))) return rc;
+    *steps = s->hc->lz_steps;
+    return SDPLR_OK;
+  }
   if ((rc = pull(s))) return rc;
   DevCtrl* c = s->hc;
   c->lz_done = 0; c->lz_steps = 0; c->lz_beta_prev = 0.0; c->lz_gamma_cur = 1.0; c->lz_gamma_prev = 1.0; c->lz_qmax = q;
   if ((rc = push(s))) return rc;
   double *b0 = s->lz_buf[0], *b1 = s->lz_buf[1], *b2 = s->lz_buf[2];
-  if (s->use_band) {   // S is fixed for the q steps: the band layout's values are gathered once per run
+  // the palette form of the band plan takes the off-diagonal values from the live y: only when S is S(y)
+  s->lz_band_now = s->use_band && (!s->band.pal_mode || s->S_from_y);
+  if (s->lz_band_now) {   // S is fixed for the q steps: the band layout's values are gathered once per run
     ProfScope ps(s, "lanczos_init");
     if (s->band.pal_mode) k_lz_diag_fill<<<s->nb_n, SDPLR_NT, 0, s->stream>>>(s->band, (int)n, s->sp.nzval);
     else k_lz_band_fill<<<blocks_for((long long)(s->band.n_groups + 1) * 64, SDPLR_NT, 2048), SDPLR_NT, 0, s->stream>>>(s->band, s->sp.nzval);
@@ -2017,7 +2487,8 @@ int run_lanczos(S* s, int64_t q, const double* v0, double* alpha, double* beta, 
   if (const char* e = getenv("SDPLR_HIP_LZ_REPS")) reps = std::max(1, std::min(atoi(e), 64));
   if (s->lz_graph && s->lz_graph_reps != reps) { (void)hipGraphExecDestroy(s->lz_graph); s->lz_graph = nullptr; }
   const int64_t rounds = (q + 1 + 2) / 3;   // q steps + the closing k_lz_spmv of step q+1
-  bool use_graph = !s->prof_on && !s->graph_disabled && getenv("SDPLR_HIP_NO_GRAPH") == nullptr && (n >= (1 << 14) || s->force_graph);
+  bool use_graph = !s->prof_on && !s->graph_disabled && getenv("SDPLR_HIP_NO_GRAPH") == nullptr && (n >= (1 << 14) || s->force_graph) &&
+                   s->lz_band_now == s->use_band;   // (the captured steps are the band plan's when there is one)
   if (use_graph && !s->lz_graph && api_lock) {
     api_lock->unlock();
     {
@@ -2068,7 +2539,7 @@ extern "C" {
 
 int32_t sdplr_hip_A(S* s, int32_t u_slot, int32_t v_slot, int32_t out_vec) {
   ApiShared api_guard;
-  NEED_FINAL(s);
+  NEED_FINAL_RW(s);
   double* U = factor_ptr(s, u_slot);
   double* V = v_slot >= 0 ? factor_ptr(s, v_slot) : nullptr;
   if (!U || (v_slot >= 0 && !V)) return fail(s, SDPLR_ERR_INVALID_ARG, "A: bad factor slot");
@@ -2083,14 +2554,14 @@ int32_t sdplr_hip_A(S* s, int32_t u_slot, int32_t v_slot, int32_t out_vec) {
 }
 int32_t sdplr_hip_At_preprocess(S* s) {
   ApiShared api_guard;
-  NEED_FINAL(s);
+  NEED_FINAL_RW(s);
   enq_At_preprocess(s, 0);
   s->S_stale = false;
   return sync_check(s);
 }
 int32_t sdplr_hip_At_left(S* s, int32_t ys, int32_t xs) {
   ApiShared api_guard;
-  NEED_FINAL(s);
+  NEED_FINAL_RW(s);
   double *Y = factor_ptr(s, ys), *X = factor_ptr(s, xs);
   if (!Y || !X || Y == X) return fail(s, SDPLR_ERR_INVALID_ARG, "At_left: bad slots");
   ensure_S(s);
@@ -2100,7 +2571,7 @@ int32_t sdplr_hip_At_left(S* s, int32_t ys, int32_t xs) {
 }
 int32_t sdplr_hip_At_right(S* s, const double* x, double* yh, int64_t k) {
   ApiShared api_guard;
-  NEED_FINAL(s);
+  NEED_FINAL_RW(s);
   if (!x || !yh || k < 1) return fail(s, SDPLR_ERR_INVALID_ARG, "At_right: bad args");
   ensure_S(s);
   const int64_t n = s->n;
@@ -2115,7 +2586,7 @@ int32_t sdplr_hip_At_right(S* s, const double* x, double* yh, int64_t k) {
 
 int32_t sdplr_hip_At_right_device(S* s, const double* x, double* yd, int64_t k) {
   ApiShared api_guard;
-  NEED_FINAL(s);
+  NEED_FINAL_RW(s);
   if (!x || !yd || k < 1 || x == yd) return fail(s, SDPLR_ERR_INVALID_ARG, "At_right_device: bad args");
   hipPointerAttribute_t ax{}, ay{};
   if (hipPointerGetAttributes(&ax, x) != hipSuccess || hipPointerGetAttributes(&ay, yd) != hipSuccess ||
@@ -2131,9 +2602,9 @@ int32_t sdplr_hip_At_right_device(S* s, const double* x, double* yd, int64_t k) 
 
 int32_t sdplr_hip_get_stats(const S* s, int64_t* out, int32_t cap, int32_t* n_written) {
   if (!s || !out || cap < 0) return SDPLR_ERR_INVALID_ARG;
-  const int64_t v[8] = {s->st_captures, s->st_capture_failed, s->st_capture_skipped, s->st_graph_batches,
-                        s->st_eager_batches, s->st_lz_graph, s->st_lz_eager, s->st_iters};
-  const int32_t k = std::min<int32_t>(cap, 8);
+  const int64_t v[11] = {s->st_captures, s->st_capture_failed, s->st_capture_skipped, s->st_graph_batches,
+                         s->st_eager_batches, s->st_lz_graph, s->st_lz_eager, s->st_iters, s->st_rs_loops, s->st_rs_lz, s->st_rs_fg};
+  const int32_t k = std::min<int32_t>(cap, 11);
   for (int32_t i = 0; i < k; i++) out[i] = v[i];
   if (n_written) *n_written = k;
   return SDPLR_OK;
@@ -2141,7 +2612,7 @@ int32_t sdplr_hip_get_stats(const S* s, int64_t* out, int32_t cap, int32_t* n_wr
 
 int32_t sdplr_hip_f(S* s, double* L) {
   ApiShared api_guard;
-  NEED_FINAL(s);
+  NEED_FINAL_RW(s);
   enq_f(s);
   int rc = pull(s);
   if (rc) return rc;
@@ -2150,7 +2621,7 @@ int32_t sdplr_hip_f(S* s, double* L) {
 }
 int32_t sdplr_hip_g(S* s) {
   ApiShared api_guard;
-  NEED_FINAL(s);
+  NEED_FINAL_RW(s);
   enq_g(s, 0, false);
   s->S_stale = false;
   s->sg_stale = true;
@@ -2171,9 +2642,32 @@ int set_norm_params(S* s, double normC, double normb, int grel, int prel) {
 extern "C" {
 int32_t sdplr_hip_fg(S* s, double normC, double normb, int32_t grel, int32_t prel, double* L, double* gn, double* pn) {
   ApiShared api_guard;
-  NEED_FINAL(s);
+  NEED_FINAL_RW(s);
   int rc = set_norm_params(s, normC, normb, grel, prel);
   if (rc) return rc;
+  if (rs_fg_applies(s)) {   // resident route (k_resident.h): one launch; P = A_g·R stays for the loop that follows
+    RsFgArgs a{};
+    a.n = (int)s->n; a.m = (int)s->m; a.r = (int)s->r;
+    a.gid_g = s->ff.gid_g; a.row_k = s->rs_row_k; a.row_v = s->rs_row_v; a.E = s->rs_ell;
+    a.R = aslot(s->arena, AS_R); a.G = aslot(s->arena, AS_G); a.P = aslot(s->arena, 3 + 2 * (int)s->h);
+    a.y = s->y; a.pv_raw = s->pv_raw; a.pv = s->pv;
+    a.lam = s->lambda; a.lam_ub = s->lambda_ub; a.lb = s->pv_lb; a.b = s->b;
+    a.c = s->ctrl;
+    const size_t lds = rs_loop_lds(s);
+    LV_DISPATCH(({ RS_SET_ATTR((k_rs_fg<LPR, VEC>)); k_rs_fg<LPR, VEC><<<1, SDPLR_RS_NT, lds, s->stream>>>(a); }))
+    HIPCK(s, hipGetLastError());
+    s->P_valid = true;
+    s->P_age = 0;
+    s->S_stale = true;   // y is current; S is assembled by whoever reads it (ensure_S)
+    s->S_from_y = true;
+    s->sg_stale = true;
+    s->st_rs_fg++;
+    if ((rc = pull(s))) return rc;
+    if (L) *L = s->hc->L;
+    if (gn) *gn = s->hc->gnorm;
+    if (pn) *pn = s->hc->pvnorm;
+    return sync_check(s);
+  }
   enq_f(s);
   enq_g(s, 0, false);
   s->S_stale = false;
@@ -2191,7 +2685,7 @@ int32_t sdplr_hip_fg(S* s, double normC, double normb, int32_t grel, int32_t pre
 }
 int32_t sdplr_hip_norms(S* s, double normC, double normb, int32_t grel, int32_t prel, double* gn, double* pn) {
   ApiShared api_guard;
-  NEED_FINAL(s);
+  NEED_FINAL_RW(s);
   int rc = set_norm_params(s, normC, normb, grel, prel);
   if (rc) return rc;
   {
@@ -2207,7 +2701,7 @@ int32_t sdplr_hip_norms(S* s, double normC, double normb, int32_t grel, int32_t 
 }
 int32_t sdplr_hip_axpy_R(S* s, double alpha) {
   ApiShared api_guard;
-  NEED_FINAL(s);
+  NEED_FINAL_RW(s);
   int rc = pull(s);
   if (rc) return rc;
   s->hc->alpha = alpha;
@@ -2218,7 +2712,7 @@ int32_t sdplr_hip_axpy_R(S* s, double alpha) {
 }
 int32_t sdplr_hip_update_lambda(S* s) {
   ApiShared api_guard;
-  NEED_FINAL(s);
+  NEED_FINAL_RW(s);
   k_update_lambda<<<s->nb_m, SDPLR_NT, 0, s->stream>>>(s->ctrl, (int)s->m, s->lambda, s->lambda_ub, s->pv_raw);
   return sync_check(s);
 }
@@ -2226,11 +2720,9 @@ int32_t sdplr_hip_update_lambda(S* s) {
 // ---- L-BFGS ------------------------------------------------------------------------------------------
 int32_t sdplr_hip_lbfgs_clear(S* s) {
   ApiShared api_guard;
-  NEED_FINAL(s);
-  for (int j = 0; j < (int)s->h; j++) {
-    HIPCK(s, hipMemsetAsync(aslot(s->arena, AS_S0 + j), 0, s->N * sizeof(double), s->stream));
-    HIPCK(s, hipMemsetAsync(aslot(s->arena, as_y0(s->arena) + j), 0, s->N * sizeof(double), s->stream));
-  }
+  NEED_FINAL_RW(s);
+  // the 2h history slots are neighbours in the arena: one fill (a small solve clears the history once per major iteration)
+  if (s->h > 0) HIPCK(s, hipMemsetAsync(aslot(s->arena, AS_S0), 0, (size_t)2 * s->h * s->arena.stride * sizeof(double), s->stream));
   int rc = pull(s);
   if (rc) return rc;
   memset(s->hc->rho, 0, sizeof s->hc->rho); memset(s->hc->a, 0, sizeof s->hc->a);
@@ -2242,7 +2734,7 @@ int32_t sdplr_hip_lbfgs_clear(S* s) {
 }
 int32_t sdplr_hip_lbfgs_dir(S* s, int32_t negate, double* descent) {
   ApiShared api_guard;
-  NEED_FINAL(s);
+  NEED_FINAL_RW(s);
   ensure_gram(s);
   enq_lbfgs_dir(s, negate ? 1 : 0, 0, 0);
   if (s->h > 0) s->ynext_pending = true;
@@ -2253,14 +2745,14 @@ int32_t sdplr_hip_lbfgs_dir(S* s, int32_t negate, double* descent) {
 }
 int32_t sdplr_hip_descent_fallback(S* s) {
   ApiShared api_guard;
-  NEED_FINAL(s);
+  NEED_FINAL_RW(s);
   k_neg_copy<<<s->nb_dense, SDPLR_NT, 0, s->stream>>>(aslot(s->arena, AS_G), aslot(s->arena, AS_D), s->N);
   s->sg_stale = true;
   return sync_check(s);
 }
 int32_t sdplr_hip_lbfgs_update(S* s, double stepsize) {
   ApiShared api_guard;
-  NEED_FINAL(s);
+  NEED_FINAL_RW(s);
   if (s->h == 0) return SDPLR_OK;
   if (s->gram_dirty) {  // rows other than the updated one must be valid first
     s->ynext_pending = false;
@@ -2274,6 +2766,7 @@ int32_t sdplr_hip_lbfgs_update(S* s, double stepsize) {
   enq_boundary(s, 0, 1, 0, 0);
   s->ynext_pending = false;
   s->sg_stale = false;
+  s->hc_valid = false;   // (the seam kernel has just rewritten ρ, latest and the Gram data on the device)
   return sync_check(s);
 }
 
@@ -2298,12 +2791,12 @@ static int32_t linesearch_common(S* s, int armijo, double alpha_max, double* alp
 }
 int32_t sdplr_hip_linesearch(S* s, double alpha_max, double* alpha, double* L) {
   ApiShared api_guard;
-  NEED_FINAL(s);
+  NEED_FINAL_RW(s);
   return linesearch_common(s, 0, alpha_max, alpha, L);
 }
 int32_t sdplr_hip_linesearch_armijo(S* s, double alpha_max, double* alpha, double* L) {
   ApiShared api_guard;
-  NEED_FINAL(s);
+  NEED_FINAL_RW(s);
   return linesearch_common(s, 1, alpha_max, alpha, L);
 }
 
@@ -2313,7 +2806,7 @@ int32_t sdplr_hip_inner_loop(S* s, double normC, double normb, int32_t grel, int
                              double* Lio, double* gnio, double* pnio, double* last_alpha, int64_t* iters,
                              int32_t* exit_reason) {
   ApiLock api_lock(g_api_rw);
-  NEED_FINAL(s);
+  NEED_FINAL_RW(s);
   if (!Lio || !gnio || !pnio || max_local_iters < 1) return fail(s, SDPLR_ERR_INVALID_ARG, "inner_loop: bad args");
   ensure_gram(s);
   int rc = tile_lds_attr(s);
@@ -2331,6 +2824,37 @@ int32_t sdplr_hip_inner_loop(S* s, double normC, double normb, int32_t grel, int
   // once `done` is set the remaining kernels of a batch fall through.  The control block is
   // snapshotted after each batch, and batch k+1 is already queued while the host inspects the
   // snapshot of batch k, so the GPU never waits for the host.
+  if (rs_loop_applies(s, use_armijo)) {
+    // resident route (k_resident.h): the whole while loop is ONE launch of one workgroup; every exit — the time
+    // budget too — is taken on the device, the host reads the control block once
+    static const int64_t refresh_iters = getenv("SDPLR_HIP_P_REFRESH_ITERS") ? atoll(getenv("SDPLR_HIP_P_REFRESH_ITERS")) : 256;
+    const bool refresh = !s->P_valid || s->P_age >= refresh_iters;
+    if ((rc = enq_resident_loop(s, time_budget_s, refresh))) return rc;
+    s->P_valid = true;
+    if (refresh) s->P_age = 0;
+    s->S_stale = true;   // y is current, S is assembled by whoever reads it next (ensure_S)
+    s->S_from_y = true;
+    if ((rc = pull_blocking(s))) return rc;
+    const int why_rs = c->exit_reason;
+    if (c->iters > 0 && c->err == 0 && why_rs != EXIT_RELDELTA) {
+      // `dirt *= α` (src/lbfgs.jl:142) is left to this copy: dirt = s_latest
+      HIPCK(s, hipMemcpyAsync(aslot(s->arena, AS_D), aslot(s->arena, AS_S0 + (c->latest - 1)), s->N * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
+    }
+    s->sg_stale = (why_rs == EXIT_RELDELTA);
+    s->ynext_pending = (why_rs == EXIT_RELDELTA) && s->h > 0;
+    if (c->err == SDPLR_ERR_NOT_DESCENT) {
+      c->err = 0; c->done = 0;
+      (void)push(s);
+      return fail(s, SDPLR_ERR_NOT_DESCENT, "Error: cubic[1] should be less than 0.");
+    }
+    s->st_iters += c->iters;
+    s->P_age += c->iters;
+    *Lio = c->L; *gnio = c->gnorm; *pnio = c->pvnorm;
+    if (last_alpha) *last_alpha = c->alpha;
+    if (iters) *iters = c->iters;
+    if (exit_reason) *exit_reason = why_rs;
+    return sync_check(s);
+  }
   const int ar = use_armijo ? 1 : 0;
   const bool fastp = s->fast;
   const bool fast2 = fastp && s->fast_singleton && !use_armijo;
@@ -2469,7 +2993,7 @@ int32_t sdplr_hip_inner_loop(S* s, double normC, double normb, int32_t grel, int
   const bool loop_fused = fastp ? step_fuses_update(s) : spmm_fuses_update(s);   // lbfgs_update! rode another kernel
   s->gram_nb = !loop_fused ? s->nb_upd : (fastp ? s->nb_step : spmm_upd_blocks(s));
   enq_boundary(s, 0, 1, 0, 0);
-  if (fastp || edgep) s->S_stale = true;   // y is current, S is assembled by whoever reads it next (ensure_S)
+  if (fastp || edgep) { s->S_stale = true; s->S_from_y = true; }   // y is current, S is assembled by whoever reads it next (ensure_S)
   if ((rc = pull(s))) return rc;
   if (c->done) why = c->exit_reason;   // the device's verdict wins over the host's time check
   if (loop_fused && c->iters > 0 && c->err == 0 && why != EXIT_RELDELTA) {
@@ -2500,7 +3024,7 @@ int32_t sdplr_hip_inner_loop(S* s, double normC, double normb, int32_t grel, int
 // ---- Lanczos / dual bound ------------------------------------------------------------------------------
 int32_t sdplr_hip_lanczos(S* s, int64_t q, const double* v0, double* alpha, double* beta, int64_t* steps) {
   ApiShared api_guard;
-  NEED_FINAL(s);
+  NEED_FINAL_RW(s);
   if (!v0 || !alpha || !beta || !steps || q < 1) return fail(s, SDPLR_ERR_INVALID_ARG, "lanczos: bad args");
   ensure_S(s);
   return run_lanczos(s, q, v0, alpha, beta, steps, &api_guard.l);
@@ -2533,18 +3057,23 @@ static int32_t approx_mineig_impl(S* s, int64_t q, const double* v0, double* min
 }
 int32_t sdplr_hip_approx_mineigval_lanczos(S* s, int64_t q, const double* v0, double* mineig) {
   ApiShared api_guard;
-  NEED_FINAL(s);
+  NEED_FINAL_RW(s);
   if (!v0 || !mineig || q < 1) return fail(s, SDPLR_ERR_INVALID_ARG, "approx_mineigval_lanczos: bad args");
   ensure_S(s);
   return approx_mineig_impl(s, q, v0, mineig, &api_guard.l);
 }
 int32_t sdplr_hip_dual_obj(S* s, double trace_bound, int64_t iter, const double* v0, double* dual_value, double* mineig) {
   ApiShared api_guard;
-  NEED_FINAL(s);
+  NEED_FINAL_RW(s);
   if (!v0) return fail(s, SDPLR_ERR_INVALID_ARG, "dual_obj: null v0");
   enq_copy2y(s, 0);              // src/coreop.jl:384
-  enq_At_preprocess(s, 0);       // :385
-  s->S_stale = false;
+  s->S_from_y = true;
+  if (rs_lanczos_ell_applies(s)) {
+    s->S_stale = true;           // the structured Lanczos takes S from y: S is assembled (:385) only if somebody reads it
+  } else {
+    enq_At_preprocess(s, 0);     // :385
+    s->S_stale = false;
+  }
   const double it = (double)std::max<int64_t>(iter, 100);
   const int64_t eig_iter = (int64_t)(2 * std::ceil(std::pow(it, 0.5) * std::log((double)s->n)));  // :402
   double ev = 0.0;
@@ -2614,7 +3143,7 @@ extern "C" {
 int32_t sdplr_hip_S_eigval(S* s, int64_t nev, int32_t which, int64_t ncv_in, double tol, int64_t maxiter,
                            const double* v0, double* evals, int64_t* n_matvec, int64_t* n_converged) {
   ApiShared api_guard;
-  NEED_FINAL(s);
+  NEED_FINAL_RW(s);
   const int64_t n = s->n;
   if (!evals || nev < 1 || nev > n || (which != 0 && which != 1) || maxiter < 1)
     return fail(s, SDPLR_ERR_INVALID_ARG, "S_eigval: bad args");
@@ -2722,7 +3251,7 @@ int32_t sdplr_hip_S_eigval(S* s, int64_t nev, int32_t which, int64_t ncv_in, dou
 // dot of two factor-shaped arrays on the device (err6 = dot(Rt, Rt·S), src/coreop.jl:449)
 int32_t sdplr_hip_factor_dot(S* s, int32_t slot_a, int32_t slot_b, double* out) {
   ApiShared api_guard;
-  NEED_FINAL(s);
+  NEED_FINAL_RW(s);
   double *a = factor_ptr(s, slot_a), *b = factor_ptr(s, slot_b);
   if (!a || !b || !out) return fail(s, SDPLR_ERR_INVALID_ARG, "factor_dot: bad args");
   k_dot_flat<<<s->nb_dense, SDPLR_NT, 0, s->stream>>>(a, b, s->N, SLOT_DUALYB, s->partials);

@@ -58,7 +58,7 @@ def _positions_in_pattern(colptr: np.ndarray, rowval: np.ndarray, n: int, I: np.
         _sparsetools.csr_sample_values(n, n, colptr, rowval, np.arange(1, nnz + 1, dtype=np.int64), I.size,
                                        np.ascontiguousarray(J), np.ascontiguousarray(I), out)
         return out - 1
-    except (ImportError, AttributeError, TypeError):       # another scipy: sorted keys instead
+    except (ImportError, AttributeError, TypeError, ValueError):       # another scipy: sorted keys instead
         keys = np.repeat(np.arange(n, dtype=np.int64), np.diff(colptr)) * n + rowval
         want = J * n + I
         pos = np.minimum(np.searchsorted(keys, want), nnz - 1)
@@ -105,11 +105,17 @@ def preprocess_sparsecons(batch: SparseBatch) -> AggregatedLayout:
     trows = np.repeat(np.arange(n, dtype=np.int64), np.diff(T.indptr))
     strict = T.indices > trows
     lower = ~in_upper
-    if (int(lower.sum()) != int(strict.sum()) or not np.array_equal(full_rowval[lower], T.indices[strict])
-            or not np.array_equal(fcols[lower], trows[strict])):
-        raise ValueError("a constraint matrix is not symmetric: a lower-triangular entry has no "
-                         "upper-triangular mirror in the aggregated pattern")
-    mapped[lower] = T.data[strict] - 1
+    if (int(lower.sum()) == int(strict.sum()) and np.array_equal(full_rowval[lower], T.indices[strict])
+            and np.array_equal(fcols[lower], trows[strict])):
+        mapped[lower] = T.data[strict] - 1
+    else:
+        # not every strictly-upper entry has its lower mirror (e.g. upper-triangular-only input, which the reference's
+        # search accepts): look the lower entries up one by one, as src/preprocess.jl:143-156 does
+        pos = _positions_in_pattern(triu_colptr, triu_rowval, n, fcols[lower], full_rowval[lower])
+        if pos.size and pos.min() < 0:
+            raise ValueError("a constraint matrix is not symmetric: a lower-triangular entry has no "
+                             "upper-triangular mirror in the aggregated pattern")
+        mapped[lower] = pos
     return AggregatedLayout(n, batch.n_matrices, matptr.astype(np.int64), nzind, nzval_one,
                             nzval_two, batch.global_inds.astype(np.int64), triu_colptr,
                             triu_rowval, full_colptr, full_rowval, mapped)

@@ -47,14 +47,20 @@ def initial_point(data: SDPData, r: int, config: BurerMonteiroConfig):
 
 
 def build_solver(abi: CABI, data: SDPData, r: int, config: BurerMonteiroConfig,
-                 layout=None) -> DeviceSolver:
+                 layout=None, native_preprocess: bool = True) -> DeviceSolver:
     """SolverVars + SolverAuxiliary + lbfgs_init behind one handle
-    (src/sdplr.jl:114-123,163; src/structs.jl:242-263,296-361)."""
+    (src/sdplr.jl:114-123,163; src/structs.jl:242-263,296-361).  ``preprocess_sparsecons`` (src/preprocess.jl:24-169)
+    runs inside the library (``set_sparse_coo``) unless a ready ``layout`` is handed in or ``native_preprocess`` is
+    off, in which case the host-side mirror (``preprocess.py``) builds the arrays and ``set_sparse`` takes them."""
     s = DeviceSolver(abi, data.n, data.m, r, config.numlbfgsvecs)
     if data.sparse.n_matrices > 0:
-        lay = layout if layout is not None else preprocess_sparsecons(data.sparse)
-        s.set_sparse(lay)
-        s.layout = lay
+        if layout is None and native_preprocess:
+            s.set_sparse_coo(data.sparse)
+            s.layout = None
+        else:
+            lay = layout if layout is not None else preprocess_sparsecons(data.sparse)
+            s.set_sparse(lay)
+            s.layout = lay
     for gid, A in data.lowrank:
         s.add_symlowrank(gid, A)
     s.finalize()

@@ -1,0 +1,335 @@
+"""GPU parity tests of the RESIDENT route (sdplrplus.jl_amd/csrc/k_resident.h): on a small instance one workgroup
+owns the instance for a whole inner `while` (src/sdplr.jl:190-278) — ONE launch per call of the loop — and one launch
+runs a whole Lanczos recurrence (src/coreop.jl:461-500).  BASELINE config 5 (n = 800, rank 10: exps/batch_test.txt:1-9)
+takes this route.  The rest of the GPU suite runs with SDPLR_HIP_FORCE_GRAPH=1 ("treat the instance as a large one"),
+which keeps its tiny instances on the multi-launch routes; the tests here remove it.
+
+Every comparison is the same call sequence on the HIP library and on the CPU oracle (tolerances in the asserts), plus
+the multi-launch route of the HIP library itself (SDPLR_HIP_NO_RESIDENT=1)."""
+import os
+
+import numpy as np
+import pytest
+
+import sdplrplus_jl_amd as sj
+from sdplrplus_jl_amd import cabi, problems
+
+from helpers import make_data, make_solver
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    return float(np.max(np.abs(np.asarray(a) - np.asarray(b))) / max(1e-300, float(np.max(np.abs(b)))))
+
+
+@pytest.fixture(autouse=True)
+def _small_instances_take_their_own_route(monkeypatch):
+    monkeypatch.delenv("SDPLR_HIP_FORCE_GRAPH", raising=False)
+    monkeypatch.delenv("SDPLR_HIP_NO_RESIDENT", raising=False)
+
+
+def pair(hip_abi, oracle_abi, data, r, seed, h=4):
+    g, _ = make_solver(hip_abi, data, r, seed=seed, h=h)
+    o, _ = make_solver(oracle_abi, data, r, seed=seed, h=h)
+    return g, o
+
+
+def gset(name="G1"):
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "gset_G1_G9.npz"))
+    return problems.graph_from_edges(int(z[f"{name}_n"]), z[name])
+
+
+LOOP = dict(gtol=0.0, fprec=-1e300)
+
+
+def run(s, normC, normb, k, st, gtol=0.0, fprec=-1e300, budget=0.0):
+    return s.inner_loop(normC, normb, True, True, False, gtol, fprec, k, budget, *st)
+
+
+@pytest.mark.parametrize("family,n,r,h", [("maxcut", 12, 3, 4), ("maxcut", 40, 8, 1), ("maxcut", 40, 10, 2),
+                                          ("cutnorm", 14, 5, 4), ("maxcut", 30, 2, 3)])
+def test_resident_loop_iteration_by_iteration(hip_abi, oracle_abi, family, n, r, h):
+    """One iteration per call, eight calls: ℒ, ‖grad‖, ‖pv‖ to 1e-8 (north_star's tolerance), R, G, y, primal_vio_raw,
+    dirt (restored from s_latest on the way out), the history bookkeeping; every call must have been ONE resident
+    launch."""
+    data, *_ = make_data(family, 2, n, 0.4)
+    g, o = pair(hip_abi, oracle_abi, data, r, 11, h=h)
+    normC, normb = data.normC(), float(np.linalg.norm(data.b))
+    sg, so = g.fg(normC, normb), o.fg(normC, normb)
+    assert np.allclose(sg, so, rtol=1e-11)
+    # fg! itself was one launch (k_rs_fg): G, y, primal_vio_raw, primal_vio and the objective it leaves behind
+    assert g.stats()["resident_fg"] == 1
+    assert rel(g.Gt, o.Gt) < 1e-12 and rel(g.y, o.y) < 1e-12 and rel(g.primal_vio_raw, o.primal_vio_raw) < 1e-12
+    assert rel(g.get_vec(cabi.V_PV), o.get_vec(cabi.V_PV)) < 1e-12 and g.obj == pytest.approx(o.obj, rel=1e-13)
+    for it in range(8):
+        rg, ro = run(g, normC, normb, 1, sg), run(o, normC, normb, 1, so)
+        assert rg[4] == ro[4] == 1 and rg[5] == ro[5] == 2
+        assert np.allclose(rg[:3], ro[:3], rtol=1e-8, atol=1e-12), (it, rg, ro)
+        assert rg[3] == pytest.approx(ro[3], rel=1e-6)                       # α*
+        assert rel(g.Rt, o.Rt) < 1e-8 and rel(g.Gt, o.Gt) < 1e-7
+        assert rel(g.dirt, o.dirt) < 1e-7
+        assert rel(g.y, o.y) < 1e-8 and rel(g.primal_vio_raw, o.primal_vio_raw) < 1e-8
+        assert g.obj == pytest.approx(o.obj, rel=1e-9)
+        assert g.get_scalar(cabi.S_LBFGS_LATEST) == o.get_scalar(cabi.S_LBFGS_LATEST)
+        sg, so = rg[:3], ro[:3]
+    st = g.stats()
+    assert st["resident_loops"] == 8 and st["graph_batches"] == 0 and st["eager_batches"] == 0
+    assert np.allclose(g.get_vec(cabi.V_LBFGS_RHO), o.get_vec(cabi.V_LBFGS_RHO), rtol=1e-6)
+    for j in range(h):
+        assert rel(g.get_factor(cabi.F_LBFGS_S + j), o.get_factor(cabi.F_LBFGS_S + j)) < 1e-6
+        assert rel(g.get_factor(cabi.F_LBFGS_Y + j), o.get_factor(cabi.F_LBFGS_Y + j)) < 1e-6
+    g.close(); o.close()
+
+
+def test_resident_loop_exits_and_continuations(hip_abi, oracle_abi):
+    """All four exits of src/sdplr.jl:190-278 taken ON THE DEVICE inside one launch, and the state each leaves behind
+    carries on like the oracle's: gradient test (:190), iteration budget (:272-277), relative decrease (:238-241,
+    which skips lbfgs_update! and leaves dirt unscaled and y_next = −G_old parked), time budget."""
+    data, *_ = make_data("maxcut", 2, 60, 0.2)
+    g, o = pair(hip_abi, oracle_abi, data, 6, 11)
+    normC, normb = data.normC(), float(np.linalg.norm(data.b))
+    sg, so = g.fg(normC, normb), o.fg(normC, normb)
+    rg = run(g, normC, normb, 500, sg, gtol=0.02 * sg[1])
+    ro = run(o, normC, normb, 500, so, gtol=0.02 * so[1])
+    assert rg[4] == ro[4] > 3 and rg[5] == ro[5] == 0
+    assert np.allclose(rg[:3], ro[:3], rtol=1e-6) and rel(g.dirt, o.dirt) < 1e-5
+    rg, ro = run(g, normC, normb, 5, rg[:3]), run(o, normC, normb, 5, ro[:3])
+    assert rg[4] == ro[4] == 5 and rg[5] == ro[5] == 2 and np.allclose(rg[:3], ro[:3], rtol=1e-6)
+    rg, ro = run(g, normC, normb, 50, rg[:3], fprec=1e300), run(o, normC, normb, 50, ro[:3], fprec=1e300)
+    assert rg[4] == ro[4] == 1 and rg[5] == ro[5] == 1
+    assert rel(g.dirt, o.dirt) < 1e-5 and rel(g.Gt, o.Gt) < 1e-5
+    rg, ro = run(g, normC, normb, 4, rg[:3]), run(o, normC, normb, 4, ro[:3])
+    assert rg[4] == ro[4] == 4 and np.allclose(rg[:3], ro[:3], rtol=1e-5) and rel(g.Rt, o.Rt) < 1e-5
+    # already converged for the gradient tolerance asked for: no iteration, nothing touched
+    R_before, D_before = g.Rt, g.dirt
+    r0 = run(g, normC, normb, 10, rg[:3], gtol=10.0 * rg[1])
+    assert r0[4] == 0 and r0[5] == 0 and np.array_equal(g.Rt, R_before) and np.array_equal(g.dirt, D_before)
+    # time budget: the device watches its own clock; whatever count it reached, the oracle at that count agrees
+    rt = run(g, normC, normb, 1_000_000, rg[:3], budget=2e-3)
+    assert rt[5] == 3 and 0 < rt[4] < 1_000_000, rt
+    ro = run(o, normC, normb, int(rt[4]), ro[:3])
+    assert ro[4] == rt[4]
+    assert g.stats()["resident_loops"] == 6
+    g.close(); o.close()
+
+
+@pytest.mark.parametrize("r", [1, 2, 5, 16, 33, 64])
+def test_resident_loop_over_ranks(hip_abi, oracle_abi, r):
+    """Every sub-wave shape (odd ranks: 8-byte lanes; r = 33: a whole wave per row with 31 idle lanes)."""
+    data, *_ = make_data("maxcut", 4, 50, 0.2)
+    g, o = pair(hip_abi, oracle_abi, data, r, 5)
+    normC, normb = data.normC(), float(np.linalg.norm(data.b))
+    sg, so = g.fg(normC, normb), o.fg(normC, normb)
+    rg, ro = run(g, normC, normb, 6, sg), run(o, normC, normb, 6, so)
+    assert rg[4] == ro[4] == 6 and g.stats()["resident_loops"] == 1
+    assert np.allclose(rg[:3], ro[:3], rtol=1e-8, atol=1e-12)
+    assert rel(g.Rt, o.Rt) < 1e-8 and rel(g.Gt, o.Gt) < 1e-7
+    g.close(); o.close()
+
+
+def test_resident_loop_agrees_with_the_multi_launch_route(hip_abi, monkeypatch):
+    """The same library on its two routes for a config-5 instance (Gset G1, rank 10): 30 iterations, P refreshed at the
+    entry of the second call as well (SDPLR_HIP_P_REFRESH_ITERS is process-wide, so R is written from the host)."""
+    data = problems.maxcut_data(gset("G1"))
+    normC, normb = data.normC(), float(np.linalg.norm(data.b))
+    out = {}
+    for route in ("resident", "launches"):
+        if route == "launches":
+            monkeypatch.setenv("SDPLR_HIP_NO_RESIDENT", "1")
+        g, _ = make_solver(hip_abi, data, 10, seed=0)
+        st = g.fg(normC, normb)
+        res = run(g, normC, normb, 20, st)
+        g.set_factor(cabi.F_RT, g.Rt)                 # R "written outside the loop": P = A_g·R is rebuilt at entry
+        st2 = g.fg(normC, normb)
+        res2 = run(g, normC, normb, 10, st2)
+        out[route] = (res, res2, g.Rt, g.Gt, g.y, g.stats())
+        g.close()
+    a, b = out["resident"], out["launches"]
+    assert a[5]["resident_loops"] == 2 and b[5]["resident_loops"] == 0
+    assert a[0][4] == b[0][4] == 20 and a[1][4] == b[1][4] == 10
+    assert np.allclose(a[0][:3], b[0][:3], rtol=1e-9) and np.allclose(a[1][:3], b[1][:3], rtol=1e-8)
+    assert rel(a[2], b[2]) < 1e-8 and rel(a[3], b[3]) < 1e-7 and rel(a[4], b[4]) < 1e-8
+
+
+def test_resident_loop_on_a_config5_instance_vs_oracle(hip_abi, oracle_abi):
+    """Gset G1 (n = 800, nnz = 38 352, rank 10 — exps/batch_test.txt:1): 25 iterations in one launch against the oracle,
+    north_star's 1e-8 on ℒ / ‖grad‖ / objective."""
+    data = problems.maxcut_data(gset("G1"))
+    g, o = pair(hip_abi, oracle_abi, data, 10, 0)
+    normC, normb = data.normC(), float(np.linalg.norm(data.b))
+    sg, so = g.fg(normC, normb), o.fg(normC, normb)
+    rg, ro = run(g, normC, normb, 25, sg), run(o, normC, normb, 25, so)
+    assert rg[4] == ro[4] == 25
+    assert np.allclose(rg[:3], ro[:3], rtol=1e-8)
+    assert g.obj == pytest.approx(o.obj, rel=1e-8)
+    assert rel(g.Rt, o.Rt) < 1e-7
+    g.close(); o.close()
+
+
+def test_resident_loop_rows_beyond_the_register_window_and_without_constraints(hip_abi, oracle_abi):
+    """n = 1500 > 2 × 512: the third row of a thread takes its constraint data from memory; and a problem whose
+    constraints cover only some rows (the others have d_j = 0)."""
+    data = problems.maxcut_data(problems.gnp_graph(1500, 0.01, 8))
+    g, o = pair(hip_abi, oracle_abi, data, 4, 3)
+    normC, normb = data.normC(), float(np.linalg.norm(data.b))
+    sg, so = g.fg(normC, normb), o.fg(normC, normb)
+    rg, ro = run(g, normC, normb, 6, sg), run(o, normC, normb, 6, so)
+    assert g.stats()["resident_loops"] == 1
+    assert rg[4] == ro[4] == 6 and np.allclose(rg[:3], ro[:3], rtol=1e-8) and rel(g.Rt, o.Rt) < 1e-8
+    g.close(); o.close()
+    import scipy.sparse as sp
+    rng = np.random.Generator(np.random.PCG64(5))
+    n = 40
+    A = problems.make_random_graph(n, 0.3, rng)
+    C, As, bs = problems.maxcut(A)
+    keep = [i for i in range(n) if i % 3 != 1]          # rows 1, 4, 7, … carry no constraint
+    data = sj.SDPData(C, [As[i] for i in keep], np.asarray([bs[i] for i in keep]))
+    g, o = pair(hip_abi, oracle_abi, data, 4, 3)
+    normC, normb = data.normC(), float(np.linalg.norm(data.b))
+    sg, so = g.fg(normC, normb), o.fg(normC, normb)
+    rg, ro = run(g, normC, normb, 4, sg), run(o, normC, normb, 4, so)
+    assert g.stats()["resident_loops"] == 1
+    assert rg[4] == ro[4] == 4 and np.allclose(rg[:3], ro[:3], rtol=1e-8) and rel(g.Rt, o.Rt) < 1e-8
+    g.close(); o.close()
+
+
+@pytest.mark.parametrize("h", [1, 2, 4])
+def test_resident_loop_takes_the_steepest_descent_fallback(hip_abi, oracle_abi, h):
+    """src/sdplr.jl:201-205 inside the resident launch (the descent test comes from the Gram data, the DIR phase applies
+    G ← −G; dir ← G): a history whose newest pair the host has replaced by (s = G, y = 0, ρ ≪ 0)."""
+    data, *_ = make_data("maxcut", 4, 14, 0.4)
+    g, o = pair(hip_abi, oracle_abi, data, 3, 13, h=h)
+    normC, normb = data.normC(), float(np.linalg.norm(data.b))
+    sg, so = g.fg(normC, normb), o.fg(normC, normb)
+    sg, so = run(g, normC, normb, h + 1, sg)[:3], run(o, normC, normb, h + 1, so)[:3]
+    for s_ in (g, o):
+        j = int(s_.get_scalar(cabi.S_LBFGS_LATEST)) - 1
+        G = s_.Gt
+        s_.set_factor(cabi.F_LBFGS_S + j, G)
+        s_.set_factor(cabi.F_LBFGS_Y + j, np.zeros_like(G))
+        rho = s_.get_vec(cabi.V_LBFGS_RHO)
+        rho[j] = -1e6 / float(np.sum(G * G))
+        s_.set_vec(cabi.V_LBFGS_RHO, rho)
+    for it in range(3):
+        rg, ro = run(g, normC, normb, 1, sg), run(o, normC, normb, 1, so)
+        assert rg[4] == ro[4] == 1
+        assert np.allclose(rg[:3], ro[:3], rtol=1e-8, atol=1e-12), (it, rg, ro)
+        assert rel(g.Rt, o.Rt) < 1e-8 and rel(g.Gt, o.Gt) < 1e-7
+        sg, so = rg[:3], ro[:3]
+    assert g.stats()["resident_loops"] >= 4
+    g.close(); o.close()
+
+
+def test_resident_loop_is_run_to_run_deterministic_and_reports_not_descent(hip_abi):
+    data = problems.maxcut_data(problems.gnp_graph(300, 0.05, 7))
+    normC, normb = data.normC(), float(np.linalg.norm(data.b))
+    seen = set()
+    for rep in range(3):
+        g, _ = make_solver(hip_abi, data, 8, seed=2)
+        st = g.fg(normC, normb)
+        out = run(g, normC, normb, 40, st)
+        seen.add((g.Rt.tobytes(), g.Gt.tobytes(), out[0]))
+        assert g.stats()["resident_loops"] == 1
+        g.close()
+    assert len(seen) == 1
+
+
+@pytest.mark.parametrize("family", ["maxcut", "minimum_bisection", "lovasz_theta"])
+def test_resident_lanczos_and_dual_obj(hip_abi, oracle_abi, family):
+    """approx_mineigval_lanczos (src/coreop.jl:461-514) as one launch: the raw α, β of every step against the oracle
+    (plain normalised recurrence on both sides), the Ritz value, dual_obj; the low-rank term of MinBisection / Lovász-θ
+    rides along; the early exit on an invariant subspace (:494-496)."""
+    data, C, As, bs = make_data(family, 3, 30, 0.3)
+    g, o = pair(hip_abi, oracle_abi, data, 3, 4)
+    n = data.n
+    g.f(); o.f()
+    v0 = np.random.Generator(np.random.PCG64(9)).standard_normal(n)
+    (dg, eg), (do, eo) = g.dual_obj(float(n), 0, v0), o.dual_obj(float(n), 0, v0)
+    assert g.stats()["resident_lanczos"] == 1
+    assert eg == pytest.approx(eo, abs=1e-8 * max(1, abs(eo))) and dg == pytest.approx(do, rel=1e-8)
+    ag, bg, kg = g.lanczos(5, v0)
+    ao, bo, ko = o.lanczos(5, v0)
+    assert kg == ko == 5   # (plain Lanczos: later steps of the rank-one cases are ill-conditioned on both sides)
+    tol = 1e-9 if family == "maxcut" else 1e-7
+    assert np.allclose(ag, ao, rtol=tol, atol=1e-11) and np.allclose(bg, bo, rtol=tol, atol=1e-11)
+    if family == "maxcut":
+        y = np.concatenate([np.arange(1.0, data.m + 1), [0.0]])   # S = Diag(1..n)
+        e3 = np.zeros(n); e3[3] = 2.0
+        for s_ in (g, o):
+            s_.y = y
+            s_.At_preprocess()
+            a1, b1, k1 = s_.lanczos(6, e3)
+            assert k1 == 1 and a1[0] == 4.0 and b1[0] == 0.0
+    g.close(); o.close()
+
+
+def test_resident_solve_of_a_gset_instance(hip_abi, oracle_abi):
+    """sdplr() end to end on Gset G1 at the reference's batch settings (rank 10, ptol = objtol = 0.01): every inner loop
+    and every dual bound is one launch; the result lies in the objtol window of the oracle's solve; a second run is
+    bit-identical."""
+    data = problems.maxcut_data(gset("G1"))
+    kw = dict(ptol=0.01, objtol=0.01, seed=0, prior_trace_bound=800.0, printlevel=0)
+    a = sj.sdplr(data=data, r=10, **kw)
+    b = sj.sdplr(data=data, r=10, **kw)
+    o = sj.sdplr(data=data, r=10, abi=oracle_abi, **kw)
+    assert a["obj"] == b["obj"] and a["max_dual_value"] == b["max_dual_value"] and a["iter"] == b["iter"]
+    assert abs(a["obj"] - o["obj"]) <= 1e-2 * abs(o["obj"])
+    assert abs(a["max_dual_value"] - o["max_dual_value"]) <= 2e-2 * abs(o["max_dual_value"])
+    gap = (a["obj"] - a["max_dual_value"]) / min(abs(a["obj"]), abs(a["max_dual_value"]))
+    assert -1e-2 <= gap <= 1e-2
+
+
+@pytest.mark.parametrize("family", ["maxcut", "lovasz_theta", "minimum_bisection", "cutnorm", "mu_conductance_0.05", "ineq_0.05"])
+def test_native_preprocessing_matches_the_host_mirror(hip_abi, oracle_abi, family):
+    """sdplr_hip_set_sparse_coo — preprocess_sparsecons (src/preprocess.jl:24-169) inside the library — against the
+    vectorised host mirror and the oracle's literal restatement: every array of the aggregated layout, bit for bit."""
+    from oracle import oracle
+    for seed, n, p in [(1, 5, 0.4), (2, 12, 0.7), (3, 60, 0.3)]:
+        data, *_ = make_data(family, seed, n, p)
+        a, o = sj.preprocess_sparsecons(data.sparse), oracle.preprocess(data.sparse)
+        s = cabi.DeviceSolver(hip_abi, data.n, data.m, 2, 4)
+        s.set_sparse_coo(data.sparse)
+        b = s.get_layout()
+        for k in ("matptr", "nzind", "nzval_one", "nzval_two", "triu_colptr", "triu_rowval",
+                  "full_colptr", "full_rowval", "mappedto_triu", "global_inds"):
+            assert np.array_equal(getattr(a, k), getattr(b, k)) and np.array_equal(getattr(o, k), getattr(b, k)), (family, seed, k)
+        s.close()
+
+
+def test_native_preprocessing_edge_cases(hip_abi):
+    """Unsorted entries, positions shared by several matrices, upper-triangular-only input (accepted, as by the
+    reference's search), a lower entry without its mirror / an entry outside the matrix (SDPLR_ERR_INVALID_ARG with the
+    message), no entries at all."""
+    from sdplrplus_jl_amd.structs import SparseBatch
+    n = 6
+
+    def native(batch):
+        s = cabi.DeviceSolver(hip_abi, n, 3, 2, 4)
+        try:
+            s.set_sparse_coo(batch)
+            return s.get_layout()
+        finally:
+            s.close()
+
+    I = np.array([4, 1, 1, 0, 3, 3, 1, 2, 5], dtype=np.int64)
+    J = np.array([1, 4, 1, 0, 3, 3, 1, 5, 2], dtype=np.int64)
+    V = np.array([2.0, 2.0, 1.0, -1.0, 0.5, 0.25, 3.0, 7.0, 7.0])
+    batch = SparseBatch(n, np.array([0, 4, 7, 9], dtype=np.int64), I, J, V, np.array([0, 1, 2], dtype=np.int64))
+    up = SparseBatch(n, np.array([0, 3], dtype=np.int64), np.array([1, 0, 2]), np.array([4, 0, 5]), np.array([1.0, 2.0, 3.0]),
+                     np.array([0]))
+    for bt in (batch, up):
+        a, b = sj.preprocess_sparsecons(bt), native(bt)
+        for k in ("matptr", "nzind", "nzval_one", "nzval_two", "triu_colptr", "triu_rowval", "full_colptr", "full_rowval",
+                  "mappedto_triu", "global_inds"):
+            assert np.array_equal(getattr(a, k), getattr(b, k)), k
+    bad = SparseBatch(n, np.array([0, 1], dtype=np.int64), np.array([4]), np.array([1]), np.array([1.0]), np.array([0]))
+    with pytest.raises(cabi.SdplrError, match="not symmetric"):
+        native(bad)
+    out = SparseBatch(n, np.array([0, 1], dtype=np.int64), np.array([6]), np.array([1]), np.array([1.0]), np.array([0]))
+    with pytest.raises(cabi.SdplrError, match="outside"):
+        native(out)
+    empty = SparseBatch(n, np.array([0], dtype=np.int64), np.zeros(0, dtype=np.int64), np.zeros(0, dtype=np.int64),
+                        np.zeros(0), np.zeros(0, dtype=np.int64))
+    e = native(empty)
+    assert e.nnzT == 0 and e.nnzS == 0 and e.nnzAgg == 0

@@ -115,6 +115,36 @@ def test_preprocess_edge_cases():
     assert e.nnzT == 0 and e.nnzS == 0 and e.nnzAgg == 0 and np.array_equal(e.triu_colptr, np.zeros(n + 1, dtype=np.int64))
 
 
+def test_set_sparse_coo_builds_the_same_layout(oracle_abi):
+    """The ABI's set_sparse_coo (preprocess_sparsecons inside the library; here the oracle's literal restatement behind
+    the same entry point) hands back, through get_layout, the arrays of the host-side mirror."""
+    from sdplrplus_jl_amd import cabi
+    for family in ("maxcut", "lovasz_theta", "minimum_bisection", "cutnorm", "mu_conductance_0.05", "ineq_0.05"):
+        data, *_ = make_data(family, 2, 12, 0.7)
+        a = sj.preprocess_sparsecons(data.sparse)
+        s = cabi.DeviceSolver(oracle_abi, data.n, data.m, 2, 4)
+        s.set_sparse_coo(data.sparse)
+        b = s.get_layout()
+        for k in ("matptr", "nzind", "nzval_one", "nzval_two", "triu_colptr", "triu_rowval",
+                  "full_colptr", "full_rowval", "mappedto_triu", "global_inds"):
+            assert np.array_equal(getattr(a, k), getattr(b, k)), (family, k)
+        s.close()
+
+
+def test_preprocess_accepts_upper_triangular_only_input():
+    """A matrix given by its upper triangle alone: the reference's search (src/preprocess.jl:135-156) maps every stored
+    entry and never misses a mirror, so this is accepted; a LOWER entry without its upper mirror is the error."""
+    from sdplrplus_jl_amd.structs import SparseBatch
+    n = 6
+    up = SparseBatch(n, np.array([0, 3], dtype=np.int64), np.array([1, 0, 2]), np.array([4, 0, 5]), np.array([1.0, 2.0, 3.0]),
+                     np.array([0]))
+    a, b = sj.preprocess_sparsecons(up), oracle.preprocess(up)
+    for k in ("matptr", "nzind", "nzval_one", "nzval_two", "triu_colptr", "triu_rowval", "full_colptr", "full_rowval",
+              "mappedto_triu"):
+        assert np.array_equal(getattr(a, k), getattr(b, k)), k
+    assert a.nnzS == a.nnzT == 3 and np.array_equal(a.mappedto_triu, np.arange(3))
+
+
 def test_batched_builders_match_lists():
     """*_data builders produce the very same batch as the list-based reference builders."""
     A = problems.gnp_graph(60, 0.1, 3)
