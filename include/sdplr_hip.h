@@ -83,6 +83,9 @@ int32_t sdplr_hip_set_device(int32_t device); /* process-wide; call before creat
 const char* sdplr_hip_last_error(const sdplr_hip_solver* s); /* s may be NULL: last create-time error */
 const char* sdplr_hip_version(void);
 int32_t sdplr_hip_device_synchronize(void); /* hipDeviceSynchronize on the current device */
+/* Optional: primes the library's pools (HIP streams, events, pinned staging) for n_handles handles alive at once, so
+ * that the first batch of solves does not pay for them (a HIP stream costs milliseconds to create).                */
+int32_t sdplr_hip_warmup(int32_t n_handles);
 
 /* ---- construction: replaces SolverVars + SolverAuxiliary construction ------------------------
  * src/sdplr.jl:114-123, src/structs.jl:225-263 (SolverVars), :296-361 (SolverAuxiliary),
@@ -219,6 +222,19 @@ int32_t sdplr_hip_inner_loop(sdplr_hip_solver* s, double normC, double normb,
                              double time_budget_s, double* lagrangian, double* grad_norm,
                              double* primal_vio_norm, double* last_alpha, int64_t* iters_done,
                              int32_t* exit_reason);
+
+/* The device work of ONE major iteration of _sdplr as one call (src/sdplr.jl:358-362 or :366-369, then :384, :389, then
+ * the next pass of :190-278):  [update_lambda ≠ 0: λᵢ ← min(λ_ubᵢ, λᵢ − σ·primal_vio_rawᵢ) with the CURRENT σ]  →
+ * var.σ[] = sigma  →  lbfgs_clear!  →  fg!  →  the inner while loop on fg!'s (ℒ, grad_norm) — exactly
+ * sdplr_hip_update_lambda / set_scalar / lbfgs_clear / fg / inner_loop in that order, whose arguments these are.  On
+ * small instances (the resident route) all five are ONE kernel launch; out parameters as sdplr_hip_inner_loop
+ * (iterations 0, exit_reason 0 when fg!'s gradient norm is already ≤ cur_gtol).                                    */
+int32_t sdplr_hip_major_iteration(sdplr_hip_solver* s, double normC, double normb, int32_t gtol_relative,
+                                  int32_t ptol_relative, int32_t use_armijo, int32_t update_lambda,
+                                  double sigma, double cur_gtol, double fprec_eps, int64_t max_local_iters,
+                                  double time_budget_s, double* lagrangian, double* grad_norm,
+                                  double* primal_vio_norm, double* last_alpha, int64_t* iters_done,
+                                  int32_t* exit_reason);
 
 /* ---- dual bound / minimum eigenvalue -------------------------------------------------------- */
 /* The Lanczos recurrence of approx_mineigval_lanczos, src/coreop.jl:461-500, on the S left by the

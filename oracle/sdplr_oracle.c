@@ -1039,6 +1039,26 @@ int32_t sdplr_oracle_inner_loop(S* s, double normC, double normb, int32_t grel, 
 
 /* ---- Lanczos / dual bound ------------------------------------------------------------------- */
 
+/* major_iteration of the shared ABI: the sequence the name stands for (src/sdplr.jl:358-369, :384, :389, :190-278) */
+int32_t sdplr_oracle_major_iteration(S* s, double normC, double normb, int32_t grel, int32_t prel, int32_t use_armijo,
+                                     int32_t update_lambda, double sigma, double cur_gtol, double fprec_eps,
+                                     int64_t max_local_iters, double time_budget_s, double* L, double* gn, double* pn,
+                                     double* last_alpha, int64_t* iters, int32_t* exit_reason) {
+  NEED_FINAL(s);
+  if (!L || !gn || !pn || max_local_iters < 1) return fail(s, ERR_INVALID, "major_iteration: bad args");
+  int32_t rc;
+  if (update_lambda && (rc = sdplr_oracle_update_lambda(s))) return rc;
+  if ((rc = sdplr_oracle_set_scalar(s, 0, sigma))) return rc;
+  if ((rc = sdplr_oracle_lbfgs_clear(s))) return rc;
+  if ((rc = sdplr_oracle_fg(s, normC, normb, grel, prel, L, gn, pn))) return rc;
+  if (last_alpha) *last_alpha = 0.0;
+  if (iters) *iters = 0;
+  if (exit_reason) *exit_reason = 0;
+  if (!(*gn > cur_gtol)) return OK; /* :190 */
+  return sdplr_oracle_inner_loop(s, normC, normb, grel, prel, use_armijo, cur_gtol, fprec_eps, max_local_iters,
+                                 time_budget_s, L, gn, pn, last_alpha, iters, exit_reason);
+}
+
 /* the recurrence of approx_mineigval_lanczos, src/coreop.jl:461-500 */
 int32_t sdplr_oracle_lanczos(S* s, int64_t q, const double* v0, double* alpha, double* beta,
                              int64_t* steps) {
@@ -1138,6 +1158,7 @@ int32_t sdplr_oracle_dual_obj(S* s, double trace_bound, int64_t iter, const doub
 int32_t sdplr_oracle_profile_enable(S* s, int32_t on) { (void)s; (void)on; return OK; }
 int32_t sdplr_oracle_profile_filter(S* s, const char* name) { (void)s; (void)name; return OK; }
 int32_t sdplr_oracle_device_synchronize(void) { return OK; }
+int32_t sdplr_oracle_warmup(int32_t n_handles) { (void)n_handles; return OK; }
 int32_t sdplr_oracle_profile_count(const S* s, int32_t* n) { (void)s; if (n) *n = 0; return OK; }
 int32_t sdplr_oracle_profile_get(S* s, int32_t idx, char* name, int32_t cap, int64_t* launches, double* ms) {
   (void)s; (void)idx; (void)name; (void)cap; (void)launches; (void)ms;

@@ -62,6 +62,12 @@ int32_t sdplr_oracle_get_dims(const sdplr_oracle_solver* s, int64_t* n, int64_t*
                               int64_t* h, int64_t* nnzT, int64_t* nnzS, int64_t* nnzAgg);
 
 int32_t sdplr_oracle_A(sdplr_oracle_solver* s, int32_t u_slot, int32_t v_slot, int32_t out_vec);
+int32_t sdplr_oracle_major_iteration(sdplr_oracle_solver* s, double normC, double normb, int32_t gtol_relative,
+                                     int32_t ptol_relative, int32_t use_armijo, int32_t update_lambda, double sigma,
+                                     double cur_gtol, double fprec_eps, int64_t max_local_iters, double time_budget_s,
+                                     double* lagrangian, double* grad_norm, double* primal_vio_norm,
+                                     double* last_alpha, int64_t* iters_done, int32_t* exit_reason);
+int32_t sdplr_oracle_warmup(int32_t n_handles);
 int32_t sdplr_oracle_set_sparse_coo(sdplr_oracle_solver* s, int64_t index_base, int64_t n_sparse,
                                     const int64_t* ent_ptr, const int64_t* I, const int64_t* J,
                                     const double* V, const int64_t* global_inds);

@@ -26,7 +26,7 @@ def wrap(name):
             with lock:
                 acc[name] = acc.get(name, 0.0) + dt
     setattr(cabi.DeviceSolver, name, g)
-for nm in ("inner_loop", "dual_obj", "fg", "finalize", "set_sparse_coo", "close", "lbfgs_clear", "update_lambda", "set_vec", "set_factor", "get_vec", "get_factor", "set_scalar", "get_scalar"):
+for nm in ("major_iteration", "inner_loop", "dual_obj", "fg", "finalize", "set_sparse_coo", "close", "lbfgs_clear", "update_lambda", "set_vec", "set_factor", "get_vec", "get_factor", "set_scalar", "get_scalar"):
     wrap(nm)
 for K in (1, 2, 4, 8, 16):
     acc.clear()

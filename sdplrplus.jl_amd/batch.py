@@ -39,8 +39,17 @@ def solve_local(instances: Sequence, rank: int, world: int, r: int, *, abi=None,
     if concurrency <= 1 or len(mine) == 1:
         rows = [one(k) for k in mine]
     else:  # ctypes releases the GIL inside the library, so the handles' streams really overlap
-        with ThreadPoolExecutor(max_workers=min(concurrency, len(mine))) as ex:
-            rows = list(ex.map(one, mine))
+        # A thread that comes back from the library has to take the GIL again; CPython only asks the thread that holds it
+        # to let go every `switchinterval` (5 ms by default) — with 16 drivers making ≈ 100 short calls per solve that
+        # wait, not the calls, was most of a small solve's wall time.
+        import sys
+        old_interval = sys.getswitchinterval()
+        sys.setswitchinterval(min(old_interval, 5e-5))
+        try:
+            with ThreadPoolExecutor(max_workers=min(concurrency, len(mine))) as ex:
+                rows = list(ex.map(one, mine))
+        finally:
+            sys.setswitchinterval(old_interval)
     return np.asarray(rows, dtype=np.float64)
 
 

@@ -41,6 +41,7 @@ SIGNATURES = {
     "last_error": [_vp],
     "version": [],
     "device_synchronize": [],
+    "warmup": [_i32],
     "create": [_i64, _i64, _i64, _i64, C.POINTER(_vp)],
     "set_sparse": [_vp, _i64, _i64, _pi64, _pi64, _pf64, _pf64, _pi64, _i64, _pi64, _pi64, _i64,
                    _pi64, _pi64, _pi64],
@@ -79,6 +80,8 @@ SIGNATURES = {
     "update_lambda": [_vp],
     "inner_loop": [_vp, _f64, _f64, _i32, _i32, _i32, _f64, _f64, _i64, _f64, _pf64, _pf64, _pf64,
                    _pf64, _pi64, _pi32],
+    "major_iteration": [_vp, _f64, _f64, _i32, _i32, _i32, _i32, _f64, _f64, _f64, _i64, _f64, _pf64, _pf64, _pf64,
+                        _pf64, _pi64, _pi32],
     "lanczos": [_vp, _i64, _pf64, _pf64, _pf64, _pi64],
     "tridiag_mineig": [_pf64, _pf64, _i64, _pf64],
     "approx_mineigval_lanczos": [_vp, _i64, _pf64, _pf64],
@@ -430,6 +433,18 @@ class DeviceSolver:
                                      C.byref(why)))
         return (float(L.value), float(g.value), float(p.value), float(a.value), int(it.value),
                 int(why.value))
+
+    def major_iteration(self, normC, normb, gtol_relative, ptol_relative, use_armijo, update_lambda, sigma,
+                        cur_gtol, fprec_eps, max_local_iters, time_budget_s):
+        """One major iteration's device work as one call: [λ update] → σ → lbfgs_clear! → fg! → inner loop
+        (src/sdplr.jl:358-369, :384, :389, :190-278) → (ℒ, grad_norm, primal_vio_norm, last α, iterations, exit_reason)."""
+        L, g, p, a = C.c_double(0.0), C.c_double(0.0), C.c_double(0.0), C.c_double(0.0)
+        it, why = C.c_int64(0), C.c_int32(0)
+        self._ck(self.abi.major_iteration(self._h, normC, normb, int(gtol_relative), int(ptol_relative), int(use_armijo),
+                                          int(update_lambda), float(sigma), float(cur_gtol), float(fprec_eps),
+                                          int(max_local_iters), float(time_budget_s), C.byref(L), C.byref(g), C.byref(p),
+                                          C.byref(a), C.byref(it), C.byref(why)))
+        return (float(L.value), float(g.value), float(p.value), float(a.value), int(it.value), int(why.value))
 
     def lanczos(self, q: int, v0: np.ndarray):
         """src/coreop.jl:461-500 → (alpha[:steps], beta[:steps], steps)."""

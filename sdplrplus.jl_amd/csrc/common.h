@@ -52,6 +52,7 @@ struct DevCtrl {
   double lz_beta_prev;
   double lz_gamma_cur, lz_gamma_prev;  // norms of the current / previous unnormalised Lanczos vectors
   long long lz_qmax;
+  double lz_mineig;    // resident dual bound: min eigenvalue of the Lanczos tridiagonal, minus the shift (src/coreop.jl:502-513)
   // ---- L-BFGS (src/lbfgs.jl:4-28) ----
   int latest;          // 1-based, as in the reference
   int gram_pending;    // set by k_lbfgs_update, consumed by k_lbfgs_boundary

@@ -212,6 +212,148 @@ __device__ __forceinline__ void rs_ell_spmm_any(const RsEll& E, const double* Xl
   else rs_ell_spmm<VEC, 2, TO_P>(E, Xl, n, r, out);
 }
 
+// ---- fg! (src/coreop.jl:323-349) as one launch on the instances of the resident loop ----------------------------------
+// f! (:11-31): primal_vio_raw = 𝒜(RRᵀ) − b with 𝒜 row-local — v_j·‖R_j‖² for the constraint attached to row j, ⟨R, P⟩ for
+// A_g's slot, P = A_g·R by the ELL SpMM (left in place: the loop that follows starts from a fresh P) — then obj, the capped
+// violation, ℒ; g! (:305-317): y, G = 2(y_g·P + d(y)∘R), ‖G‖; the two norms of :334-347.
+struct RsFgArgs {
+  int n, m, r;
+  int gid_g;
+  const int* row_k;
+  const double* row_v;
+  RsEll E;
+  const double* R;
+  double *G, *P;
+  double *y, *pv_raw, *pv;
+  const double *lam, *lam_ub, *lb, *b;
+  DevCtrl* c;
+};
+// the body of fg!: every thread of the resident workgroup calls it; Rl[Npad] | rrl[n] | djl[n] are LDS work arrays, sred holds
+// 3·NW doubles, c is the control block (global memory in k_rs_fg, the LDS copy in the loop's prologue)
+struct RsFgShared {
+  double yg, obj_row;
+  int has_obj_row;
+};
+template <int LPR, int VEC>
+__device__ __forceinline__ void rs_fg_body(const RsFgArgs& a, DevCtrl& c, double* Rl, double* rrl, double* djl, double* sred,
+                                           RsFgShared& sh) {
+  constexpr int NT = SDPLR_RS_NT, G = NT / LPR;
+  const int tid = threadIdx.x, grp = tid / LPR, lane = tid % LPR;
+  const int n = a.n, m = a.m, r = a.r;
+  const long long N = (long long)n * r;
+  const int ch0 = lane * VEC;
+  const bool act = ch0 < r;
+  const double sigma = c.sigma, normC = c.normC, normb = c.normb;
+  const int grel = c.grel, prel = c.prel;
+  if (tid == 0) sh.has_obj_row = 0;
+  for (long long e = tid; e < N; e += NT) Rl[e] = a.R[e];
+  __syncthreads();
+  rs_ell_spmm_any<VEC, true>(a.E, Rl, n, r, a.P);     // P = A_g·R
+  __syncthreads();
+  double acc[3] = {0.0, 0.0, 0.0};   // ⟨R, P⟩
+#pragma nounroll
+  for (int j = grp; j < n; j += G) {
+    double rr = 0.0;
+    if (act) {
+      const vecd<VEC> x = ldrow<VEC>(Rl + (long long)j * r + ch0), p = ldrow<VEC>(a.P + (long long)j * r + ch0);
+#pragma unroll
+      for (int k = 0; k < VEC; k++) {
+        rr += x.v[k] * x.v[k];
+        acc[0] += x.v[k] * p.v[k];
+      }
+    }
+    rr = group_sum<LPR>(rr);
+    if (lane == 0) rrl[j] = rr;
+  }
+  rs_sum_to0<1>(reinterpret_cast<double(&)[1]>(acc[0]), sred);
+  __syncthreads();
+  double fs = 0.0, pn = 0.0;
+  if (tid == 0) {   // A_g's slot
+    const int kg = a.gid_g;
+    double v = acc[0];
+    double yk = 1.0;
+    if (kg < m) {
+      v -= a.b[kg];                                          // (:20)
+      const double pc = fmax(v, a.lb[kg]);                   // (:22)
+      a.pv[kg] = pc;
+      pn += pc * pc;
+      const double l = a.lam[kg], yt = fmin(a.lam_ub[kg], l - sigma * v);   // (:27)
+      fs += (yt * yt - l * l) / (2 * sigma);                 // (:28)
+      yk = -yt;                                              // src/coreop.jl:233
+    }
+    a.pv_raw[kg] = v;
+    a.y[kg] = yk;
+    sh.yg = yk;
+  }
+  for (int j = tid; j < n; j += NT) {
+    const int k = a.row_k[j];
+    double dj = 0.0;
+    if (k >= 0) {
+      const double rv = a.row_v[j];
+      double v = rv * rrl[j];
+      double yk = 1.0;
+      if (k < m) {
+        v -= a.b[k];
+        const double pc = fmax(v, a.lb[k]);
+        a.pv[k] = pc;
+        pn += pc * pc;
+        const double l = a.lam[k], yt = fmin(a.lam_ub[k], l - sigma * v);
+        fs += (yt * yt - l * l) / (2 * sigma);
+        yk = -yt;
+      } else {            // the cost matrix as a row-attached entry
+        sh.obj_row = v;
+        sh.has_obj_row = 1;
+      }
+      a.pv_raw[k] = v;
+      a.y[k] = yk;
+      dj = rv * yk;
+    }
+    djl[j] = dj;
+  }
+  double two[2] = {fs, pn};
+  rs_sum_to0<2>(two, sred);
+  __syncthreads();
+  const double yg = sh.yg;
+  double gn = 0.0;
+#pragma nounroll
+  for (int j = grp; j < n; j += G) {
+    if (act) {
+      const long long e = (long long)j * r + ch0;
+      const vecd<VEC> x = ldrow<VEC>(Rl + e), p = ldrow<VEC>(a.P + e);
+      const double dj = djl[j];
+      vecd<VEC> g;
+#pragma unroll
+      for (int k = 0; k < VEC; k++) {
+        g.v[k] = p.v[k] * yg + x.v[k] * dj;
+        g.v[k] *= 2.0;                                        // src/coreop.jl:315
+        gn += g.v[k] * g.v[k];
+      }
+      strow<VEC>(a.G + e, g);
+    }
+  }
+  double one[1] = {gn};
+  rs_sum_to0<1>(one, sred);
+  if (tid == 0) {
+    const double obj = (a.gid_g == m) ? acc[0] : (sh.has_obj_row ? sh.obj_row : a.pv_raw[m]);
+    c.obj = obj;                                              // (:16)
+    c.L = obj + two[0];                                       // (:25-30)
+    const double g2 = sqrt(one[0]), p2 = sqrt(two[1]);
+    c.gnorm = grel ? g2 / normC : g2;                         // (:334-338)
+    c.pvnorm = prel ? p2 / normb : p2;                        // (:340-347)
+  }
+  __syncthreads();
+}
+template <int LPR, int VEC>
+__global__ void __launch_bounds__(SDPLR_RS_NT)
+k_rs_fg(RsFgArgs a) {
+  extern __shared__ __attribute__((aligned(16))) double rs_lds[];
+  __shared__ double sred[3 * SDPLR_RS_NW];
+  __shared__ RsFgShared sh;
+  const long long N = (long long)a.n * a.r;
+  const long long Npad = (N + 1) & ~1LL;
+  rs_fg_body<LPR, VEC>(a, *a.c, rs_lds, rs_lds + Npad, rs_lds + Npad + a.n, sred, sh);
+}
+
 struct RsLoopArgs {
   int n, m, r, h;
   int gid_g;                            // slot of A_g in the (m+1)-vectors
@@ -224,6 +366,11 @@ struct RsLoopArgs {
   const double *lam, *lam_ub, *lb;
   DevCtrl* c;
   int refresh_P;                        // P = A_g·R from scratch before the first iteration
+  // the head of a major iteration in the same launch (sdplr_hip_major_iteration): λ update (src/sdplr.jl:358-362),
+  // lbfgs_clear! (:384, src/lbfgs.jl:52-59), fg! (:389) — then the while loop (:190-278) on what fg! returned
+  int pre_lambda, pre_clear, pre_fg;
+  const double* b;
+  double* lam_rw;                       // λ, writable (pre_lambda)
   long long budget_ticks;               // wall_clock64() ticks this call may run (≤ 0: no limit), src/sdplr.jl:272-277
 };
 
@@ -273,6 +420,32 @@ k_rs_loop(RsLoopArgs a) {
   for (int t = tid; t < (int)(sizeof(DevCtrl) / 8); t += NT)
     reinterpret_cast<unsigned long long*>(&gd.c)[t] = reinterpret_cast<const unsigned long long*>(a.c)[t];
   const long long t_start = (long long)wall_clock64();
+  if (a.pre_lambda || a.pre_clear || a.pre_fg) {
+    __shared__ RsFgShared fsh;
+    __syncthreads();
+    if (a.pre_lambda) {      // λᵢ ← min(λ_ubᵢ, λᵢ − σ·primal_vio_rawᵢ)  (src/sdplr.jl:358-362)
+      const double sigma = gd.c.sigma;
+      for (int k = tid; k < m; k += NT) a.lam_rw[k] = fmin(a.lam_ub[k], a.lam_rw[k] - sigma * a.pv_raw[k]);
+    }
+    if (a.pre_clear) {       // lbfgs_clear!: s, y ← 0 (neighbours in the arena), ρ = a = 0, and with them the Gram data
+      double* const hist = aslot(a.A, AS_S0);
+      const long long len = 2LL * h * a.A.stride;
+      for (long long e = tid; e < len; e += NT) hist[e] = 0.0;
+      for (int k = tid; k < SDPLR_HMAX * SDPLR_HMAX; k += NT) {
+        gd.c.SY[k] = 0.0;
+        gd.c.YY[k] = 0.0;
+        if (k < SDPLR_HMAX) gd.c.rho[k] = gd.c.a[k] = gd.c.c_alpha[k] = gd.c.c_gamma[k] = gd.c.Sg[k] = gd.c.Yg[k] = 0.0;
+      }
+    }
+    __syncthreads();
+    if (a.pre_fg) {
+      RsFgArgs f{};
+      f.n = n; f.m = m; f.r = r; f.gid_g = a.gid_g; f.row_k = a.row_k; f.row_v = a.row_v; f.E = a.E;
+      f.R = R; f.G = Gm; f.P = a.P; f.y = a.y; f.pv_raw = a.pv_raw; f.pv = a.pv;
+      f.lam = a.lam; f.lam_ub = a.lam_ub; f.lb = a.lb; f.b = a.b; f.c = a.c;
+      rs_fg_body<LPR, VEC>(f, gd.c, Dl, rdl, djl, sred, fsh);
+    }
+  }
   // constraint data of this thread's rows: constant over the call except primal_vio_raw, which the thread owns
   RsRow rw_[SDPLR_RS_RPT];
 #pragma unroll
@@ -281,7 +454,7 @@ k_rs_loop(RsLoopArgs a) {
     if (j < n) rw_[q] = rs_load_row(a, j);
     else { rw_[q].k = -1; rw_[q].v = rw_[q].lam = rw_[q].lub = rw_[q].lb = rw_[q].pvr = 0.0; }
   }
-  if (a.refresh_P) {   // P = A_g·R (entry of the loop: R was written outside, or the incremental P is due for a refresh)
+  if (a.refresh_P && !a.pre_fg) {   // P = A_g·R (entry of the loop: R was written outside, or the incremental P is due for a refresh)
     for (long long e = tid; e < N; e += NT) Dl[e] = R[e];
     __syncthreads();
     rs_ell_spmm_any<VEC, true>(a.E, Dl, n, r, a.P);
@@ -646,12 +819,15 @@ k_rs_loop(RsLoopArgs a) {
            stamp_acc[0] / gd.c.iters, stamp_acc[1] / gd.c.iters, stamp_acc[7] / gd.c.iters, stamp_acc[2] / gd.c.iters, stamp_acc[3] / gd.c.iters,
            stamp_acc[4] / gd.c.iters, stamp_acc[5] / gd.c.iters, stamp_acc[6] / gd.c.iters);
 #endif
-  // dirt as the last lbfgs_dir! left it (the host overwrites it with s_latest unless the loop left through the
-  // relative-decrease exit, which skips lbfgs_update!: sdplr_hip_inner_loop)
+  // dirt as the reference leaves it when the loop is left
   __syncthreads();
   if (dir_ran) {
+    // … = the unscaled direction after a relative-decrease exit (no lbfgs_update!), s_latest = α·dirt otherwise
+    // (`dirt *= α`, src/lbfgs.jl:142, is not stored inside the loop)
     double* const Dg = aslot(a.A, AS_D);
-    for (long long e = tid; e < N; e += NT) Dg[e] = Dl[e];
+    const bool scaled = gd.c.iters > 0 && gd.c.err == 0 && gd.c.exit_reason != EXIT_RELDELTA;
+    const double* const Sl = aslot(a.A, AS_S0 + (gd.c.latest - 1));
+    for (long long e = tid; e < N; e += NT) Dg[e] = scaled ? Sl[e] : Dl[e];
   }
   // the control block goes back whole (done / exit_reason / iters / L / norms / Gram data / latest …)
   if (tid == 0) {
@@ -786,7 +962,24 @@ struct RsLzEllArgs {
   const double* v0;
   double *alpha_out, *beta_out;
   DevCtrl* c;
+  // dual_obj (src/coreop.jl:376-415) around the recurrence, in the same launch: copy2y_λ_sub_pvio! (:384) before it,
+  // ⟨y[1:m], b⟩ (:412) and the smallest eigenvalue of the tridiagonal (:502-513) after it
+  int dual, m;
+  double* y_rw;
+  const double *lam, *lam_ub, *pv_raw, *b;
 };
+// number of eigenvalues of SymTridiagonal(d, e) below x (Sturm count), d = alpha + 1
+__device__ __forceinline__ int rs_sturm_below(const double* al, const double* be, int k, double x) {
+  int cnt = 0;
+  double q = (al[0] + 1.0) - x;
+  if (q < 0) cnt++;
+  for (int i = 1; i < k; i++) {
+    const double den = (q == 0.0) ? 2.2250738585072014e-308 : q;
+    q = (al[i] + 1.0) - x - be[i - 1] * be[i - 1] / den;
+    if (q < 0) cnt++;
+  }
+  return cnt;
+}
 template <bool ELL_LDS>
 __global__ void __launch_bounds__(SDPLR_RS_NT)
 k_rs_lanczos_ell(RsLzEllArgs a) {
@@ -811,6 +1004,12 @@ k_rs_lanczos_ell(RsLzEllArgs a) {
     for (int i = 0; i < SDPLR_RS_NW; i++) t += sred[i];
     return t;
   };
+  if (a.dual) {   // copy2y_λ_sub_pvio!  src/coreop.jl:229-236
+    const double sigma = a.c->sigma;
+    for (int i = tid; i <= a.m; i += NT)
+      a.y_rw[i] = (i == a.m) ? 1.0 : -fmin(a.lam_ub[i], a.lam[i] - sigma * a.pv_raw[i]);
+    __syncthreads();
+  }
   const double yg = a.yvec[a.gid_g];
   const bool uniform = a.E.val == nullptr;
   const double s_off = yg * a.E.one;         // the value every off-diagonal entry of S has (unit weights)
@@ -941,137 +1140,50 @@ k_rs_lanczos_ell(RsLzEllArgs a) {
     a.c->lz_steps = steps;
     a.c->lz_beta_prev = beta_prev;
   }
-}
-
-// ---- fg! (src/coreop.jl:323-349) as one launch on the instances of the resident loop ----------------------------------
-// f! (:11-31): primal_vio_raw = 𝒜(RRᵀ) − b with 𝒜 row-local — v_j·‖R_j‖² for the constraint attached to row j, ⟨R, P⟩ for
-// A_g's slot, P = A_g·R by the ELL SpMM (left in place: the loop that follows starts from a fresh P) — then obj, the capped
-// violation, ℒ; g! (:305-317): y, G = 2(y_g·P + d(y)∘R), ‖G‖; the two norms of :334-347.
-struct RsFgArgs {
-  int n, m, r;
-  int gid_g;
-  const int* row_k;
-  const double* row_v;
-  RsEll E;
-  const double* R;
-  double *G, *P;
-  double *y, *pv_raw, *pv;
-  const double *lam, *lam_ub, *lb, *b;
-  DevCtrl* c;
-};
-template <int LPR, int VEC>
-__global__ void __launch_bounds__(SDPLR_RS_NT)
-k_rs_fg(RsFgArgs a) {
-  extern __shared__ __attribute__((aligned(16))) double rs_lds[];
-  __shared__ double sred[3 * SDPLR_RS_NW];
-  __shared__ double sh_yg, sh_obj_row;
-  __shared__ int sh_has_obj_row;
-  constexpr int NT = SDPLR_RS_NT, G = NT / LPR;
-  const int tid = threadIdx.x, grp = tid / LPR, lane = tid % LPR;
-  const int n = a.n, m = a.m, r = a.r;
-  const long long N = (long long)n * r;
-  const long long Npad = (N + 1) & ~1LL;
-  double* Rl = rs_lds;          // [Npad] R
-  double* rrl = Rl + Npad;      // [n] ‖R_j‖²
-  double* djl = rrl + n;        // [n] d_j = v_j·y[k_j]
-  const int ch0 = lane * VEC;
-  const bool act = ch0 < r;
-  const double sigma = a.c->sigma, normC = a.c->normC, normb = a.c->normb;
-  const int grel = a.c->grel, prel = a.c->prel;
-  if (tid == 0) sh_has_obj_row = 0;
-  for (long long e = tid; e < N; e += NT) Rl[e] = a.R[e];
-  __syncthreads();
-  rs_ell_spmm_any<VEC, true>(a.E, Rl, n, r, a.P);     // P = A_g·R
-  __syncthreads();
-  double acc[3] = {0.0, 0.0, 0.0};   // ⟨R, P⟩; then Σ(ỹ² − λ²)/(2σ), ‖pv‖²; then ‖G‖²
-#pragma nounroll
-  for (int j = grp; j < n; j += G) {
-    double rr = 0.0;
-    if (act) {
-      const vecd<VEC> x = ldrow<VEC>(Rl + (long long)j * r + ch0), p = ldrow<VEC>(a.P + (long long)j * r + ch0);
-#pragma unroll
-      for (int k = 0; k < VEC; k++) {
-        rr += x.v[k] * x.v[k];
-        acc[0] += x.v[k] * p.v[k];
+  if (!a.dual) return;
+  {   // ⟨y[1:m], b⟩  (:412)
+    double t = 0.0;
+    for (int i = tid; i < a.m; i += NT) t += a.yvec[i] * a.b[i];
+    const double yb = bsum(t);
+    if (tid == 0) a.c->descent = yb;
+  }
+  // The smallest eigenvalue of SymTridiagonal(alpha .+ 1, beta) minus 1 (:502-513) — the host routine's bisection
+  // (sdplr_hip_tridiag_mineig), with 64 trial points per round by wave 0 until the bracket is a few ulps wide and the
+  // scalar loop finishes it: the bracket it ends on is the one the sequential bisection ends on.
+  if (wave == 0) {
+    __threadfence_block();
+    const double* al = a.alpha_out;   // (written by thread 0 above: same wave, global memory, fenced)
+    const double* be = a.beta_out;
+    const int k = steps;
+    double ev;
+    if (k == 1) {
+      ev = (al[0] + 1.0) - 1.0;                                   // (:505-507)
+    } else {
+      double lo = 1.0 / 0.0, hi = -lo;
+      for (int i = 0; i < k; i++) {
+        const double rad = (i > 0 ? fabs(be[i - 1]) : 0.0) + (i + 1 < k ? fabs(be[i]) : 0.0);
+        lo = fmin(lo, (al[i] + 1.0) - rad);
+        hi = fmax(hi, (al[i] + 1.0) + rad);
       }
-    }
-    rr = group_sum<LPR>(rr);
-    if (lane == 0) rrl[j] = rr;
-  }
-  rs_sum_to0<1>(reinterpret_cast<double(&)[1]>(acc[0]), sred);
-  __syncthreads();
-  double fs = 0.0, pn = 0.0;
-  if (tid == 0) {   // A_g's slot
-    const int kg = a.gid_g;
-    double v = acc[0];
-    double yk = 1.0;
-    if (kg < m) {
-      v -= a.b[kg];                                          // (:20)
-      const double pc = fmax(v, a.lb[kg]);                   // (:22)
-      a.pv[kg] = pc;
-      pn += pc * pc;
-      const double l = a.lam[kg], yt = fmin(a.lam_ub[kg], l - sigma * v);   // (:27)
-      fs += (yt * yt - l * l) / (2 * sigma);                 // (:28)
-      yk = -yt;                                              // src/coreop.jl:233
-    }
-    a.pv_raw[kg] = v;
-    a.y[kg] = yk;
-    sh_yg = yk;
-  }
-  for (int j = tid; j < n; j += NT) {
-    const int k = a.row_k[j];
-    double dj = 0.0;
-    if (k >= 0) {
-      const double rv = a.row_v[j];
-      double v = rv * rrl[j];
-      double yk = 1.0;
-      if (k < m) {
-        v -= a.b[k];
-        const double pc = fmax(v, a.lb[k]);
-        a.pv[k] = pc;
-        pn += pc * pc;
-        const double l = a.lam[k], yt = fmin(a.lam_ub[k], l - sigma * v);
-        fs += (yt * yt - l * l) / (2 * sigma);
-        yk = -yt;
-      } else {            // the cost matrix as a row-attached entry
-        sh_obj_row = v;
-        sh_has_obj_row = 1;
+      for (int round = 0; round < 40; round++) {
+        const double w = hi - lo;
+        const double x = lo + w * ((double)(wl + 1) / 65.0);
+        const bool inside = x > lo && x < hi;
+        const bool below = inside && rs_sturm_below(al, be, k, x) >= 1;
+        const unsigned long long mk = __ballot(below), mi = __ballot(inside);
+        if (mi != ~0ull) break;                                    // the trial points no longer separate: finish below
+        const int f = mk ? __ffsll((long long)mk) - 1 : 64;        // first point with an eigenvalue below it
+        const double xhi = __shfl(x, min(f, 63), 64), xlo = __shfl(x, max(f - 1, 0), 64);
+        if (f < 64) hi = xhi;
+        if (f > 0) lo = xlo;
       }
-      a.pv_raw[k] = v;
-      a.y[k] = yk;
-      dj = rv * yk;
-    }
-    djl[j] = dj;
-  }
-  double two[2] = {fs, pn};
-  rs_sum_to0<2>(two, sred);
-  __syncthreads();
-  const double yg = sh_yg;
-  double gn = 0.0;
-#pragma nounroll
-  for (int j = grp; j < n; j += G) {
-    if (act) {
-      const long long e = (long long)j * r + ch0;
-      const vecd<VEC> x = ldrow<VEC>(Rl + e), p = ldrow<VEC>(a.P + e);
-      const double dj = djl[j];
-      vecd<VEC> g;
-#pragma unroll
-      for (int k = 0; k < VEC; k++) {
-        g.v[k] = p.v[k] * yg + x.v[k] * dj;
-        g.v[k] *= 2.0;                                        // src/coreop.jl:315
-        gn += g.v[k] * g.v[k];
+      for (int it = 0; it < 200; it++) {
+        const double mid = 0.5 * (lo + hi);
+        if (mid <= lo || mid >= hi) break;
+        if (rs_sturm_below(al, be, k, mid) >= 1) hi = mid; else lo = mid;
       }
-      strow<VEC>(a.G + e, g);
+      ev = 0.5 * (lo + hi) - 1.0;                                  // cancel the shift (:513)
     }
-  }
-  double one[1] = {gn};
-  rs_sum_to0<1>(one, sred);
-  if (tid == 0) {
-    const double obj = (a.gid_g == m) ? acc[0] : (sh_has_obj_row ? sh_obj_row : a.pv_raw[m]);
-    a.c->obj = obj;                                           // (:16)
-    a.c->L = obj + two[0];                                    // (:25-30)
-    const double g2 = sqrt(one[0]), p2 = sqrt(two[1]);
-    a.c->gnorm = grel ? g2 / normC : g2;                      // (:334-338)
-    a.c->pvnorm = prel ? p2 / normb : p2;                     // (:340-347)
+    if (wl == 0) a.c->lz_mineig = ev;
   }
 }

@@ -79,9 +79,11 @@ struct sdplr_hip_solver {
   // instance made ≈ 70 synchronous hipMemcpy / hipMemset calls: 1.3 ms alone, 16 ms with 16 handles being built at once)
   struct UploadArena {
     bool on = false;
-    char* dev = nullptr;
+    char* dev = nullptr;      // uploads: a chunk mirrored in a pinned staging block, one asynchronous copy at commit
+    char* host = nullptr;
     size_t cap = 0, used = 0;
-    std::vector<char> host;
+    char* zdev = nullptr;     // zero-filled arrays: a chunk of their own, one device fill at commit (nothing crosses PCIe)
+    size_t zcap = 0, zused = 0;
   } up;
   std::vector<void*> allocs;
   DevSparse sp{};
@@ -226,6 +228,7 @@ struct DevPool {
   std::map<std::pair<int, size_t>, std::vector<void*>> free_blocks;
   std::unordered_map<void*, std::pair<int, size_t>> live;
   std::vector<void*> pinned_free;   // pinned host blocks of sizeof(DevCtrl)
+  std::vector<void*> pinned_chunks_free;   // pinned staging blocks of finalize's upload arena
   // streams and events of destroyed handles: hipStreamCreate / hipStreamDestroy cost 1–2 ms each, more than the rest of
   // finalize on a small instance (a batch creates and destroys a handle per instance)
   std::map<int, std::vector<hipStream_t>> streams_free;
@@ -371,14 +374,42 @@ int dalloc(S* s, T** p, size_t count) {
   return SDPLR_OK;
 }
 constexpr size_t ARENA_ITEM_MAX = (size_t)256 << 10, ARENA_CHUNK = (size_t)4 << 20;
-int arena_commit(S* s) {   // the pending chunk → device (zero-filled where nothing was uploaded)
-  S::UploadArena& u = s->up;
-  if (u.dev && u.used > 0) {
-    HIPCK(s, hipMemcpyAsync(u.dev, u.host.data(), u.used, hipMemcpyHostToDevice, s->stream));
-    HIPCK(s, hipStreamSynchronize(s->stream));
+hipError_t pool_host_chunk(void** out) {   // pinned staging blocks of ARENA_CHUNK bytes
+  DevPool& P = pool();
+  if (!P.off) {
+    std::lock_guard<std::mutex> g(P.mu);
+    if (!P.pinned_chunks_free.empty()) {
+      *out = P.pinned_chunks_free.back();
+      P.pinned_chunks_free.pop_back();
+      return hipSuccess;
+    }
   }
-  u.dev = nullptr;
-  u.cap = u.used = 0;
+  return hipHostMalloc(out, ARENA_CHUNK, hipHostMallocDefault);
+}
+void pool_host_chunk_free(void* p) {
+  if (!p) return;
+  DevPool& P = pool();
+  if (!P.off) {
+    std::lock_guard<std::mutex> g(P.mu);
+    if (P.pinned_chunks_free.size() < 32) {
+      P.pinned_chunks_free.push_back(p);
+      return;
+    }
+  }
+  (void)hipHostFree(p);
+}
+int arena_commit(S* s) {   // the pending chunks → device
+  S::UploadArena& u = s->up;
+  bool wait = false;
+  if (u.dev && u.used > 0) {
+    HIPCK(s, hipMemcpyAsync(u.dev, u.host, u.used, hipMemcpyHostToDevice, s->stream));
+    wait = true;
+  }
+  if (u.zdev && u.zused > 0) HIPCK(s, hipMemsetAsync(u.zdev, 0, u.zused, s->stream));
+  if (wait) HIPCK(s, hipStreamSynchronize(s->stream));   // (the staging block goes back to the pool)
+  if (u.host) pool_host_chunk_free(u.host);
+  u.dev = u.host = u.zdev = nullptr;
+  u.cap = u.used = u.zcap = u.zused = 0;
   return SDPLR_OK;
 }
 // room for `bytes` in the current chunk (src == nullptr: zeros); *out = nullptr ⇒ not an arena item
@@ -387,18 +418,41 @@ int arena_take(S* s, size_t bytes, const void* src, void** out) {
   S::UploadArena& u = s->up;
   const size_t b = (std::max<size_t>(bytes, 1) + 255) / 256 * 256;
   if (!u.on || b > ARENA_ITEM_MAX) return SDPLR_OK;
+  if (src == nullptr) {
+    if (u.zused + b > u.zcap) {
+      if (u.zdev && u.zused > 0) HIPCK(s, hipMemsetAsync(u.zdev, 0, u.zused, s->stream));
+      void* q = nullptr;
+      hipError_t e = pool_malloc(&q, ARENA_CHUNK);
+      if (e != hipSuccess) return fail(s, SDPLR_ERR_ALLOC, std::string("hipMalloc: ") + hipGetErrorString(e));
+      s->allocs.push_back(q);
+      u.zdev = (char*)q;
+      u.zcap = ARENA_CHUNK;
+      u.zused = 0;
+    }
+    *out = u.zdev + u.zused;
+    u.zused += b;
+    return SDPLR_OK;
+  }
   if (u.used + b > u.cap) {
-    int rc = arena_commit(s);
-    if (rc) return rc;
+    if (u.dev && u.used > 0) {
+      HIPCK(s, hipMemcpyAsync(u.dev, u.host, u.used, hipMemcpyHostToDevice, s->stream));
+      HIPCK(s, hipStreamSynchronize(s->stream));
+    }
     void* q = nullptr;
     hipError_t e = pool_malloc(&q, ARENA_CHUNK);
     if (e != hipSuccess) return fail(s, SDPLR_ERR_ALLOC, std::string("hipMalloc: ") + hipGetErrorString(e));
     s->allocs.push_back(q);
+    if (!u.host) {
+      void* hp = nullptr;
+      e = pool_host_chunk(&hp);
+      if (e != hipSuccess) return fail(s, SDPLR_ERR_ALLOC, std::string("hipHostMalloc: ") + hipGetErrorString(e));
+      u.host = (char*)hp;
+    }
     u.dev = (char*)q;
     u.cap = ARENA_CHUNK;
-    u.host.assign(ARENA_CHUNK, 0);
+    u.used = 0;
   }
-  if (src && bytes) memcpy(u.host.data() + u.used, src, bytes);
+  if (bytes) memcpy(u.host + u.used, src, bytes);
   *out = u.dev + u.used;
   u.used += b;
   return SDPLR_OK;
@@ -947,6 +1001,29 @@ int32_t sdplr_hip_set_device(int32_t device) {
   return SDPLR_OK;
 }
 
+// Primes the library's per-device pools for `n_handles` solver handles alive at the same time: HIP streams (creating
+// one costs milliseconds — tens of them when 16 threads ask at once), events, the pinned blocks of the control-block
+// shadows and of finalize's staging.  Optional; part of bringing the device context up, like the first HIP call.
+int32_t sdplr_hip_warmup(int32_t n_handles) {
+  ApiShared api_guard;
+  if (have_device() <= 0) return fail(nullptr, SDPLR_ERR_NO_DEVICE, "no HIP device");
+  if (n_handles < 1 || n_handles > 64) return fail(nullptr, SDPLR_ERR_INVALID_ARG, "warmup: 1 ≤ n_handles ≤ 64");
+  std::vector<hipStream_t> st(n_handles, nullptr);
+  std::vector<hipEvent_t> ev(2 * (size_t)n_handles, nullptr);
+  std::vector<void*> pc(3 * (size_t)n_handles, nullptr), ch(n_handles, nullptr);
+  hipError_t e = hipSuccess;
+  for (auto& x : st) if (e == hipSuccess) e = pool_stream(&x);
+  for (auto& x : ev) if (e == hipSuccess) e = pool_event(&x);
+  for (auto& x : pc) if (e == hipSuccess) e = pool_host_ctrl(&x);
+  for (auto& x : ch) if (e == hipSuccess) e = pool_host_chunk(&x);
+  for (auto x : st) pool_stream_free(x);
+  for (auto x : ev) pool_event_free(x);
+  for (auto x : pc) pool_host_ctrl_free(x);
+  for (auto x : ch) pool_host_chunk_free(x);
+  if (e != hipSuccess) return fail(nullptr, SDPLR_ERR_HIP, std::string("warmup: ") + hipGetErrorString(e));
+  return SDPLR_OK;
+}
+
 int32_t sdplr_hip_create(int64_t n, int64_t m, int64_t r, int64_t h, sdplr_hip_solver** out) {
   ApiShared api_guard;
   if (!out) return fail(nullptr, SDPLR_ERR_INVALID_ARG, "create: null out");
@@ -1166,19 +1243,20 @@ int32_t sdplr_hip_finalize(S* s) {
   ApiShared api_guard;
   if (!s) return fail(nullptr, SDPLR_ERR_INVALID_ARG, "null handle");
   if (s->finalized) return fail(s, SDPLR_ERR_STATE, "finalize: already finalized");
-  HIPCK(s, pool_stream(&s->stream));
   const int64_t n = s->n, m = s->m;
   int rc;
   s->up.on = getenv("SDPLR_HIP_NO_UPLOAD_ARENA") == nullptr;
   // SDPLR_HIP_TIMING=1: where the set-up time goes (stderr)
   const bool timing = getenv("SDPLR_HIP_TIMING") != nullptr;
   auto t_last = std::chrono::steady_clock::now();
+  HIPCK(s, pool_stream(&s->stream));
   auto lap = [&](const char* what) {
     if (!timing) return;
     const auto t = std::chrono::steady_clock::now();
     fprintf(stderr, "[sdplr_hip finalize] %-28s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(t - t_last).count());
     t_last = t;
   };
+  lap("stream");
   // ---- sparse layout ----
   DevSparse& sp = s->sp;
   sp.n = (int)n; sp.nnzT = (int)s->nnzT; sp.nnzS = (int)s->nnzS; sp.nnzAgg = (int)s->nnzAgg; sp.n_sparse = (int)s->n_sparse;
@@ -1543,9 +1621,10 @@ int32_t sdplr_hip_finalize(S* s) {
   s->nb_nnzT = blocks_for(s->nnzT, SDPLR_NT, 4096);
   s->nb_nnzS = blocks_for(s->nnzS, SDPLR_NT, 4096);
   s->nb_n = blocks_for(n, SDPLR_NT, 1024);
+  lap("before commit");
   if ((rc = arena_commit(s))) return rc;
   s->up.on = false;
-  std::vector<char>().swap(s->up.host);
+  lap("arena commit");
   // low-rank scratch depends on r: allocated for the largest rank seen (reset_rank re-allocates)
   if ((rc = dzero(s, &s->lr_part, (size_t)std::max(s->nb_lr, SDPLR_MAXNB) * 2 * std::max(lr.ST, 1) * s->r))) return rc;
   if ((rc = dzero(s, &s->lr_W, (size_t)2 * std::max(lr.ST, 1) * s->r))) return rc;
@@ -1554,7 +1633,9 @@ int32_t sdplr_hip_finalize(S* s) {
   std::vector<int>().swap(s->h_nzind); std::vector<int>().swap(s->h_trv); std::vector<int>().swap(s->h_frv);
   std::vector<int>().swap(s->h_mapped); std::vector<double>().swap(s->h_one); std::vector<double>().swap(s->h_two);
   for (auto& L : s->h_lr) { std::vector<double>().swap(L.B); }
+  lap("rank-sized scratch");
   HIPCK(s, hipStreamSynchronize(s->stream));
+  lap("final sync");
   s->finalized = true;
   return SDPLR_OK;
 }
@@ -1570,6 +1651,7 @@ int32_t sdplr_hip_destroy(S* s) {
   if (s->lz_alpha) pool_free(s->lz_alpha);
   if (s->lz_beta) pool_free(s->lz_beta);
   if (s->hc) pool_host_ctrl_free(s->hc);
+  if (s->up.host) pool_host_chunk_free(s->up.host);   // (a finalize that failed half-way)
   if (s->lz_graph) (void)hipGraphExecDestroy(s->lz_graph);
   for (int k = 0; k < 2; k++) {
     if (s->snap[k]) pool_host_ctrl_free(s->snap[k]);
@@ -2253,8 +2335,12 @@ bool rs_lanczos_applies(const S* s) {
     }                                                                                                                \
   } while (0)
 
-int enq_resident_loop(S* s, double time_budget_s, bool refresh_P) {
+int enq_resident_loop(S* s, double time_budget_s, bool refresh_P, bool pre_lambda = false, bool pre_clear_fg = false) {
   RsLoopArgs a{};
+  a.pre_lambda = pre_lambda ? 1 : 0;
+  a.pre_clear = a.pre_fg = pre_clear_fg ? 1 : 0;
+  a.b = s->b;
+  a.lam_rw = s->lambda;
   a.n = (int)s->n; a.m = (int)s->m; a.r = (int)s->r; a.h = (int)s->h;
   a.gid_g = s->ff.gid_g;
   a.row_k = s->rs_row_k; a.row_v = s->rs_row_v;
@@ -2271,6 +2357,40 @@ int enq_resident_loop(S* s, double time_budget_s, bool refresh_P) {
   HIPCK(s, hipGetLastError());
   s->st_rs_loops++;
   return SDPLR_OK;
+}
+
+// launch + wait + the host-side bookkeeping of one resident loop (the control block has been pushed by the caller);
+// pre_lambda / pre_clear_fg: the head of a major iteration rides the same launch (sdplr_hip_major_iteration)
+int run_resident_loop(S* s, double time_budget_s, bool pre_lambda, bool pre_clear_fg, double* Lio, double* gnio, double* pnio,
+                      double* last_alpha, int64_t* iters, int32_t* exit_reason) {
+  static const int64_t refresh_iters = getenv("SDPLR_HIP_P_REFRESH_ITERS") ? atoll(getenv("SDPLR_HIP_P_REFRESH_ITERS")) : 256;
+  const bool refresh = pre_clear_fg || !s->P_valid || s->P_age >= refresh_iters;   // (fg! rebuilds P = A_g·R itself)
+  int rc = enq_resident_loop(s, time_budget_s, refresh, pre_lambda, pre_clear_fg);
+  if (rc) return rc;
+  s->P_valid = true;
+  if (refresh) s->P_age = 0;
+  s->S_stale = true;   // y is current, S is assembled by whoever reads it next (ensure_S)
+  s->S_from_y = true;
+  if (pre_clear_fg) { s->st_rs_fg++; s->gram_dirty = false; }
+  if ((rc = pull_blocking(s))) return rc;
+  DevCtrl* c = s->hc;
+  const int why_rs = c->exit_reason;
+  // (`dirt *= α`, src/lbfgs.jl:142: the kernel itself left dirt = s_latest)
+  // no iteration ran after the fg! of the prologue: the dots with G are those of a cleared history (zero, exact)
+  s->sg_stale = (why_rs == EXIT_RELDELTA);
+  s->ynext_pending = (why_rs == EXIT_RELDELTA) && s->h > 0;
+  if (c->err == SDPLR_ERR_NOT_DESCENT) {
+    c->err = 0; c->done = 0;
+    (void)push(s);
+    return fail(s, SDPLR_ERR_NOT_DESCENT, "Error: cubic[1] should be less than 0.");
+  }
+  s->st_iters += c->iters;
+  s->P_age += c->iters;
+  *Lio = c->L; *gnio = c->gnorm; *pnio = c->pvnorm;
+  if (last_alpha) *last_alpha = c->alpha;
+  if (iters) *iters = c->iters;
+  if (exit_reason) *exit_reason = why_rs;
+  return SDPLR_OK;   // (pull_blocking has drained the stream and checked the launch)
 }
 
 // host restatement of the Sturm bisection for the Lanczos tridiagonal
@@ -2402,6 +2522,30 @@ void enq_lz_step(S* s, double* uprev, double* u, double* t) {
   k_lz_step<<<s->nb_n, SDPLR_NT, 0, s->stream>>>((int)s->n, s->ctrl, uprev, u, t, s->lr, s->lr_btx_part, s->nb_lzv + std::min(s->sp.n_long_rows, 256), s->lz_alpha, s->partials);
 }
 
+// the structured resident Lanczos (k_rs_lanczos_ell); dual: with copy2y in front and ⟨y, b⟩ + the tridiagonal's smallest
+// eigenvalue behind it — the whole of dual_obj (src/coreop.jl:376-415) in one launch
+int enq_lanczos_ell(S* s, int64_t q, bool dual) {
+  const int64_t n = s->n;
+  RsLzEllArgs a{};
+  a.n = (int)n; a.q = (int)q;
+  a.E = s->rs_ell; a.gid_g = s->ff.gid_g; a.row_k = s->rs_row_k; a.row_v = s->rs_row_v;
+  a.yvec = s->y; a.v0 = s->lz_v0;
+  a.alpha_out = s->lz_alpha; a.beta_out = s->lz_beta; a.c = s->ctrl;
+  a.dual = dual ? 1 : 0; a.m = (int)s->m; a.y_rw = s->y;
+  a.lam = s->lambda; a.lam_ub = s->lambda_ub; a.pv_raw = s->pv_raw; a.b = s->b;
+  const size_t base = (size_t)4 * n * sizeof(double), packed = s->rs_ell_pair_lines * 64 * sizeof(unsigned);
+  if (s->rs_ell.val == nullptr && base + packed <= RS_LDS_MAX && getenv("SDPLR_HIP_RESIDENT_LZ_STREAM") == nullptr) {
+    RS_SET_ATTR(k_rs_lanczos_ell<true>);
+    k_rs_lanczos_ell<true><<<1, SDPLR_RS_NT, base + packed, s->stream>>>(a);
+  } else {
+    RS_SET_ATTR(k_rs_lanczos_ell<false>);
+    k_rs_lanczos_ell<false><<<1, SDPLR_RS_NT, base, s->stream>>>(a);
+  }
+  HIPCK(s, hipGetLastError());
+  s->st_rs_lz++;
+  return SDPLR_OK;
+}
+
 // approx_mineigval_lanczos's recurrence, src/coreop.jl:461-500 (see k_sparse.h "Lanczos recurrence")
 int run_lanczos(S* s, int64_t q, const double* v0, double* alpha, double* beta, int64_t* steps,
                 ApiLock* api_lock) {
@@ -2417,21 +2561,7 @@ int run_lanczos(S* s, int64_t q, const double* v0, double* alpha, double* beta, 
     HIPCK(s, hipMemsetAsync(s->lz_alpha, 0, q * sizeof(double), s->stream));
     HIPCK(s, hipMemsetAsync(s->lz_beta, 0, q * sizeof(double), s->stream));
     if (rs_lanczos_ell_applies(s)) {   // S(y) = y_g·A_g + Diag(d(y)) straight from the ELL of A_g and y: no assembled S is read
-      RsLzEllArgs a{};
-      a.n = (int)n; a.q = (int)q;
-      a.E = s->rs_ell; a.gid_g = s->ff.gid_g; a.row_k = s->rs_row_k; a.row_v = s->rs_row_v;
-      a.yvec = s->y; a.v0 = s->lz_v0;
-      a.alpha_out = s->lz_alpha; a.beta_out = s->lz_beta; a.c = s->ctrl;
-      const size_t base = (size_t)4 * n * sizeof(double), packed = s->rs_ell_pair_lines * 64 * sizeof(unsigned);
-      if (s->rs_ell.val == nullptr && base + packed <= RS_LDS_MAX && getenv("SDPLR_HIP_RESIDENT_LZ_STREAM") == nullptr) {
-        RS_SET_ATTR(k_rs_lanczos_ell<true>);
-        k_rs_lanczos_ell<true><<<1, SDPLR_RS_NT, base + packed, s->stream>>>(a);
-      } else {
-        RS_SET_ATTR(k_rs_lanczos_ell<false>);
-        k_rs_lanczos_ell<false><<<1, SDPLR_RS_NT, base, s->stream>>>(a);
-      }
-      HIPCK(s, hipGetLastError());
-      s->st_rs_lz++;
+      if ((rc = enq_lanczos_ell(s, q, false))) return rc;
       HIPCK(s, hipMemcpyAsync(alpha, s->lz_alpha, q * sizeof(double), hipMemcpyDeviceToHost, s->stream));
       HIPCK(s, hipMemcpyAsync(beta, s->lz_beta, q * sizeof(double), hipMemcpyDeviceToHost, s->stream));
       if ((rc = pull_blocking(s))) return rc;
@@ -2806,12 +2936,16 @@ int32_t sdplr_hip_inner_loop(S* s, double normC, double normb, int32_t grel, int
                              double* Lio, double* gnio, double* pnio, double* last_alpha, int64_t* iters,
                              int32_t* exit_reason) {
   ApiLock api_lock(g_api_rw);
+  const bool hc_was_valid = s && s->finalized && s->hc_valid;
   NEED_FINAL_RW(s);
   if (!Lio || !gnio || !pnio || max_local_iters < 1) return fail(s, SDPLR_ERR_INVALID_ARG, "inner_loop: bad args");
+  const bool gram_work = s->h > 0 && (s->gram_dirty || s->ynext_pending || s->sg_stale);
   ensure_gram(s);
   int rc = tile_lds_attr(s);
   if (rc) return rc;
-  if ((rc = pull(s))) return rc;
+  s->hc_valid = hc_was_valid && !gram_work;   // (nothing has been enqueued since the shadow was last in step)
+  if ((rc = pull_if_stale(s))) return rc;
+  s->hc_valid = false;
   DevCtrl* c = s->hc;
   c->done = 0; c->exit_reason = 0; c->err = 0; c->use_armijo = use_armijo;
   c->iters = 0; c->max_iters = max_local_iters; c->reldelta_exit = 0; c->norms_pending = 0; c->pv2_extra = 0.0;
@@ -2827,33 +2961,7 @@ int32_t sdplr_hip_inner_loop(S* s, double normC, double normb, int32_t grel, int
   if (rs_loop_applies(s, use_armijo)) {
     // resident route (k_resident.h): the whole while loop is ONE launch of one workgroup; every exit — the time
     // budget too — is taken on the device, the host reads the control block once
-    static const int64_t refresh_iters = getenv("SDPLR_HIP_P_REFRESH_ITERS") ? atoll(getenv("SDPLR_HIP_P_REFRESH_ITERS")) : 256;
-    const bool refresh = !s->P_valid || s->P_age >= refresh_iters;
-    if ((rc = enq_resident_loop(s, time_budget_s, refresh))) return rc;
-    s->P_valid = true;
-    if (refresh) s->P_age = 0;
-    s->S_stale = true;   // y is current, S is assembled by whoever reads it next (ensure_S)
-    s->S_from_y = true;
-    if ((rc = pull_blocking(s))) return rc;
-    const int why_rs = c->exit_reason;
-    if (c->iters > 0 && c->err == 0 && why_rs != EXIT_RELDELTA) {
-      // `dirt *= α` (src/lbfgs.jl:142) is left to this copy: dirt = s_latest
-      HIPCK(s, hipMemcpyAsync(aslot(s->arena, AS_D), aslot(s->arena, AS_S0 + (c->latest - 1)), s->N * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
-    }
-    s->sg_stale = (why_rs == EXIT_RELDELTA);
-    s->ynext_pending = (why_rs == EXIT_RELDELTA) && s->h > 0;
-    if (c->err == SDPLR_ERR_NOT_DESCENT) {
-      c->err = 0; c->done = 0;
-      (void)push(s);
-      return fail(s, SDPLR_ERR_NOT_DESCENT, "Error: cubic[1] should be less than 0.");
-    }
-    s->st_iters += c->iters;
-    s->P_age += c->iters;
-    *Lio = c->L; *gnio = c->gnorm; *pnio = c->pvnorm;
-    if (last_alpha) *last_alpha = c->alpha;
-    if (iters) *iters = c->iters;
-    if (exit_reason) *exit_reason = why_rs;
-    return sync_check(s);
+    return run_resident_loop(s, time_budget_s, false, false, Lio, gnio, pnio, last_alpha, iters, exit_reason);
   }
   const int ar = use_armijo ? 1 : 0;
   const bool fastp = s->fast;
@@ -3021,6 +3129,52 @@ int32_t sdplr_hip_inner_loop(S* s, double normC, double normb, int32_t grel, int
   return sync_check(s);
 }
 
+// One major iteration's device work as ONE call: [λ update (src/sdplr.jl:358-362)] → σ → lbfgs_clear! (:384) → fg! (:389)
+// → the inner while loop (:190-278) on what fg! returned.  On the resident route the five are one launch; otherwise this
+// is the sequence of the entry points above.
+int32_t sdplr_hip_major_iteration(S* s, double normC, double normb, int32_t grel, int32_t prel, int32_t use_armijo,
+                                  int32_t update_lambda, double sigma, double cur_gtol, double fprec_eps,
+                                  int64_t max_local_iters, double time_budget_s, double* L, double* gn, double* pn,
+                                  double* last_alpha, int64_t* iters, int32_t* exit_reason) {
+  if (!s) return fail(nullptr, SDPLR_ERR_INVALID_ARG, "null handle");
+  if (!L || !gn || !pn || max_local_iters < 1) return fail(s, SDPLR_ERR_INVALID_ARG, "major_iteration: bad args");
+  bool resident = false;
+  {
+    ApiShared api_guard;
+    const bool hc_was_valid = s->finalized && s->hc_valid;
+    NEED_FINAL_RW(s);
+    resident = rs_loop_applies(s, use_armijo) && rs_fg_applies(s);
+    if (resident) {
+      const bool was_valid = hc_was_valid;
+      s->hc_valid = was_valid;
+      int rc = pull_if_stale(s);   // (every entry point returns with its stream drained)
+      if (rc) return rc;
+      s->hc_valid = false;
+      DevCtrl* c = s->hc;
+      c->sigma = sigma;
+      c->done = 0; c->exit_reason = 0; c->err = 0; c->use_armijo = use_armijo;
+      c->iters = 0; c->max_iters = max_local_iters; c->reldelta_exit = 0; c->norms_pending = 0; c->pv2_extra = 0.0;
+      c->cur_gtol = cur_gtol; c->fprec_eps = fprec_eps; c->normC = normC; c->normb = normb;
+      c->grel = grel; c->prel = prel;
+      c->alpha = 0.0; c->alpha_max = 1.0;
+      if ((rc = push(s))) return rc;
+      s->sg_stale = s->ynext_pending = false;   // (cleared history: see sdplr_hip_lbfgs_clear)
+      return run_resident_loop(s, time_budget_s, update_lambda != 0, true, L, gn, pn, last_alpha, iters, exit_reason);
+    }
+  }
+  int32_t rc;
+  if (update_lambda && (rc = sdplr_hip_update_lambda(s))) return rc;
+  if ((rc = sdplr_hip_set_scalar(s, SDPLR_S_SIGMA, sigma))) return rc;
+  if ((rc = sdplr_hip_lbfgs_clear(s))) return rc;
+  if ((rc = sdplr_hip_fg(s, normC, normb, grel, prel, L, gn, pn))) return rc;
+  if (last_alpha) *last_alpha = 0.0;
+  if (iters) *iters = 0;
+  if (exit_reason) *exit_reason = EXIT_GTOL;
+  if (!(*gn > cur_gtol)) return SDPLR_OK;           // src/sdplr.jl:190
+  return sdplr_hip_inner_loop(s, normC, normb, grel, prel, use_armijo, cur_gtol, fprec_eps, max_local_iters, time_budget_s,
+                              L, gn, pn, last_alpha, iters, exit_reason);
+}
+
 // ---- Lanczos / dual bound ------------------------------------------------------------------------------
 int32_t sdplr_hip_lanczos(S* s, int64_t q, const double* v0, double* alpha, double* beta, int64_t* steps) {
   ApiShared api_guard;
@@ -3066,6 +3220,24 @@ int32_t sdplr_hip_dual_obj(S* s, double trace_bound, int64_t iter, const double*
   ApiShared api_guard;
   NEED_FINAL_RW(s);
   if (!v0) return fail(s, SDPLR_ERR_INVALID_ARG, "dual_obj: null v0");
+  if (rs_lanczos_ell_applies(s) && s->n >= 2 && getenv("SDPLR_HIP_NO_FUSED_DUAL") == nullptr) {
+    // resident route: copy2y (:384), the q Lanczos steps on S(y) (:461-500), the tridiagonal's smallest eigenvalue
+    // (:502-513) and ⟨y, b⟩ (:412) are ONE launch; S itself is assembled (:385) only if somebody reads it later
+    const double itd = (double)std::max<int64_t>(iter, 100);
+    int64_t q = (int64_t)(2 * std::ceil(std::pow(itd, 0.5) * std::log((double)s->n)));   // :402
+    q = std::min<int64_t>(q, s->n - 1);                                                    // :465
+    int rc = ensure_lz_capacity(s, q);
+    if (rc) return rc;
+    HIPCK(s, hipMemcpyAsync(s->lz_v0, v0, s->n * sizeof(double), hipMemcpyHostToDevice, s->stream));
+    if ((rc = enq_lanczos_ell(s, q, true))) return rc;
+    s->S_stale = true;
+    s->S_from_y = true;
+    if ((rc = pull_blocking(s))) return rc;
+    const double ev = s->hc->lz_mineig;
+    if (dual_value) *dual_value = -s->hc->descent + trace_bound * std::min(ev, 0.0);        // :412
+    if (mineig) *mineig = ev;
+    return SDPLR_OK;
+  }
   enq_copy2y(s, 0);              // src/coreop.jl:384
   s->S_from_y = true;
   if (rs_lanczos_ell_applies(s)) {

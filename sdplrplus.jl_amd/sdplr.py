@@ -157,13 +157,23 @@ def _sdplr(data: SDPData, var: DeviceSolver, config: BurerMonteiroConfig,
     best_λ = var.λ.copy()
     rng = _rng(config)
 
+    # The tail of a major iteration — λ update or σ increase (:358-369), lbfgs_clear! (:384), fg! (:389) — is device work
+    # with no host decision in between, and so is the while loop it feeds: with the native loop the four travel as ONE
+    # call (``major_iteration``; one kernel launch on small instances).  `pending` holds a tail not yet sent.
+    pending = None
     for _ in range(config.maxmajoriter):        # :185
         majoriter += 1
         localiter = 0
         if native_inner_loop:
-            if grad_norm > cur_gtol:
-                budget = max(config.maxiter + 1 - iter_, 1)
-                tleft = config.maxtime - (time.time() - starttime)
+            budget = max(config.maxiter + 1 - iter_, 1)
+            tleft = config.maxtime - (time.time() - starttime)
+            if pending is not None:
+                L_val, grad_norm, primal_vio_norm, _α, localiter, _why = var.major_iteration(
+                    normC, normb, grel, prel, use_armijo, pending[0], pending[1], cur_gtol, config.fprec * EPS,
+                    budget, max(tleft, 1e-9))
+                pending = None
+                iter_ += localiter
+            elif grad_norm > cur_gtol:
                 L_val, grad_norm, primal_vio_norm, _α, localiter, _why = var.inner_loop(
                     normC, normb, grel, prel, use_armijo, cur_gtol, config.fprec * EPS, budget,
                     max(tleft, 1e-9), L_val, grad_norm, primal_vio_norm)
@@ -247,14 +257,20 @@ def _sdplr(data: SDPData, var: DeviceSolver, config: BurerMonteiroConfig,
                 min_duality_gap = min(min_duality_gap, duality_gap)
                 if rankupd_tol_cnt == 0:
                     rank_double = True
-            var.update_lambda()                                 # :358-362
+            upd_λ = True                                        # :358-362
             cur_ptol = cur_ptol / σ ** 0.9                      # :363-364
             cur_gtol = cur_gtol / σ
         else:
+            upd_λ = False
             σ = σ * config.σfac                                 # :366-369
-            var.σ = σ
             cur_ptol = 1 / σ ** 0.1
             cur_gtol = 1 / σ
+        fuse_tail = native_inner_loop and not rank_double and majoriter < config.maxmajoriter
+        if not fuse_tail:
+            if upd_λ:
+                var.update_lambda()
+            else:
+                var.σ = σ
 
         if rank_double:                                         # :373-382
             newr = min(barvinok_pataki(data.n, data.m), var.r * 2)    # coreop.jl:518-526
@@ -268,12 +284,15 @@ def _sdplr(data: SDPData, var: DeviceSolver, config: BurerMonteiroConfig,
             rankupd_tol_cnt = config.rankupd_tol
             if config.printlevel > 0:
                 print(f"rank doubled, newrank is {var.r}.", flush=True)
-        else:
+        elif not fuse_tail:
             var.lbfgs_clear()                                   # :384
 
         cur_ptol = max(cur_ptol, config.ptol)                   # :387-389
         cur_gtol = max(cur_gtol, config.gtol)
-        L_val, grad_norm, primal_vio_norm = var.fg(normC, normb, grel, prel)
+        if fuse_tail:
+            pending = (upd_λ, σ)                                # sent with the next pass of the while loop
+        else:
+            L_val, grad_norm, primal_vio_norm = var.fg(normC, normb, grel, prel)
         if majoriter == config.maxmajoriter:
             print("Warning: Major iteration limit exceeded. Stop optimizing.", file=sys.stderr)
 

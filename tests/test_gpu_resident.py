@@ -236,7 +236,7 @@ def test_resident_loop_is_run_to_run_deterministic_and_reports_not_descent(hip_a
 
 
 @pytest.mark.parametrize("family", ["maxcut", "minimum_bisection", "lovasz_theta"])
-def test_resident_lanczos_and_dual_obj(hip_abi, oracle_abi, family):
+def test_resident_lanczos_and_dual_obj(hip_abi, oracle_abi, family, monkeypatch):
     """approx_mineigval_lanczos (src/coreop.jl:461-514) as one launch: the raw α, β of every step against the oracle
     (plain normalised recurrence on both sides), the Ritz value, dual_obj; the low-rank term of MinBisection / Lovász-θ
     rides along; the early exit on an invariant subspace (:494-496)."""
@@ -248,6 +248,16 @@ def test_resident_lanczos_and_dual_obj(hip_abi, oracle_abi, family):
     (dg, eg), (do, eo) = g.dual_obj(float(n), 0, v0), o.dual_obj(float(n), 0, v0)
     assert g.stats()["resident_lanczos"] == 1
     assert eg == pytest.approx(eo, abs=1e-8 * max(1, abs(eo))) and dg == pytest.approx(do, rel=1e-8)
+    if family == "maxcut":
+        # on the instances of the resident loop dual_obj is ONE launch (copy2y, the recurrence, the tridiagonal's smallest
+        # eigenvalue by 64-point multisection, ⟨y, b⟩); piece by piece — host bisection — it must give the very same numbers
+        monkeypatch.setenv("SDPLR_HIP_NO_FUSED_DUAL", "1")
+        d2, e2 = g.dual_obj(float(n), 0, v0)
+        monkeypatch.delenv("SDPLR_HIP_NO_FUSED_DUAL")
+        assert (d2, e2) == (dg, eg)
+        d3, e3 = g.dual_obj(float(n), 40000, v0)      # q = 2⌈200·ln n⌉ > n − 1: clipped (src/coreop.jl:465)
+        d4, e4 = o.dual_obj(float(n), 40000, v0)
+        assert e3 == pytest.approx(e4, abs=1e-8 * max(1, abs(e4))) and d3 == pytest.approx(d4, rel=1e-8)
     ag, bg, kg = g.lanczos(5, v0)
     ao, bo, ko = o.lanczos(5, v0)
     assert kg == ko == 5   # (plain Lanczos: later steps of the rank-one cases are ill-conditioned on both sides)
@@ -333,3 +343,46 @@ def test_native_preprocessing_edge_cases(hip_abi):
                         np.zeros(0), np.zeros(0, dtype=np.int64))
     e = native(empty)
     assert e.nnzT == 0 and e.nnzS == 0 and e.nnzAgg == 0
+
+
+@pytest.mark.parametrize("update_lambda", [True, False])
+def test_major_iteration_is_the_sequence_it_stands_for(hip_abi, oracle_abi, update_lambda, monkeypatch):
+    """sdplr_hip_major_iteration — [λ update] → σ → lbfgs_clear! → fg! → while loop (src/sdplr.jl:358-369, :384, :389,
+    :190-278) as ONE resident launch — against the same five calls made one by one on the HIP library (its multi-launch
+    route) and on the oracle: state after the call, and the continuation."""
+    data = problems.maxcut_data(problems.gnp_graph(200, 0.05, 3))
+    normC, normb = data.normC(), float(np.linalg.norm(data.b))
+    g, o = pair(hip_abi, oracle_abi, data, 6, 2)
+    monkeypatch.setenv("SDPLR_HIP_NO_RESIDENT", "1")
+    g2, _ = make_solver(hip_abi, data, 6, seed=2)      # the same library, one call at a time on the multi-launch route
+    monkeypatch.delenv("SDPLR_HIP_NO_RESIDENT")
+    outs = []
+    for s_ in (g, o, g2):
+        st = s_.fg(normC, normb)
+        st = run(s_, normC, normb, 12, st)[:3]
+        sigma = 2.0 if update_lambda else 4.0
+        if s_ is g2:
+            if update_lambda:
+                s_.update_lambda()
+            s_.σ = sigma
+            s_.lbfgs_clear()
+            st = s_.fg(normC, normb)
+            res = run(s_, normC, normb, 9, st, gtol=1e-3)
+        else:
+            res = s_.major_iteration(normC, normb, True, True, False, update_lambda, sigma, 1e-3, -1e300, 9, 0.0)
+        outs.append(res)
+    assert g.stats()["resident_loops"] == 2 and g.stats()["resident_fg"] == 2 and g2.stats()["resident_loops"] == 0
+    for res in outs[1:]:
+        assert res[4] == outs[0][4] == 9 and np.allclose(res[:3], outs[0][:3], rtol=1e-8)
+    for other in (o, g2):
+        assert rel(g.Rt, other.Rt) < 1e-8 and rel(g.λ, other.λ) < 1e-12 and g.σ == other.σ
+        assert rel(g.y, other.y) < 1e-8 and rel(g.Gt, other.Gt) < 1e-7 and rel(g.dirt, other.dirt) < 1e-6
+        assert g.get_scalar(cabi.S_LBFGS_LATEST) == other.get_scalar(cabi.S_LBFGS_LATEST)
+        assert np.allclose(g.get_vec(cabi.V_LBFGS_RHO), other.get_vec(cabi.V_LBFGS_RHO), rtol=1e-6)
+    # already converged for fg!'s gradient: no iteration, exit 0, and fg!'s values come back
+    r0 = [s_.major_iteration(normC, normb, True, True, False, False, 8.0, 1e9, -1e300, 5, 0.0) for s_ in (g, o)]
+    assert r0[0][4] == r0[1][4] == 0 and r0[0][5] == r0[1][5] == 0 and np.allclose(r0[0][:3], r0[1][:3], rtol=1e-9)
+    rg, ro = run(g, normC, normb, 5, r0[0][:3]), run(o, normC, normb, 5, r0[1][:3])
+    assert rg[4] == ro[4] == 5 and np.allclose(rg[:3], ro[:3], rtol=1e-7)
+    for s_ in (g, o, g2):
+        s_.close()
