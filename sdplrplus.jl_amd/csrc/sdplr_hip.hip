@@ -732,7 +732,11 @@ int build_band(S* s) {
   const int hub_blocks = s->sp.n_long_rows > 0 ? std::min((s->sp.n_long_rows + 3) / 4, 64) : 0;
   int NC = std::max<int>((int)((n + CHMAX - 1) / CHMAX), std::max(1, (256 - hub_blocks - (hub_blocks > 0 ? 1 : 0)) / NB));
   if (const char* e = getenv("SDPLR_HIP_LZBAND_NC")) NC = std::max(NC, atoi(e));
-  if ((int64_t)NB * NC > 1024) return SDPLR_OK;
+  // the kernel's static LDS (wave sums, the palette) comes out of the same 160 KB as the x band and the chunk's partial t:
+  // more chunks (a shorter t) where a full band and a full chunk would not fit together (n = 2¹⁷, 2¹⁸ and just below)
+  constexpr int64_t LZB_LDS_BUDGET = 160 * 1024 - (16 + 256) * 8 - 256;
+  while (((int64_t)BW + (n + NC - 1) / NC) * 8 > LZB_LDS_BUDGET && (int64_t)NB * (NC + 1) <= 1024) NC++;
+  if ((int64_t)NB * NC > 1024 || ((int64_t)BW + (n + NC - 1) / NC) * 8 > LZB_LDS_BUDGET) return SDPLR_OK;
   const int CH = (int)((n + NC - 1) / NC);
   const int thresh = s->sp.long_thresh;
   auto is_hub = [&](int64_t j) { return s->sp.n_long_rows > 0 && s->h_fcp[j + 1] - s->h_fcp[j] > thresh; };
@@ -869,11 +873,18 @@ int build_band(S* s) {
   }
   if ((rc = dzero(s, &bd.tpart, (size_t)NB * n))) return rc;
   if ((rc = dzero(s, &bd.textra, (size_t)n))) return rc;
-  // more than 64 KB of dynamic LDS has to be asked for
-  HIPCK(s, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lz_band<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (int)((size_t)(BW + CH) * sizeof(double))));
-  HIPCK(s, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lz_band<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (int)((size_t)(BW + CH) * sizeof(double))));
+  // more than 64 KB of dynamic LDS has to be asked for: a per-function, PROCESS-wide attribute — set once, to the fixed
+  // upper bound (a per-handle value would lower the cap under another handle's feet)
+  {
+    static std::mutex mu;
+    static bool done = false;
+    std::lock_guard<std::mutex> g(mu);
+    if (!done) {
+      HIPCK(s, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lz_band<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LZB_LDS_BUDGET));
+      HIPCK(s, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lz_band<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LZB_LDS_BUDGET));
+      done = true;
+    }
+  }
   s->use_band = true;
   return SDPLR_OK;
 }
@@ -1850,9 +1861,22 @@ namespace {
 int tile_lds_attr(S* s) {
   if (!s->use_tile || s->tile_attr_done) return SDPLR_OK;
   const int bytes = (int)(((size_t)SDPLR_NT * s->VEC * (s->tile.K + 1) + (size_t)(SDPLR_NT / s->LPR) * (2 * s->tile.K + 8) + (size_t)(SDPLR_NT / 64) * 2 * s->LPR * s->VEC) * sizeof(double));
+  // The attribute is per function and PROCESS-wide: each instantiation keeps the largest value any handle has asked for
+  // (a smaller request from another handle, or after a rank change, must not lower the cap under the first one's feet).
+  static std::mutex mu;
+  std::lock_guard<std::mutex> g(mu);
   hipError_t e = hipSuccess;
-  LV_DISPATCH((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_spmm_tile<LPR, VEC, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes)))
-  if (e == hipSuccess) { LV_DISPATCH((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_spmm_tile<LPR, VEC, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes))) }
+#define TILE_ATTR(LRN)                                                                                                           \
+  LV_DISPATCH(({                                                                                                                  \
+    static int cur_max = 0;                                                                                                       \
+    if (bytes > cur_max) {                                                                                                        \
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_spmm_tile<LPR, VEC, LRN>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes); \
+      if (e == hipSuccess) cur_max = bytes;                                                                                       \
+    }                                                                                                                             \
+  }))
+  TILE_ATTR(0)
+  if (e == hipSuccess) { TILE_ATTR(1) }
+#undef TILE_ATTR
   if (e != hipSuccess) return fail(s, SDPLR_ERR_HIP, std::string("hipFuncSetAttribute(k_spmm_tile): ") + hipGetErrorString(e));
   s->tile_attr_done = true;
   return SDPLR_OK;
@@ -2973,6 +2997,9 @@ int32_t sdplr_hip_inner_loop(S* s, double normC, double normb, int32_t grel, int
     else if (edgep) enq_iteration_edge(s);
     else enq_iteration(s, use_armijo);
   };
+  // the structured loops leave y current and S unassembled: said before the first enqueue, so that an error return on the
+  // way cannot leave a stale S marked as assembled
+  if (fastp || edgep) { s->S_stale = true; s->S_from_y = true; }
   if (fastp) {
     static const int64_t refresh_iters = getenv("SDPLR_HIP_P_REFRESH_ITERS") ? atoll(getenv("SDPLR_HIP_P_REFRESH_ITERS")) : 256;
     if (!s->P_valid || s->P_age >= refresh_iters) {

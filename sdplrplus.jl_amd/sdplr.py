@@ -161,6 +161,7 @@ def _sdplr(data: SDPData, var: DeviceSolver, config: BurerMonteiroConfig,
     # with no host decision in between, and so is the while loop it feeds: with the native loop the four travel as ONE
     # call (``major_iteration``; one kernel launch on small instances).  `pending` holds a tail not yet sent.
     pending = None
+    schedule = []   # per major iteration: (majoriter, inner iterations, σ, η, ω, rank) — what printintermediate shows (src/myprint.jl:17-58)
     for _ in range(config.maxmajoriter):        # :185
         majoriter += 1
         localiter = 0
@@ -210,6 +211,7 @@ def _sdplr(data: SDPData, var: DeviceSolver, config: BurerMonteiroConfig,
         current_time = time.time()
         _print_row(config, majoriter, localiter, iter_, L_val, var.obj, var.σ, cur_gtol, cur_ptol,
                    grad_norm, primal_vio_norm, min_duality_gap, max_dual_value)
+        schedule.append((majoriter, int(localiter), float(var.σ), float(cur_gtol), float(cur_ptol), int(var.r)))
         lastprint = current_time
         if current_time - starttime > config.maxtime:           # :298-301
             print("Warning: Time limit exceeded. Stop optimizing.", file=sys.stderr)
@@ -310,6 +312,7 @@ def _sdplr(data: SDPData, var: DeviceSolver, config: BurerMonteiroConfig,
         "iter": iter_, "majoriter": majoriter, "DIMACS_errs": DIMACS_errs, "ptol": config.ptol,
         "objtol": config.objtol, "fprec": config.fprec, "rankupd_tol": config.rankupd_tol,
         "r": Rt.shape[1],
+        "schedule": schedule,                                   # not in the reference's Dict: the per-major-iteration log
     }
 
 
