@@ -29,6 +29,9 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# config 5 (other_configs) keeps 16 small instances in flight, each a resident launch that holds its hardware queue for
+# milliseconds: one queue per instance (ROCm's default is 4 per process).  Read when HIP starts; no effect on the headline.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured streaming)
 N_NODES, P_EDGE, RANK_R, GRAPH_SEED, R_SEED = 100_000, 2e-4, 32, 20240610, 0
@@ -41,6 +44,7 @@ def parse_args(argv=None):
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the other_configs block (configs 3–5)")
     ap.add_argument("--selftest-cpu", action="store_true",
                     help="launcher/collective self-test WITHOUT a GPU: gloo + the CPU checker on a small instance; "
                          "exercises spawn, rendezvous, barrier, max-over-ranks and the gather — not a measurement")
@@ -62,20 +66,31 @@ def launch_children(args) -> int:
            "--warmup", str(args.warmup)]
     if args.no_cpu_baseline:
         cmd.append("--no-cpu-baseline")
+    if args.no_other_configs:
+        cmd.append("--no-other-configs")
     if args.selftest_cpu:
         cmd.append("--selftest-cpu")
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: what RCCL needs on this driver
     env.setdefault("OMP_NUM_THREADS", "1")
-    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
-    line = None
-    for out in proc.stdout:                 # relay rank 0's JSON line (the only thing ranks write to stdout)
-        out = out.rstrip("\n")
-        if out.startswith("{") and '"metric"' in out:
-            line = out
-        elif out:
-            print(out, file=sys.stderr, flush=True)
-    rc = proc.wait()
+    line, rc = None, 1
+    for attempt in range(3):
+        # free_port() closes its socket before torchrun binds the port: if somebody else took it meanwhile the ranks die
+        # at the rendezvous within seconds — a fresh port and another try (a run that got past the rendezvous is not retried)
+        cmd[cmd.index("--master-port") + 1] = str(free_port())
+        t_start = time.time()
+        proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+        line = None
+        for out in proc.stdout:                 # relay rank 0's JSON line (the only thing ranks write to stdout)
+            out = out.rstrip("\n")
+            if out.startswith("{") and '"metric"' in out:
+                line = out
+            elif out:
+                print(out, file=sys.stderr, flush=True)
+        rc = proc.wait()
+        if rc == 0 or time.time() - t_start > 30:
+            break
+        print(f"bench.py: the {args.gpus}-rank launch failed early (code {rc}); retrying on another port", file=sys.stderr)
     if rc != 0:
         print(f"bench.py: the {args.gpus}-rank run exited with code {rc}", file=sys.stderr)
         return rc
@@ -142,6 +157,13 @@ def first_iterations(sj, abi, data, r, n_iters):
     return var, [st[0], st[1], st[2], var.obj]
 
 
+def parity_ok(parity, gpu_first, cpu_first, tol=1e-8) -> bool:
+    """ℒ, ‖grad‖, objective and ‖primal_vio‖ within `tol` relative — ‖primal_vio‖ absolutely (tol · max(1, ‖b‖-scale)) when
+    it is itself at round-off level, where a relative error means nothing."""
+    pv_ok = parity["rel_pv"] < tol or abs(gpu_first[2] - cpu_first[2]) < tol
+    return bool(max(parity["rel_L"], parity["rel_grad"], parity["rel_obj"]) < tol and pv_ok)
+
+
 def effective_cpus() -> int:
     """CPUs this process may really use: the affinity mask capped by the cgroup CPU quota (a GPU box hands a
     16-CPU share of a much larger host to one GPU; sizing an OpenMP team to the host would oversubscribe it)."""
@@ -202,7 +224,7 @@ def cpu_baseline(sj, data, r, gpu_first, repeats=5, sample_s=2.5):
     parity = {"iters": PARITY_ITERS, "rel_L": relerr(gpu_first[0], first[0]), "rel_grad": relerr(gpu_first[1], first[1]),
               "rel_pv": relerr(gpu_first[2], first[2]), "rel_obj": relerr(gpu_first[3], first[3]),
               "tolerance": 1e-8, "against": "oracle (CPU restatement), same R0/λ0/σ0, fg! + 5 inner iterations"}
-    parity["ok"] = bool(max(parity["rel_L"], parity["rel_grad"], parity["rel_obj"]) < 1e-8)
+    parity["ok"] = parity_ok(parity, gpu_first, first)
     sample = (f"same MaxCut G(1e5,2e-4) r={r} instance; median of {repeats} samples of {it_one} inner iterations "
               f"after fg! + {PARITY_ITERS} + 2 iterations")
     base = {"value": v_one, "unit": "iterations/s", "cores": 1, "kind": "port", "sample": sample, "build": how,
@@ -310,7 +332,7 @@ def main():
     launches, dom_ms = prof_all.get(dominant, (0, 0.0))
     stats = var.stats() if hasattr(var, "stats") else {}
 
-    dt_max, objs = reduce_over_ranks(dist, dt, obj, None if (dist is None or selftest) else "cuda")
+    dt_max, objs, dts = reduce_over_ranks(dist, dt, obj, None if (dist is None or selftest) else "cuda")
 
     rc = 0
     if rank == 0:
@@ -346,6 +368,8 @@ def main():
                                    "unit": "GB/s", "frac": b_iter * (K / dt_max) / 1e9 / HBM_PEAK_GBPS},
             "kernels_eager_profile": kern,
             "objectives": objs,
+            "per_rank": {"seconds": dts, "iterations_per_s": [K / t for t in dts],
+                         "slowest_over_fastest": max(dts) / min(dts)},
             "library_stats": stats,
         }
         if selftest:
@@ -357,29 +381,178 @@ def main():
             if not line["parity"]["ok"]:
                 print(f"bench.py: PARITY FAILED against the oracle: {line['parity']}", file=sys.stderr)
                 rc = 3
+            if not args.no_other_configs:
+                var.close()
+                var = None
+                line["other_configs"] = other_configs(sj, abi)
+                bad = [k for k, v in line["other_configs"].items() if isinstance(v, dict) and "parity" in v and not v["parity"]["ok"]]
+                if bad:
+                    print(f"bench.py: PARITY FAILED against the oracle in {bad}", file=sys.stderr)
+                    rc = 3
+        elif world > 1 and not selftest and not args.no_cpu_baseline:
+            # rank 0 still compares its first iterations with the oracle (one thread, ≈ 10 s): cheap, and a wrong result on
+            # a multi-GPU node should not pass for a fast one
+            from oracle import oracle
+            ovar, cpu_first = first_iterations(sj, oracle.abi(), data, rank_r, PARITY_ITERS)
+            ovar.close()
+            relerr = lambda a, b: abs(a - b) / max(abs(b), 1e-300)
+            par = {"iters": PARITY_ITERS, "rel_L": relerr(gpu_first[0], cpu_first[0]), "rel_grad": relerr(gpu_first[1], cpu_first[1]),
+                   "rel_pv": relerr(gpu_first[2], cpu_first[2]), "rel_obj": relerr(gpu_first[3], cpu_first[3]), "tolerance": 1e-8,
+                   "against": "oracle (CPU restatement) on rank 0's instance, fg! + 5 inner iterations"}
+            par["ok"] = parity_ok(par, gpu_first, cpu_first)
+            line["parity"] = par
+            if not par["ok"]:
+                print(f"bench.py: PARITY FAILED against the oracle: {par}", file=sys.stderr)
+                rc = 3
         print(json.dumps(line), flush=True)
-    var.close()
+    if var is not None:
+        var.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
     return rc
 
 
+def measure_config(sj, abi, data, r, seed, K=200, W=20, P=40, parity_iters=PARITY_ITERS, with_oracle=True):
+    """One BASELINE configuration that is not the headline: inner iterations/s at fixed σ (same protocol as the headline:
+    fg!, pre-warm, W untimed + K timed iterations on the route the library picks), the dominant kernel's roofline entry
+    (hipEvent pairs in an eager replay) and the state after fg! + `parity_iters` iterations against the one-thread oracle."""
+    import numpy as np
+    normC, normb = data.normC(), float(np.linalg.norm(data.b))
+    arm = data.has_inequalities
+    cfg = lambda: sj.BurerMonteiroConfig(seed=seed, printlevel=0)
+    var = sj.build_solver(abi, data, r, cfg())
+    run = lambda v, st, k: v.inner_loop(normC, normb, True, True, arm, 0.0, -1e300, k, 0.0, *st)[:3]
+    st = run(var, var.fg(normC, normb), parity_iters)
+    first = [st[0], st[1], st[2], var.obj]
+    t0 = time.perf_counter()
+    st = var.fg(normC, normb)
+    while time.perf_counter() - t0 < 0.3:
+        st = var.fg(normC, normb)
+    st = run(var, st, W)
+    abi.device_synchronize()
+    t0 = time.perf_counter()
+    st = run(var, st, K)
+    abi.device_synchronize()
+    dt = time.perf_counter() - t0
+    dims, h = var.dims(), var.h
+    per_kernel, _ = algorithmic_bytes(dims, h)
+    N = 8 * dims["n"] * dims["r"]
+    # the SpMM that produces G with lbfgs_update! riding on it (generic / edge paths): R rows, G_old, D in; G, s_j, y_j out
+    per_kernel["spmm_upd"] = 6 * N + 4 * (dims["n"] + 1) + 12 * dims["nnzS"]
+    var.profile_enable(True)
+    st = run(var, st, P)
+    prof = var.profile()
+    var.profile_enable(False)
+    fused_step = prof.get("fast_step", (0, 0.0))[0] and not prof.get("lbfgs_update", (0, 0.0))[0]
+    fused_spmm = prof.get("spmm", (0, 0.0))[0] and not prof.get("lbfgs_update", (0, 0.0))[0] and not prof.get("fast_step", (0, 0.0))[0]
+    if fused_step:
+        per_kernel["fast_step"] = per_kernel["fast_step_upd"]
+        per_kernel["lbfgs_dir"] = per_kernel["lbfgs_dir_noynext"]
+    if fused_spmm:
+        per_kernel["spmm"] = per_kernel["spmm_upd"]
+        per_kernel["lbfgs_dir"] = per_kernel["lbfgs_dir_noynext"]
+    cand = [k for k in per_kernel if k in prof and prof[k][0]]
+    out = {"n": dims["n"], "m": dims["m"], "r": dims["r"], "nnzT": dims["nnzT"], "nnzS": dims["nnzS"],
+           "inner_iterations_per_s": K / dt, "us_per_iteration": 1e6 * dt / K, "steps": K, "warmup": W,
+           "kernels_eager_profile": {k: {"launches_per_step": round(c / P, 3), "us_per_step": round(1e3 * ms / P, 2)}
+                                     for k, (c, ms) in sorted(prof.items(), key=lambda kv: -kv[1][1])}}
+    if cand:
+        dom = max(cand, key=lambda k: prof[k][1])
+        cnt, ms = prof[dom]
+        avg_s = ms / cnt / 1e3
+        ach = per_kernel[dom] / avg_s / 1e9
+        out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                           "frac": ach / HBM_PEAK_GBPS, "traffic": load_traffic(dom + "@" + str(dims["n"])),
+                           "algorithmic_bytes_per_launch": per_kernel[dom], "avg_launch_us": 1e6 * avg_s, "launches_timed": cnt}
+    if with_oracle:
+        from oracle import oracle
+        o = sj.build_solver(oracle.abi(), data, r, cfg())
+        so = run(o, o.fg(normC, normb), parity_iters)
+        cpu_first = [so[0], so[1], so[2], o.obj]
+        o.close()
+        relerr = lambda a, b: abs(a - b) / max(abs(b), 1e-300)
+        par = {"iters": parity_iters, "rel_L": relerr(first[0], cpu_first[0]), "rel_grad": relerr(first[1], cpu_first[1]),
+               "rel_pv": relerr(first[2], cpu_first[2]), "rel_obj": relerr(first[3], cpu_first[3]), "tolerance": 1e-8}
+        par["ok"] = parity_ok(par, first, cpu_first)
+        out["parity"] = par
+    return var, out
+
+
+def other_configs(sj, abi):
+    """BASELINE.json configs[2..4] on this GPU, after the headline's timed region: the reference's runner records the
+    same timers for every problem (exps/test.jl:109-162).  Lovász-θ (the Chung–Lu stand-in of SURVEY §8d), MinBisection
+    n = 1e5 with its Lanczos run (q = 232), and the batch of 64 MaxCut instances of exps/batch_test.txt on one GPU."""
+    import numpy as np
+    from sdplrplus_jl_amd import batch, problems
+    out = {}
+    t_all = time.perf_counter()
+    # ---- config 3: Lovász-θ stand-in ----
+    data = problems.lovasz_theta_data(problems.chung_lu_graph(50_000, 10.0, 2.5, 3))
+    var, res = measure_config(sj, abi, data, 32, 1)
+    res["workload"] = "Lovász-θ SDP on a Chung–Lu power-law graph n≈5e4, |E|≈2.5e5 (SNAP stand-in), r=32: one constraint per edge + trace"
+    out["config3_lovasz_theta"] = res
+    var.close()
+    # ---- config 4: MinBisection + Lanczos ----
+    data = problems.minimum_bisection_data(problems.gnp_graph(100_000, 2e-4, 4))
+    var, res = measure_config(sj, abi, data, 32, 2)
+    res["workload"] = "Minimum-bisection SDP, G(n=1e5, p=2e-4), r=32: diagonal constraints + the rank-one 1ᵀX1 = 0"
+    v0 = np.random.Generator(np.random.PCG64(5)).standard_normal(data.n)
+    var.dual_obj(float(data.n), 0, v0)                   # S(y) of the current state; captures the Lanczos graph
+    q, reps = 232, 5
+    abi.device_synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        al, be, k = var.lanczos(q, v0)
+    abi.device_synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    d = var.dims()
+    lz_bytes = 12 * d["nnzS"] + 4 * (d["n"] + 1) + 8 * 8 * d["n"]       # SURVEY §8d: S once + ≈ 8 n-vector touches per step
+    res["lanczos"] = {"steps": int(k), "steps_per_s": k / dt, "us_per_step": 1e6 * dt / k, "ms_per_run": 1e3 * dt,
+                      "roofline": {"bound": "hbm", "kernel": "lanczos step (SpMV + recurrence)", "achieved": lz_bytes * (k / dt) / 1e9,
+                                   "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": lz_bytes * (k / dt) / 1e9 / HBM_PEAK_GBPS,
+                                   "algorithmic_bytes_per_step": lz_bytes, "traffic": load_traffic("lanczos_step@100000")},
+                      "ritz_value": float(var.tridiag_mineig(al, be))}
+    out["config4_minimum_bisection"] = res
+    var.close()
+    # ---- config 5: the batch of 64 MaxCut instances (Gset G1–G9 + 55 G(800, 0.06)), rank 10, ptol = objtol = 1e-2 ----
+    z = np.load(os.path.join(ROOT, "tests", "golden", "gset_G1_G9.npz"))
+    graphs = [problems.graph_from_edges(int(z[f"G{k}_n"]), z[f"G{k}"]) for k in range(1, 10)]
+    graphs += [problems.gnp_graph(800, 0.06, seed) for seed in range(10, 65)]
+    conc = 16
+    abi.warmup(conc)
+    datas = [problems.maxcut_data(g) for g in graphs]     # the problem is the solver's input (exps/test.jl:166-176)
+    kw = dict(ptol=1e-2, objtol=1e-2, seed=0, prior_trace_bound=800.0)
+    batch.solve_local(datas[:2], 0, 1, 10, concurrency=2, **kw)          # device code + pools warm
+    abi.device_synchronize()
+    t0 = time.perf_counter()
+    rows = batch.solve_local(datas, 0, 1, 10, concurrency=conc, **kw)
+    wall = time.perf_counter() - t0
+    gap = (rows[:, 1] - rows[:, 2]) / np.minimum(np.abs(rows[:, 1]), np.abs(rows[:, 2]))
+    out["config5_batch64"] = {"workload": "64 MaxCut instances n=800 (Gset G1–G9 + 55 G(800,0.06)), rank 10, ptol=objtol=1e-2, one GPU",
+                              "instances": 64, "in_flight": conc, "wall_s": wall, "instances_per_s": 64 / wall,
+                              "inner_iterations_total": int(rows[:, 3].sum()), "max_abs_relative_gap": float(np.max(np.abs(gap))),
+                              "route": "resident (one launch per major iteration and per dual bound)",
+                              "all_converged": bool(np.all(np.abs(gap) <= 1e-2))}
+    out["seconds_spent"] = time.perf_counter() - t_all
+    return out
+
+
 def reduce_over_ranks(dist, dt, obj, device):
-    """max-over-ranks of the timed region and the per-rank objectives — the only collectives of the
+    """max-over-ranks of the timed region, the per-rank objectives and per-rank seconds — the only collectives of the
     workload (RCCL over xGMI on the GPU node; gloo in tests/test_batch_gloo.py)."""
     if dist is None or not dist.is_initialized() or (
             dist.get_world_size() == 1 and not os.environ.get("SDPLR_BENCH_FORCE_DIST")
             and not os.environ.get("SDPLR_BENCH_FORCE_LAUNCH")):
-        return dt, [obj]
+        return dt, [obj], [dt]
     import torch
     world = dist.get_world_size()
     t = torch.tensor([dt], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    o = torch.tensor([obj], dtype=torch.float64, device=device)
+    o = torch.tensor([obj, dt], dtype=torch.float64, device=device)      # (objective, this rank's own seconds: stragglers show)
     gathered = [torch.zeros_like(o) for _ in range(world)]
     dist.all_gather(gathered, o)
-    return float(t.item()), [float(x.item()) for x in gathered]
+    return float(t.item()), [float(x[0].item()) for x in gathered], [float(x[1].item()) for x in gathered]
 
 
 def load_traffic(kernel):

@@ -63,14 +63,15 @@ def _bench_worker(rank, world, port, q):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import bench
-    dt_max, objs = bench.reduce_over_ranks(dist, 0.25 * (rank + 1), -100.0 - rank, None)
-    q.put((rank, dt_max, objs))
+    dt_max, objs, dts = bench.reduce_over_ranks(dist, 0.25 * (rank + 1), -100.0 - rank, None)
+    q.put((rank, dt_max, objs, dts))
     dist.barrier()
     dist.destroy_process_group()
 
 
 def test_bench_rank_reduction_gloo():
-    """bench.py's N > 1 reduction: MAX of the timed region over ranks + all_gather of the objectives."""
+    """bench.py's N > 1 reduction: MAX of the timed region over ranks + all_gather of the objectives and of every
+    rank's own seconds (a straggler is visible in the line, not only in the maximum)."""
     import torch.multiprocessing as mp
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn")
@@ -82,5 +83,5 @@ def test_bench_rank_reduction_gloo():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    for rank, dt_max, objs in got:
-        assert dt_max == 0.5 and objs == [-100.0, -101.0]
+    for rank, dt_max, objs, dts in got:
+        assert dt_max == 0.5 and objs == [-100.0, -101.0] and dts == [0.25, 0.5]
