@@ -467,8 +467,13 @@ k_lbfgs_dir(const DevCtrl* __restrict__ c, FactorArena A, long long N, int h, in
     double2 yv[HM], sv[HM];
 #pragma unroll
     for (int k = 0; k < HM; k++) {
+#ifdef SDPLR_DIR_HIST_PLAIN   /* experiment: let the history allocate in the Infinity Cache for the step kernel's re-read */
+      yv[k] = reinterpret_cast<const double2*>(yp[k])[i];
+      sv[k] = reinterpret_cast<const double2*>(sp_[k])[i];
+#else
       yv[k] = ldnt2(yp[k], i);
       sv[k] = ldnt2(sp_[k], i);
+#endif
     }
     double2 r = g;
 #pragma unroll

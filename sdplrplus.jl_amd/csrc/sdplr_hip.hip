@@ -15,9 +15,11 @@
 #include <cstring>
 #include <limits>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <shared_mutex>
 #include <string>
+#include <thread>
 #include <unordered_map>
 #include <utility>
 #include <vector>
@@ -61,6 +63,20 @@ struct ProfEntry {
 
 }  // namespace
 
+struct BandHost {   // the band plan between its host half and its upload
+  bool ok = false, pal = false;
+  int NB = 0, NC = 0, BW = 0, CH = 0;
+  size_t n_groups = 0;
+  std::vector<int> fcp, frv;            // the full pattern (moved out of the solver's staging)
+  std::vector<int> blk_slot, slot_g, diagpos;
+  std::vector<uint4> cw;
+  std::vector<int4> pos;
+  std::vector<double> palv;
+  // the test knobs, read by the thread that calls finalize (the plan itself may be built on another one, later)
+  int env_min_n = 0, env_bw = 0, env_ch = 0, env_nc = 0;
+  bool env_no_band = false, env_no_pal = false;
+};
+
 struct sdplr_hip_solver {
   int64_t n = 0, m = 0, r = 0, h = 0;
   bool finalized = false;
@@ -102,6 +118,8 @@ struct sdplr_hip_solver {
   bool edge_lr_fused = false;
   DevBand band{};            // full pattern as LDS-band slices for the Lanczos SpMV (k_lz_band)
   bool use_band = false;
+  std::unique_ptr<BandHost> band_host;   // the plan being built on a host thread (finalize → first Lanczos run)
+  std::thread band_thread;
   int nb_tile = 0, nb_step = 1, tile_blocks = 512;
   bool use_tile = false;
   bool tile_attr_done = false;
@@ -214,6 +232,28 @@ int have_device() {
   int c = 0;
   if (hipGetDeviceCount(&c) != hipSuccess) return 0;
   return c;
+}
+
+// Host-side set-up loops over independent items (tiles, band blocks, columns) on a few host threads: the set-up of a
+// north-star-size instance was ≈ 150 ms of single-threaded sorting and packing (SDPLR_HIP_HOST_THREADS, default ≤ 8).
+int host_threads() {
+  static const int n = [] {
+    int k = (int)std::thread::hardware_concurrency();
+    if (const char* e = getenv("SDPLR_HIP_HOST_THREADS")) k = atoi(e);
+    return std::max(1, std::min(k, 8));
+  }();
+  return n;
+}
+template <typename F>
+void parallel_for(int64_t n_items, int64_t min_per_thread, F&& body) {   // body(begin, end)
+  const int64_t nt = std::max<int64_t>(1, std::min<int64_t>(host_threads(), n_items / std::max<int64_t>(min_per_thread, 1)));
+  if (nt <= 1) { body((int64_t)0, n_items); return; }
+  std::vector<std::thread> th;
+  for (int64_t t = 0; t < nt; t++) {
+    const int64_t b = n_items * t / nt, e = n_items * (t + 1) / nt;
+    th.emplace_back([&body, b, e] { body(b, e); });
+  }
+  for (auto& x : th) x.join();
 }
 
 // ---- device-memory pool ---------------------------------------------------------------------------------------
@@ -674,28 +714,33 @@ int build_tiles(S* s) {
   int K = 1;
   for (int64_t t = 0; t < nt; t++) K = std::max(K, t_row[t + 1] - t_row[t]);
   std::vector<double> t_val;
-  t_ent.reserve(g_col.size() + (size_t)nt * L / 2 + 128);
-  t_val.reserve(g_col.size() + (size_t)nt * L / 2 + 128);
-  std::vector<unsigned long long> tmp;  // column << 32 | position in the tile's slice of the CSR
-  std::vector<int> rowof;
-  for (int64_t t = 0; t < nt; t++) {
-    const int64_t r0 = t_row[t], r1 = t_row[t + 1];
-    const int b = g_ptr[r0], e = g_ptr[r1];
-    tmp.resize(e - b);
-    for (int q = b; q < e; q++) tmp[q - b] = ((unsigned long long)(unsigned)g_col[q] << 32) | (unsigned)(q - b);
-    std::sort(tmp.begin(), tmp.end());  // by column, then by CSR position (= by row)
-    int64_t row = r0;
-    rowof.assign(e - b, 0);
-    for (int q = b; q < e; q++) { while (q >= g_ptr[row + 1]) row++; rowof[q - b] = (int)(row - r0); }
-    for (int q = 0; q < e - b; q++) {
-      const int col = (int)(tmp[q] >> 32), at = (int)(tmp[q] & 0xFFFFFFFFull);
-      t_ent.push_back((rowof[at] << SDPLR_TILE_COLBITS) | col);
-      t_val.push_back(g_val[b + at]);
-    }
-    while (t_ent.size() % L) { t_ent.push_back((K << SDPLR_TILE_COLBITS) | (int)r0); t_val.push_back(0.0); }
-    t_ptr[t + 1] = (int)t_ent.size();
+  for (int64_t t = 0; t < nt; t++) {   // list lengths, padded to the sub-wave width
+    const int len = g_ptr[t_row[t + 1]] - g_ptr[t_row[t]];
+    t_ptr[t + 1] = t_ptr[t] + (len + L - 1) / L * L;
   }
-  for (int q = 0; q < 128; q++) { t_ent.push_back(0); t_val.push_back(0.0); }
+  t_ent.assign((size_t)t_ptr[nt] + 128, 0);
+  t_val.assign((size_t)t_ptr[nt] + 128, 0.0);
+  parallel_for(nt, 64, [&](int64_t t0, int64_t t1) {   // the tiles are independent: sorted and packed on a few host threads
+    std::vector<unsigned long long> tmp;  // column << 32 | position in the tile's slice of the CSR
+    std::vector<int> rowof;
+    for (int64_t t = t0; t < t1; t++) {
+      const int64_t r0 = t_row[t], r1 = t_row[t + 1];
+      const int b = g_ptr[r0], e = g_ptr[r1];
+      tmp.resize(e - b);
+      for (int q = b; q < e; q++) tmp[q - b] = ((unsigned long long)(unsigned)g_col[q] << 32) | (unsigned)(q - b);
+      std::sort(tmp.begin(), tmp.end());  // by column, then by CSR position (= by row)
+      int64_t row = r0;
+      rowof.assign(e - b, 0);
+      for (int q = b; q < e; q++) { while (q >= g_ptr[row + 1]) row++; rowof[q - b] = (int)(row - r0); }
+      size_t at0 = (size_t)t_ptr[t];
+      for (int q = 0; q < e - b; q++) {
+        const int col = (int)(tmp[q] >> 32), at = (int)(tmp[q] & 0xFFFFFFFFull);
+        t_ent[at0] = (rowof[at] << SDPLR_TILE_COLBITS) | col;
+        t_val[at0++] = g_val[b + at];
+      }
+      for (; at0 < (size_t)t_ptr[t + 1]; at0++) { t_ent[at0] = (K << SDPLR_TILE_COLBITS) | (int)r0; t_val[at0] = 0.0; }
+    }
+  });
   int rc;
   const size_t first = s->allocs.size();
   if ((rc = upload(s, &s->tile.row0, t_row))) return rc;
@@ -715,38 +760,43 @@ int build_tiles(S* s) {
 // symmetric S: column j lists row j's neighbours).  NB bands of BW ≤ 16 384 columns (x band in LDS: ≤ 128 KB),
 // NC row chunks of CH ≤ 4096 rows (partial t of the chunk in LDS: ≤ 32 KB), one 1024-thread block per (band,
 // chunk), about one block per CU.  Hub rows are left to k_spmv_long.
-int build_band(S* s) {
-  s->use_band = false;
+// host half (no HIP calls): may run on a thread of its own while the first inner loops occupy the device
+void band_host(S* s, BandHost& H) {
+  H.ok = false;
+  std::vector<int>& h_fcp = H.fcp;
+  std::vector<int>& h_frv = H.frv;
   const int64_t n = s->n;
   // (SDPLR_HIP_LZBAND_MIN_N / _BW / _CH: test knobs — small instances with several narrow bands and chunks)
   int64_t min_n = 1 << 14;
-  if (const char* e = getenv("SDPLR_HIP_LZBAND_MIN_N")) min_n = std::max(1, atoi(e));
-  if (!s->have_sparse || s->nnzS == 0 || n < min_n || getenv("SDPLR_HIP_NO_LZBAND") != nullptr) return SDPLR_OK;
+  if (H.env_min_n > 0) min_n = H.env_min_n;
+  if (!s->have_sparse || s->nnzS == 0 || n < min_n || H.env_no_band) return;
   int BWMAX = 16384, CHMAX = 4096;
-  if (const char* e = getenv("SDPLR_HIP_LZBAND_BW")) BWMAX = std::max(64, std::min(atoi(e), 16384)) / 64 * 64;
-  if (const char* e = getenv("SDPLR_HIP_LZBAND_CH")) CHMAX = std::max(1, std::min(atoi(e), 4096));
+  if (H.env_bw > 0) BWMAX = std::max(64, std::min(H.env_bw, 16384)) / 64 * 64;
+  if (H.env_ch > 0) CHMAX = std::max(1, std::min(H.env_ch, 4096));
   const int NB = (int)((n + BWMAX - 1) / BWMAX);
-  if (NB > 16) return SDPLR_OK;
+  if (NB > 16) return;
   const int BW = (int)(((n + NB - 1) / NB + 63) / 64 * 64);
   // one resident round of blocks (256 CUs, one 1024-thread block each): the sweeping blocks, the hub-row blocks, the closer
   const int hub_blocks = s->sp.n_long_rows > 0 ? std::min((s->sp.n_long_rows + 3) / 4, 64) : 0;
   int NC = std::max<int>((int)((n + CHMAX - 1) / CHMAX), std::max(1, (256 - hub_blocks - (hub_blocks > 0 ? 1 : 0)) / NB));
-  if (const char* e = getenv("SDPLR_HIP_LZBAND_NC")) NC = std::max(NC, atoi(e));
+  if (H.env_nc > 0) NC = std::max(NC, H.env_nc);
   // the kernel's static LDS (wave sums, the palette) comes out of the same 160 KB as the x band and the chunk's partial t:
   // more chunks (a shorter t) where a full band and a full chunk would not fit together (n = 2¹⁷, 2¹⁸ and just below)
   constexpr int64_t LZB_LDS_BUDGET = 160 * 1024 - (16 + 256) * 8 - 256;
   while (((int64_t)BW + (n + NC - 1) / NC) * 8 > LZB_LDS_BUDGET && (int64_t)NB * (NC + 1) <= 1024) NC++;
-  if ((int64_t)NB * NC > 1024 || ((int64_t)BW + (n + NC - 1) / NC) * 8 > LZB_LDS_BUDGET) return SDPLR_OK;
+  if ((int64_t)NB * NC > 1024 || ((int64_t)BW + (n + NC - 1) / NC) * 8 > LZB_LDS_BUDGET) return;
   const int CH = (int)((n + NC - 1) / NC);
   const int thresh = s->sp.long_thresh;
-  auto is_hub = [&](int64_t j) { return s->sp.n_long_rows > 0 && s->h_fcp[j + 1] - s->h_fcp[j] > thresh; };
+  auto is_hub = [&](int64_t j) { return s->sp.n_long_rows > 0 && h_fcp[j + 1] - h_fcp[j] > thresh; };
   // PALETTE form (k_sparse.h, DevBand): on the structured path every off-diagonal entry of S is y_g·A_g[i,j]; with
   // ≤ 255 distinct off-diagonal values in A_g an entry shrinks from 12 bytes (2-byte column, 8-byte value + padding
   // share) to 3, and the per-run refill of the values disappears.  The plan is then built on the pattern WITHOUT its
   // diagonal (ocp/orv, codes oc); the diagonal rides band 0's partial from `sdiag`.
-  bool pal = s->fast && !s->h_gptr.empty() && getenv("SDPLR_HIP_NO_LZPAL") == nullptr;
-  std::vector<double> palv(1, 0.0);
-  std::vector<int> ocp, orv, diagpos;
+  bool pal = s->fast && !s->h_gptr.empty() && !H.env_no_pal;
+  std::vector<double>& palv = H.palv;
+  palv.assign(1, 0.0);
+  std::vector<int> ocp, orv;
+  std::vector<int>& diagpos = H.diagpos;
   std::vector<unsigned char> oc;
   if (pal) {   // distinct off-diagonal values of A_g, ascending; more than 255 ⇒ the value-array form
     std::vector<double> all;
@@ -764,12 +814,12 @@ int build_band(S* s) {
   if (pal) {
     ocp.assign(n + 1, 0);
     diagpos.assign(n, -1);
-    orv.reserve(s->h_frv.size());
-    oc.reserve(s->h_frv.size());
+    orv.reserve(h_frv.size());
+    oc.reserve(h_frv.size());
     for (int64_t j = 0; j < n && pal; j++) {
       int q = s->h_gptr[j];   // A_g's row j and the full pattern's row j are both sorted by column
-      for (int p = s->h_fcp[j]; p < s->h_fcp[j + 1]; p++) {
-        const int col = s->h_frv[p];
+      for (int p = h_fcp[j]; p < h_fcp[j + 1]; p++) {
+        const int col = h_frv[p];
         if (col == (int)j) {
           if (!is_hub(j)) diagpos[j] = p;
           continue;
@@ -783,16 +833,18 @@ int build_band(S* s) {
       ocp[j + 1] = (int)orv.size();
     }
   }
-  const std::vector<int>&cp = pal ? ocp : s->h_fcp, &rv = pal ? orv : s->h_frv;
+  const std::vector<int>&cp = pal ? ocp : h_fcp, &rv = pal ? orv : h_frv;
   // entries of row j that fall into band b, in ascending column order: counted, then filled
   std::vector<int> cnt((size_t)NB * n, 0);
   for (int64_t j = 0; j < n; j++) {
     if (is_hub(j)) continue;
     for (int p = cp[j]; p < cp[j + 1]; p++) cnt[(size_t)(rv[p] / BW) * n + j]++;
   }
-  std::vector<int> blk_slot(1, 0), slot_g(1, 0);
-  std::vector<uint4> cw;
-  std::vector<int4> pos;
+  std::vector<int>&blk_slot = H.blk_slot, &slot_g = H.slot_g;
+  blk_slot.assign(1, 0);
+  slot_g.assign(1, 0);
+  std::vector<uint4>& cw = H.cw;
+  std::vector<int4>& pos = H.pos;
   std::vector<int> rows;
   auto push_group = [&](const int* first, const int* rowsp, int nl, int k0, int64_t r0, int b) {
     for (int l = 0; l < 64; l++) {
@@ -848,8 +900,29 @@ int build_band(S* s) {
     }
   }
   const size_t n_groups = cw.size() / 64;
-  if ((n_groups + 1) * 64 >= (size_t)1 << 31) return SDPLR_OK;
+  if ((n_groups + 1) * 64 >= (size_t)1 << 31) return;
   push_group(nullptr, nullptr, 0, 0, 0, 0);   // the all-padding dummy group
+  H.NB = NB; H.NC = NC; H.BW = BW; H.CH = CH; H.n_groups = n_groups; H.pal = pal;
+  H.ok = true;
+}
+
+// device half: uploads + the LDS attribute; joins the host half first.  Called by whoever is about to use the plan.
+int ensure_band(S* s) {
+  if (!s->band_host) return SDPLR_OK;
+  if (s->band_thread.joinable()) s->band_thread.join();
+  std::unique_ptr<BandHost> Hp = std::move(s->band_host);
+  BandHost& H = *Hp;
+  s->use_band = false;
+  if (!H.ok) return SDPLR_OK;
+  const int64_t n = s->n;
+  const int NB = H.NB, NC = H.NC, BW = H.BW, CH = H.CH;
+  const bool pal = H.pal;
+  std::vector<int>&blk_slot = H.blk_slot, &slot_g = H.slot_g, &diagpos = H.diagpos;
+  std::vector<uint4>& cw = H.cw;
+  std::vector<int4>& pos = H.pos;
+  std::vector<double>& palv = H.palv;
+  const size_t n_groups = H.n_groups;
+  constexpr int64_t LZB_LDS_BUDGET = 160 * 1024 - (16 + 256) * 8 - 256;
   DevBand& bd = s->band;
   bd = DevBand{};
   bd.NB = NB; bd.NC = NC; bd.BW = BW; bd.CH = CH; bd.n_slots = (int)slot_g.size() - 1; bd.n_groups = (int)n_groups;
@@ -1623,8 +1696,28 @@ int32_t sdplr_hip_finalize(S* s) {
     }
   }
   lap("classification / edge plan");
-  if ((rc = build_band(s))) return rc;   // (after the classification: the palette form needs to know A_g)
-  lap("band plan");
+  // The band plan of the Lanczos SpMV (after the classification: the palette form needs to know A_g) is ≈ 60 ms of host
+  // work at the north-star size and is not needed before the first dual bound: built on a thread of its own while the
+  // first inner loops run, uploaded by the first Lanczos run (ensure_band).  SDPLR_HIP_BAND_SYNC=1: built here.
+  s->use_band = false;
+  s->band_host.reset(new BandHost());
+  s->band_host->fcp = s->h_fcp;
+  s->band_host->frv = std::move(s->h_frv);
+  {
+    BandHost& H = *s->band_host;
+    auto envi = [](const char* k) { const char* e = getenv(k); return e ? std::max(1, atoi(e)) : 0; };
+    H.env_min_n = envi("SDPLR_HIP_LZBAND_MIN_N"); H.env_bw = envi("SDPLR_HIP_LZBAND_BW");
+    H.env_ch = envi("SDPLR_HIP_LZBAND_CH"); H.env_nc = envi("SDPLR_HIP_LZBAND_NC");
+    H.env_no_band = getenv("SDPLR_HIP_NO_LZBAND") != nullptr; H.env_no_pal = getenv("SDPLR_HIP_NO_LZPAL") != nullptr;
+  }
+  if (getenv("SDPLR_HIP_BAND_SYNC") != nullptr) {
+    band_host(s, *s->band_host);
+  } else {
+    S* sp_ = s;
+    BandHost* hp_ = s->band_host.get();
+    s->band_thread = std::thread([sp_, hp_] { band_host(sp_, *hp_); });
+  }
+  lap("band plan (started)");
   if ((rc = alloc_factors(s))) return rc;
   lap("factors");
   s->nb_m = blocks_for(m + 1, SDPLR_NT, 256);
@@ -1654,6 +1747,7 @@ int32_t sdplr_hip_finalize(S* s) {
 int32_t sdplr_hip_destroy(S* s) {
   ApiShared api_guard;
   if (!s) return SDPLR_OK;
+  if (s->band_thread.joinable()) s->band_thread.join();
   if (s->stream) (void)hipStreamSynchronize(s->stream);
   for (auto& p : s->prof_pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
   for (auto e : s->ev_pool) (void)hipEventDestroy(e);
@@ -2612,6 +2706,7 @@ int run_lanczos(S* s, int64_t q, const double* v0, double* alpha, double* beta, 
   c->lz_done = 0; c->lz_steps = 0; c->lz_beta_prev = 0.0; c->lz_gamma_cur = 1.0; c->lz_gamma_prev = 1.0; c->lz_qmax = q;
   if ((rc = push(s))) return rc;
   double *b0 = s->lz_buf[0], *b1 = s->lz_buf[1], *b2 = s->lz_buf[2];
+  if ((rc = ensure_band(s))) return rc;
   // the palette form of the band plan takes the off-diagonal values from the live y: only when S is S(y)
   s->lz_band_now = s->use_band && (!s->band.pal_mode || s->S_from_y);
   if (s->lz_band_now) {   // S is fixed for the q steps: the band layout's values are gathered once per run
