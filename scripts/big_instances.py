@@ -1,10 +1,14 @@
-import sys, time
-sys.path.insert(0, "/root/repo")
+"""Large / wide instances (not BASELINE configs): MaxCut at n up to 2e6 and ranks up to 128 — ms per inner iteration on
+the default route, with the state checked against scipy identities (asserted, not only printed).  Prints a table for
+DESIGN.md."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import sdplrplus_jl_amd as sj
 from sdplrplus_jl_amd import problems
 abi = sj.load_hip()
-for n, p, r in ((1_000_000, 2e-5, 16), (300_000, 1e-4, 64), (2_000_000, 4e-6, 8)):
+print("| n | r | nnz | ms / inner iteration | it/s | 𝒜 err | obj err | G err |\n|---|---|---|---|---|---|---|---|")
+for n, p, r in ((1_000_000, 2e-5, 16), (300_000, 1e-4, 64), (2_000_000, 4e-6, 8), (100_000, 2e-4, 64), (100_000, 2e-4, 128), (300_000, 1e-4, 128)):
     t0 = time.time()
     A = problems.gnp_graph(n, p, 11)
     data = problems.maxcut_data(A)
@@ -24,5 +28,6 @@ for n, p, r in ((1_000_000, 2e-5, 16), (300_000, 1e-4, 64), (2_000_000, 4e-6, 8)
     G = var.Gt
     Gref = 2 * (CR + var.y[:-1, None] * R)
     e3 = np.max(np.abs(G - Gref)) / np.max(np.abs(Gref))
-    print(f"n={n} r={r} nnz={A.nnz} setup {t1-t0:.1f}s  {1e3*(t3-t2)/100:.3f} ms/iter  L {st[0]:.6e} -> {out[0]:.6e}  errs {e1:.2e} {e2:.2e} {e3:.2e}", flush=True)
+    assert out[4] == 100 and out[0] < st[0] and e1 < 1e-8 and e2 < 1e-10 and e3 < 1e-10, (n, r, e1, e2, e3)
+    print(f"| {n} | {r} | {A.nnz} | {1e3*(t3-t2)/100:.3f} | {100/(t3-t2):.0f} | {e1:.1e} | {e2:.1e} | {e3:.1e} |", flush=True)
     var.close()

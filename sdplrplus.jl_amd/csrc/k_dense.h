@@ -561,55 +561,52 @@ __global__ void __launch_bounds__(SDPLR_NT) k_neg_copy(double* __restrict__ G, d
 
 // ---- history update + Gram rows of slot j ----------------------------------------------------------
 // UPDATE: src/lbfgs.jl:140-146 — dirt *= α; s_j = dirt; y_j += G, j = latest mod h (0-based).
-// Both variants accumulate, for every slot l (with the new s_j, y_j for l = j):
+// Both variants accumulate, for the slots l of ONE window of four (l0 ≤ l < l0 + 4; with the new s_j, y_j for l = j):
 //   q=0: ⟨s_j, y_l⟩   q=1: ⟨s_l, y_j⟩   q=2: ⟨y_j, y_l⟩   q=3: ⟨s_l, G⟩   q=4: ⟨y_l, G⟩
-// into partial slot SLOT_GRAM + q*SDPLR_HMAX + l.  !UPDATE recomputes row `jfixed` from the stored
-// vectors (used when the host has written history slots or G behind the library's back).
-template <int HM, bool UPDATE>
-__global__ void __launch_bounds__(SDPLR_NT, HM <= 4 ? 4 : (HM <= 8 ? 2 : 1))
-k_lbfgs_update(const DevCtrl* __restrict__ c, FactorArena A, long long N, int h, int jfixed,
+// into partial slot SLOT_GRAM + q*SDPLR_HMAX + l.  A history longer than four pairs takes one launch per window — the
+// first one makes the update (UPDATE), the others read the pair it wrote (jmode 1: j = latest mod h from the control
+// block) — instead of one kernel with 5·h running sums per lane: at h = 8 / 16 that kernel spilled 292 / 580 bytes per
+// lane to scratch.  !UPDATE with jmode 0 recomputes row `jfixed` from the stored vectors (used when the host has written
+// history slots or G behind the library's back).
+template <bool UPDATE>
+__global__ void __launch_bounds__(SDPLR_NT, 2)
+k_lbfgs_update(const DevCtrl* __restrict__ c, FactorArena A, long long N, int h, int jfixed, int jmode, int l0,
                int check_done, double* __restrict__ partials) {
-  __shared__ double sh[5 * HM * (SDPLR_NT / 64)];
+  constexpr int HW = 4;
+  __shared__ double sh[5 * HW * (SDPLR_NT / 64)];
   const int dn = check_done ? (c->done | c->reldelta_exit) : 0;  // :239-241 breaks before lbfgs_update!
-  const int j = UPDATE ? (c->latest % h) : jfixed;
+  const int j = (UPDATE || jmode) ? (c->latest % h) : jfixed;
   const double alpha = c->alpha;
   if (dn) return;  // (all four scalars were requested together)
   const double* G = aslot(A, AS_G);
   double* dir = aslot(A, AS_D);
   double* Sj = aslot(A, AS_S0 + j);
   double* Yj = aslot(A, as_y0(A) + j);
-  double acc[5 * HM];
+  double acc[5 * HW];
 #pragma unroll
-  for (int k = 0; k < 5 * HM; k++) acc[k] = 0.0;
+  for (int k = 0; k < 5 * HW; k++) acc[k] = 0.0;
   const long long N2 = N >> 1;
   const long long stride = (long long)gridDim.x * SDPLR_NT;
-  // all 2·HM + 2 loads of a trip are unconditional (slots l ≥ h alias slot 0 and are masked out of the sums):
+  // all 2·HW + 4 loads of a trip are unconditional (slots l ≥ h alias slot 0 and are masked out of the sums):
   // see k_lbfgs_dir
-  const double* slp[HM];
-  const double* ylp[HM];
+  const double* slp[HW];
+  const double* ylp[HW];
 #pragma unroll
-  for (int l = 0; l < HM; l++) {
-    const int slot = (l < h) ? l : 0;
+  for (int l = 0; l < HW; l++) {
+    const int slot = (l0 + l < h) ? l0 + l : 0;
     slp[l] = aslot(A, AS_S0 + slot);
     ylp[l] = aslot(A, as_y0(A) + slot);
   }
   for (long long i = (long long)blockIdx.x * SDPLR_NT + threadIdx.x; i < N2; i += stride) {
     const double2 g = ldnt2(G, i);
     const double2 d = ldnt2(dir, i);
-    double2 sv[HM], yv[HM];
+    double2 sn = ldnt2(Sj, i), yn = ldnt2(Yj, i);   // the stored s_j, y_j (y_j holds −G_old, written by lbfgs_dir!)
+    double2 sv[HW], yv[HW];
 #pragma unroll
-    for (int l = 0; l < HM; l++) {
+    for (int l = 0; l < HW; l++) {
       sv[l] = ldnt2(slp[l], i);
       yv[l] = ldnt2(ylp[l], i);
     }
-    double2 sn, yn;
-    sn.x = sn.y = yn.x = yn.y = 0.0;
-#pragma unroll
-    for (int l = 0; l < HM; l++)   // the stored s_j, y_j (y_j holds −G_old, written by lbfgs_dir!)
-      if (l == j) {
-        sn = sv[l];
-        yn = yv[l];
-      }
     if (UPDATE) {
       sn.x = alpha * d.x;  // BLAS.scal!(stepsize, dir)  (:142)
       sn.y = alpha * d.y;
@@ -620,15 +617,15 @@ k_lbfgs_update(const DevCtrl* __restrict__ c, FactorArena A, long long N, int h,
       reinterpret_cast<double2*>(Yj)[i] = yn;
     }
 #pragma unroll
-    for (int l = 0; l < HM; l++)
-      if (l < h) {
-        const double2 sl = (l == j) ? sn : sv[l];
-        const double2 yl = (l == j) ? yn : yv[l];
-        acc[0 * HM + l] += sn.x * yl.x + sn.y * yl.y;
-        acc[1 * HM + l] += sl.x * yn.x + sl.y * yn.y;
-        acc[2 * HM + l] += yn.x * yl.x + yn.y * yl.y;
-        acc[3 * HM + l] += sl.x * g.x + sl.y * g.y;
-        acc[4 * HM + l] += yl.x * g.x + yl.y * g.y;
+    for (int l = 0; l < HW; l++)
+      if (l0 + l < h) {
+        const double2 sl = (l0 + l == j) ? sn : sv[l];
+        const double2 yl = (l0 + l == j) ? yn : yv[l];
+        acc[0 * HW + l] += sn.x * yl.x + sn.y * yl.y;
+        acc[1 * HW + l] += sl.x * yn.x + sl.y * yn.y;
+        acc[2 * HW + l] += yn.x * yl.x + yn.y * yl.y;
+        acc[3 * HW + l] += sl.x * g.x + sl.y * g.y;
+        acc[4 * HW + l] += yl.x * g.x + yl.y * g.y;
       }
   }
   if ((N & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
@@ -646,24 +643,24 @@ k_lbfgs_update(const DevCtrl* __restrict__ c, FactorArena A, long long N, int h,
       yn = Yj[e];
     }
 #pragma unroll
-    for (int l = 0; l < HM; l++)
-      if (l < h) {
-        const double sl = (l == j) ? sn : aslot(A, AS_S0 + l)[e];
-        const double yl = (l == j) ? yn : aslot(A, as_y0(A) + l)[e];
-        acc[0 * HM + l] += sn * yl;
-        acc[1 * HM + l] += sl * yn;
-        acc[2 * HM + l] += yn * yl;
-        acc[3 * HM + l] += sl * g;
-        acc[4 * HM + l] += yl * g;
+    for (int l = 0; l < HW; l++)
+      if (l0 + l < h) {
+        const double sl = (l0 + l == j) ? sn : aslot(A, AS_S0 + l0 + l)[e];
+        const double yl = (l0 + l == j) ? yn : aslot(A, as_y0(A) + l0 + l)[e];
+        acc[0 * HW + l] += sn * yl;
+        acc[1 * HW + l] += sl * yn;
+        acc[2 * HW + l] += yn * yl;
+        acc[3 * HW + l] += sl * g;
+        acc[4 * HW + l] += yl * g;
       }
   }
-  block_sum<5 * HM>(acc, sh);
+  block_sum<5 * HW>(acc, sh);
   if (threadIdx.x == 0) {
 #pragma unroll
     for (int q = 0; q < 5; q++)
 #pragma unroll
-      for (int l = 0; l < HM; l++)
-        if (l < h) slot_partials(partials, SLOT_GRAM + q * SDPLR_HMAX + l)[blockIdx.x] = acc[q * HM + l];
+      for (int l = 0; l < HW; l++)
+        if (l0 + l < h) slot_partials(partials, SLOT_GRAM + q * SDPLR_HMAX + l0 + l)[blockIdx.x] = acc[q * HW + l];
     if (UPDATE && blockIdx.x == 0) const_cast<DevCtrl*>(c)->gram_pending = 1;  // consumed by k_lbfgs_boundary
   }
 }

@@ -1201,8 +1201,11 @@ __device__ __forceinline__ double group_bcast(double v, int src) {
   return __hiloint2double(group_bcast<LPR>(__double2hiint(v), src), group_bcast<LPR>(__double2loint(v), src));
 }
 
+// (launch bounds: the tile's LDS rows leave room for two blocks per CU — two waves per SIMD — whatever the second
+// argument says; for rows wider than a DPP row (LPR ≥ 32: the hand-offs are ds_bpermute results that stay live across the
+// unrolled chunk) the 128-VGPR cap of "4" cost 20–268 bytes of scratch per lane inside the gather loop)
 template <int LPR, int VEC, int LRN>
-__global__ void __launch_bounds__(SDPLR_NT, 4)
+__global__ void __launch_bounds__(SDPLR_NT, LPR >= 32 ? 2 : 4)
 k_spmm_tile(DevTile tl, int n, int m, DevFast ff, const double* __restrict__ R, const double* __restrict__ D,
             const double* __restrict__ P, double* __restrict__ W, int r, const double* __restrict__ lam,
             const double* __restrict__ pv_raw, double* __restrict__ A_RD, double* __restrict__ A_DD,

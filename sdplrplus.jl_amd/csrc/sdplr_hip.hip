@@ -2097,7 +2097,8 @@ void enq_boundary(S* s, int jfixed, int fin_mode, int do_loop, int do_coeff, int
 }
 void enq_gram_row(S* s, int j) {
   s->gram_nb = s->nb_upd;
-  HM_DISPATCH((k_lbfgs_update<HM, false><<<s->nb_upd, SDPLR_NT, 0, s->stream>>>(s->ctrl, s->arena, s->N, (int)s->h, j, 0, s->partials)))
+  for (int l0 = 0; l0 < (int)s->h; l0 += 4)   // one launch per window of four history slots
+    k_lbfgs_update<false><<<s->nb_upd, SDPLR_NT, 0, s->stream>>>(s->ctrl, s->arena, s->N, (int)s->h, j, 0, l0, 0, s->partials);
   enq_boundary(s, j, 2, 0, 0);
 }
 // make the Gram data consistent with the stored history and the current G (see k_dense.h)
@@ -2139,7 +2140,9 @@ void enq_lbfgs_update(S* s, int chk) {
   if (s->h == 0) return;
   s->gram_nb = s->nb_upd;
   ProfScope ps(s, "lbfgs_update");
-  HM_DISPATCH((k_lbfgs_update<HM, true><<<s->nb_upd, SDPLR_NT, 0, s->stream>>>(s->ctrl, s->arena, s->N, (int)s->h, 0, chk, s->partials)))
+  k_lbfgs_update<true><<<s->nb_upd, SDPLR_NT, 0, s->stream>>>(s->ctrl, s->arena, s->N, (int)s->h, 0, 1, 0, chk, s->partials);
+  for (int l0 = 4; l0 < (int)s->h; l0 += 4)   // longer histories: the dots of the new pair with the other windows of four slots
+    k_lbfgs_update<false><<<s->nb_upd, SDPLR_NT, 0, s->stream>>>(s->ctrl, s->arena, s->N, (int)s->h, 0, 1, l0, chk, s->partials);
 }
 
 // both line searches up to and including the commit; fuse_y also writes y of the following g!

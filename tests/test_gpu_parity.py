@@ -910,3 +910,25 @@ def test_lanczos_band_form_matches_gather_form_and_oracle(hip_abi, oracle_abi, m
         # the Ritz value of the whole (unorthogonalised) run: agreement on the scale of ‖S‖, looser where the run
         # has long lost orthogonality (the μ-conductance S has λ_max/λ_min ≈ 1e7)
         assert abs(a[5] - b[5]) <= 1e-6 * scale and abs(a[1] - b[1]) <= 1e-6 * scale and a[1] == a[5]
+
+
+@pytest.mark.parametrize("family,r,h", [("maxcut", 128, 12), ("maxcut", 64, 16), ("minimum_bisection", 96, 7), ("lovasz_theta", 128, 5)])
+def test_wide_ranks_and_long_histories(hip_abi, oracle_abi, family, r, h):
+    """Ranks beyond one DPP row (r = 64 … 128: whole-wave row groups, the tile kernel's wide instantiations — built without
+    scratch since round 3) together with histories longer than the fused kernels' four pairs (numlbfgsvecs up to the
+    library's 16: lbfgs_update! then runs as one launch per window of four slots): 2h + 3 inner iterations against the
+    oracle, through several wraps of the cyclic history (src/lbfgs.jl:77-149)."""
+    data, *_ = make_data(family, 6, 40, 0.2)
+    g, o = pair(hip_abi, oracle_abi, data, r, 17, h=h)
+    normC, normb = data.normC(), float(np.linalg.norm(data.b))
+    sg, so = g.fg(normC, normb), o.fg(normC, normb)
+    assert np.allclose(sg, so, rtol=1e-11)
+    k = 2 * h + 3
+    rg = g.inner_loop(normC, normb, True, True, False, 0.0, -1e300, k, 0.0, *sg)
+    ro = o.inner_loop(normC, normb, True, True, False, 0.0, -1e300, k, 0.0, *so)
+    assert rg[4] == ro[4] == k
+    assert np.allclose(rg[:3], ro[:3], rtol=1e-7, atol=1e-12), (rg, ro)
+    assert rel(g.Rt, o.Rt) < 1e-7
+    assert g.get_scalar(cabi.S_LBFGS_LATEST) == o.get_scalar(cabi.S_LBFGS_LATEST)
+    assert np.allclose(g.get_vec(cabi.V_LBFGS_RHO), o.get_vec(cabi.V_LBFGS_RHO), rtol=1e-5)
+    g.close(); o.close()
