@@ -51,6 +51,42 @@ mutable struct HIPAux
     n::Int
     m::Int
     host::Any
+    # HIPAux(data, r, numlbfgsvecs): preprocess_sparsecons (src/preprocess.jl:24-169) runs INSIDE the library — the sparse
+    # matrices go over as concatenated COO triplets in findnz order (sdplr_hip_set_sparse_coo), no SolverAuxiliary is built
+    function HIPAux(data, r::Integer, numlbfgsvecs::Integer)
+        h = Ref{Ptr{Cvoid}}(C_NULL)
+        n, m = Int(data.n), Int(data.m)
+        hip_check(ccall((:sdplr_hip_create, LIBSDPLR_HIP), Int32,
+                        (Int64, Int64, Int64, Int64, Ptr{Ptr{Cvoid}}), n, m, r, numlbfgsvecs, h), C_NULL)
+        hd = h[]
+        ent_ptr, I, J, V, gids = Int64[1], Int64[], Int64[], Float64[], Int64[]
+        lowrank = Tuple{Any,Int}[]
+        for (gid, A) in Iterators.flatten((enumerate(data.As), ((m + 1, data.C),)))      # src/structs.jl:303-334
+            if A isa SymLowRankMatrix
+                push!(lowrank, (A, gid))
+                continue
+            end
+            i, j, v = findnz(A isa Diagonal ? sparse(A) : A)
+            append!(I, i); append!(J, j); append!(V, v)
+            push!(ent_ptr, length(I) + 1)
+            push!(gids, gid)
+        end
+        if !isempty(gids)
+            hip_check(ccall((:sdplr_hip_set_sparse_coo, LIBSDPLR_HIP), Int32,
+                (Ptr{Cvoid}, Int64, Int64, Ptr{Int64}, Ptr{Int64}, Ptr{Int64}, Ptr{Float64}, Ptr{Int64}),
+                hd, 1, length(gids), ent_ptr, I, J, V, gids), hd)
+        end
+        for (A, gid) in lowrank
+            d = collect(Float64, diag(A.D))
+            B = Matrix{Float64}(A.B)
+            hip_check(ccall((:sdplr_hip_add_symlowrank, LIBSDPLR_HIP), Int32,
+                (Ptr{Cvoid}, Int64, Int64, Int64, Ptr{Float64}, Ptr{Float64}), hd, 1, gid, size(B, 2), B, d), hd)
+        end
+        hip_check(ccall((:sdplr_hip_finalize, LIBSDPLR_HIP), Int32, (Ptr{Cvoid},), hd), hd)
+        obj = new(hd, n, m, nothing)
+        finalizer(x -> ccall((:sdplr_hip_destroy, LIBSDPLR_HIP), Int32, (Ptr{Cvoid},), x.handle), obj)
+        return obj
+    end
     function HIPAux(data, aux, r::Integer, numlbfgsvecs::Integer)
         h = Ref{Ptr{Cvoid}}(C_NULL)
         n = size(aux.sparse_S, 1)
@@ -201,6 +237,27 @@ function inner_loop!(aux::HIPAux, normC, normb, config, use_armijo::Bool, cur_gt
     return Lr[], gr[], pr[], ar[], Int(it[]), Int(why[])
 end
 
+"""
+    major_iteration!(aux, normC, normb, config, use_armijo, update_λ, σ, cur_gtol, budget, time_left)
+
+The device work between two host decisions of `_sdplr` as ONE call: [λ update, src/sdplr.jl:358-362] → `var.σ[] = σ` →
+`lbfgs_clear!` (:384) → `fg!` (:389) → the inner `while` (:190-278) on what `fg!` returned.  On small instances the
+library runs all of it as one kernel launch.
+"""
+function major_iteration!(aux::HIPAux, normC, normb, config, use_armijo::Bool, update_λ::Bool, σ, cur_gtol,
+                          budget::Integer, time_left)
+    Lr, gr, pr, ar, it, why = Ref(0.0), Ref(0.0), Ref(0.0), Ref(0.0), Ref{Int64}(0), Ref{Int32}(0)
+    hip_check(ccall((:sdplr_hip_major_iteration, LIBSDPLR_HIP), Int32,
+                    (Ptr{Cvoid}, Float64, Float64, Int32, Int32, Int32, Int32, Float64, Float64, Float64, Int64, Float64,
+                     Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Int64}, Ptr{Int32}),
+                    aux.handle, normC, normb, config.gtol_mode == :relative, config.ptol_mode == :relative, use_armijo,
+                    update_λ, σ, cur_gtol, config.fprec * eps(), budget, time_left, Lr, gr, pr, ar, it, why), aux.handle)
+    return Lr[], gr[], pr[], ar[], Int(it[]), Int(why[])
+end
+
+"primes the library's pools (HIP streams, events, pinned staging) for `n` handles alive at once — optional, before a batch"
+hip_warmup(n::Integer) = hip_check(ccall((:sdplr_hip_warmup, LIBSDPLR_HIP), Int32, (Int32,), n), C_NULL)
+
 "approx_mineigval_lanczos(var, aux, q) — src/coreop.jl:461-514 (the start vector replaces the internal randn of :473)"
 function approx_mineigval_lanczos(var::SolverVars, aux::HIPAux, q::Integer)
     v0 = randn(side_dimension(aux))
@@ -293,12 +350,21 @@ function _sdplr(data, var::SolverVars{Ti,Tv}, aux::HIPAux, stats::SolverStats{Tv
     report(li) = printintermediate(config.dataset, majoriter, li, iter, 𝓛, obj, σ, cur_gtol, cur_ptol, gnorm, pnorm,
                                    min_gap, best_dual)
 
+    # The tail of a major iteration — λ update or σ increase (:358-369), lbfgs_clear! (:384), fg! (:389) — has no host
+    # decision in it, nor has the while loop it feeds: the four travel as ONE call (major_iteration!); `pending` holds a
+    # tail that has not been sent yet: (update_λ, σ).
+    pending = nothing
     for _ in 1:config.maxmajoriter                                         # :185
         majoriter += 1
         localiter = 0
-        if gnorm > cur_gtol                                                # the while of :190-278, device-driven
-            budget = max(config.maxiter + 1 - iter, 1)
-            time_left = max(config.maxtime - (time() - stats.starttime[]), 1e-9)
+        budget = max(config.maxiter + 1 - iter, 1)
+        time_left = max(config.maxtime - (time() - stats.starttime[]), 1e-9)
+        if pending !== nothing
+            𝓛, gnorm, pnorm, _, localiter, _ = major_iteration!(aux, normC, normb, config, use_armijo, pending[1],
+                                                                pending[2], cur_gtol, budget, time_left)
+            pending = nothing
+            iter += localiter
+        elseif gnorm > cur_gtol                                            # the while of :190-278, device-driven
             𝓛, gnorm, pnorm, _, localiter, _ = inner_loop!(aux, normC, normb, config, use_armijo, cur_gtol, budget,
                                                            time_left, 𝓛, gnorm, pnorm)
             iter += localiter
@@ -338,13 +404,21 @@ function _sdplr(data, var::SolverVars{Ti,Tv}, aux::HIPAux, stats::SolverStats{Tv
                 min_gap = min(min_gap, gap)
                 grow_rank = stall_left == 0
             end
-            hip_check(ccall((:sdplr_hip_update_lambda, LIBSDPLR_HIP), Int32, (Ptr{Cvoid},), h), h)   # :358-362
+            update_λ = true                                                # :358-362
             cur_ptol /= σ^0.9                                              # :363-364
             cur_gtol /= σ
         else
+            update_λ = false
             σ *= config.σfac                                               # :366-369
-            hip_set_scalar!(aux, HIP_S_SIGMA, σ)
             cur_ptol, cur_gtol = 1 / σ^0.1, 1 / σ
+        end
+        fuse_tail = !grow_rank && majoriter < config.maxmajoriter
+        if !fuse_tail
+            if update_λ
+                hip_check(ccall((:sdplr_hip_update_lambda, LIBSDPLR_HIP), Int32, (Ptr{Cvoid},), h), h)
+            else
+                hip_set_scalar!(aux, HIP_S_SIGMA, σ)
+            end
         end
 
         if grow_rank                                                       # :373-382
@@ -356,12 +430,16 @@ function _sdplr(data, var::SolverVars{Ti,Tv}, aux::HIPAux, stats::SolverStats{Tv
             min_gap, best_dual = 1e20, -1e20
             stall_left = config.rankupd_tol
             @info "rank doubled, newrank is $(var.r[])."
-        else
+        elseif !fuse_tail
             hip_check(ccall((:sdplr_hip_lbfgs_clear, LIBSDPLR_HIP), Int32, (Ptr{Cvoid},), h), h)     # :384
         end
         cur_ptol = max(cur_ptol, config.ptol)                              # :387-389
         cur_gtol = max(cur_gtol, config.gtol)
-        𝓛, gnorm, pnorm = fg!(data, var, aux, normC, normb, config)
+        if fuse_tail
+            pending = (update_λ, σ)                                        # sent with the next pass of the while loop
+        else
+            𝓛, gnorm, pnorm = fg!(data, var, aux, normC, normb, config)
+        end
         majoriter == config.maxmajoriter && @warn "Major iteration limit exceeded. Stop optimizing."
     end
 
