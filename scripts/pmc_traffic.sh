@@ -7,9 +7,9 @@ cd /tmp && export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof
 rm -rf $OUT; mkdir -p $OUT
 for C in FETCH_SIZE WRITE_SIZE; do
-  SDPLR_BENCH_PREWARM_S=0 rocprofv3 --kernel-trace --pmc $C -d $OUT/$C -o p --output-format csv -- python3 $GRAFT_REPO_ROOT/bench.py --steps 16 --warmup 8 --no-cpu-baseline > $OUT/$C.log 2>&1 || exit 1
+  SDPLR_BENCH_PREWARM_S=0 rocprofv3 --kernel-trace --pmc $C -d $OUT/$C -o p --output-format csv -- python3 $GRAFT_REPO_ROOT/bench.py --steps 16 --warmup 8 --no-cpu-baseline --no-other-configs > $OUT/$C.log 2>&1 || exit 1
 done
-rocprofv3 --kernel-trace --stats -d $OUT/trace -o t --output-format csv -- python3 $GRAFT_REPO_ROOT/bench.py --steps 200 --warmup 20 --no-cpu-baseline > $OUT/bench_traced.json 2> $OUT/trace.log || exit 1
+rocprofv3 --kernel-trace --stats -d $OUT/trace -o t --output-format csv -- python3 $GRAFT_REPO_ROOT/bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-other-configs > $OUT/bench_traced.json 2> $OUT/trace.log || exit 1
 python3 - "$OUT" <<'PY'
 import sys, glob, csv, collections, statistics, json, shutil
 out = sys.argv[1]
@@ -38,7 +38,7 @@ for k in sorted(set(vals["FETCH_SIZE"]) | set(vals["WRITE_SIZE"])):
         js[SCOPE[k]] = int(fetch_b + write_b)
 with open(f"{out}/pmc_traffic.csv", "w") as f:
     f.write("# HBM-side traffic per launch from rocprofv3 --pmc (separate FETCH_SIZE / WRITE_SIZE passes)\n")
-    f.write("# command: SDPLR_BENCH_PREWARM_S=0 rocprofv3 --pmc <COUNTER> --kernel-trace --output-format csv -- python3 bench.py --steps 16 --warmup 8 --no-cpu-baseline\n")
+    f.write("# command: SDPLR_BENCH_PREWARM_S=0 rocprofv3 --pmc <COUNTER> --kernel-trace --output-format csv -- python3 bench.py --steps 16 --warmup 8 --no-cpu-baseline --no-other-configs\n")
     f.write("# FETCH_SIZE/WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reads half of a wide coalesced read (MI355X_MICROARCH.md §HBM) and is doubled here.\n")
     f.write("# median over real launches (fall-through launches after loop exit dropped). MB = 1e6 bytes.\n")
     f.write("kernel,launches,fetch_MB_x2,write_MB,total_MB\n")
@@ -51,7 +51,7 @@ d = collections.defaultdict(list)
 for row in csv.DictReader(open(f)):
     d[row["Kernel_Name"].split("(")[0].replace("void ", "")].append((int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1e3)
 with open(f"{out}/kernel_medians.csv", "w") as g:
-    g.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 200 --warmup 20 --no-cpu-baseline ; durations in us\n")
+    g.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-other-configs ; durations in us\n")
     g.write("kernel,launches,median_us,mean_us,min_us,total_ms\n")
     for k, v in sorted(d.items(), key=lambda kv: -sum(kv[1])):
         g.write(f"{k},{len(v)},{statistics.median(v):.2f},{sum(v)/len(v):.2f},{min(v):.2f},{sum(v)/1e3:.3f}\n")
