@@ -1217,22 +1217,27 @@ int32_t sdplr_hip_set_sparse_coo(S* s, int64_t base, int64_t n_sparse, const int
   std::vector<int>&fcp = s->h_fcp, &frv = s->h_frv, &tcp = s->h_tcp, &trv = s->h_trv;
   fcp.assign(n + 1, 0);
   tcp.assign(n + 1, 0);
-  frv.clear(); frv.reserve(E);
-  trv.clear(); trv.reserve(n_upper);
-  for (int64_t j = 0; j < n; j++) {
-    int* b = rows.data() + cnt[j];
-    int* e = rows.data() + cnt[j + 1];
-    if (!std::is_sorted(b, e)) std::sort(b, e);
-    int last = -1;
-    for (int* p = b; p < e; p++) {
-      if (*p == last) continue;
-      last = *p;
-      frv.push_back(last);
-      if (last <= (int)j) trv.push_back(last);
+  // (columns are independent: sorted and made unique on a few host threads, compacted after a prefix sum)
+  parallel_for(n, 4096, [&](int64_t j0, int64_t j1) {
+    for (int64_t j = j0; j < j1; j++) {
+      int* b = rows.data() + cnt[j];
+      int* e = rows.data() + cnt[j + 1];
+      if (!std::is_sorted(b, e)) std::sort(b, e);
+      int* u = std::unique(b, e);
+      fcp[j + 1] = (int)(u - b);
+      tcp[j + 1] = (int)(std::upper_bound(b, u, (int)j) - b);   // rows ≤ j: the column's part of the upper triangle
     }
-    fcp[j + 1] = (int)frv.size();
-    tcp[j + 1] = (int)trv.size();
-  }
+  });
+  for (int64_t j = 0; j < n; j++) { fcp[j + 1] += fcp[j]; tcp[j + 1] += tcp[j]; }
+  frv.resize(fcp[n]);
+  trv.resize(tcp[n]);
+  parallel_for(n, 4096, [&](int64_t j0, int64_t j1) {
+    for (int64_t j = j0; j < j1; j++) {
+      const int* b = rows.data() + cnt[j];
+      std::copy(b, b + (fcp[j + 1] - fcp[j]), frv.begin() + fcp[j]);
+      std::copy(b, b + (tcp[j + 1] - tcp[j]), trv.begin() + tcp[j]);
+    }
+  });
   const int64_t nnzS = (int64_t)frv.size(), nnzT = (int64_t)trv.size();
   auto find_triu = [&](int col, int row) -> int {   // position of (row, col) in the triu pattern, −1 if absent
     const int* b = trv.data() + tcp[col];
@@ -1244,37 +1249,72 @@ int32_t sdplr_hip_set_sparse_coo(S* s, int64_t base, int64_t n_sparse, const int
   s->h_matptr.assign(n_sparse + 1, 0);
   s->h_nzind.resize(n_upper); s->h_one.resize(n_upper); s->h_two.resize(n_upper);
   s->h_gids.resize(n_sparse);
-  int64_t cum = 0;
-  for (int64_t k = 0; k < n_sparse; k++) {
-    s->h_matptr[k] = (int)cum;
-    s->h_gids[k] = (int)(gids[k] - base);
-    for (int64_t e = ent_ptr[k] - base; e < ent_ptr[k + 1] - base; e++) {
-      const int i = (int)(I[e] - base), j = (int)(J[e] - base);
-      if (i > j) continue;                                   // triu keeps i ≤ j (:9)
-      s->h_nzind[cum] = find_triu(j, i);
-      s->h_one[cum] = V[e];
-      s->h_two[cum] = (i == j) ? V[e] : 2.0 * V[e];           // off-diagonal entries count twice (:121-128)
-      cum++;
+  {
+    // (the per-matrix segments are disjoint ranges of the output: counted, then filled on a few host threads — cut at
+    // equal numbers of ENTRIES, so that one multi-entry matrix among 1e5 singletons does not land on one thread)
+    const int64_t nt = std::max<int64_t>(1, std::min<int64_t>(host_threads(), E / 65536));
+    std::vector<int64_t> kcut(nt + 1, n_sparse);
+    kcut[0] = 0;
+    for (int64_t t = 1; t < nt; t++) {
+      const int64_t want = E * t / nt + base;
+      kcut[t] = std::lower_bound(ent_ptr, ent_ptr + n_sparse + 1, want) - ent_ptr;
+      kcut[t] = std::min<int64_t>(std::max<int64_t>(kcut[t], kcut[t - 1]), n_sparse);
     }
+    std::vector<int64_t> ucnt(nt, 0);
+    auto run = [&](int64_t t, bool fill, int64_t start) {
+      int64_t cum = start;
+      for (int64_t k = kcut[t]; k < kcut[t + 1]; k++) {
+        if (fill) { s->h_matptr[k] = (int)cum; s->h_gids[k] = (int)(gids[k] - base); }
+        for (int64_t e = ent_ptr[k] - base; e < ent_ptr[k + 1] - base; e++) {
+          const int i = (int)(I[e] - base), j = (int)(J[e] - base);
+          if (i > j) continue;                                   // triu keeps i ≤ j (:9)
+          if (fill) {
+            s->h_nzind[cum] = find_triu(j, i);
+            s->h_one[cum] = V[e];
+            s->h_two[cum] = (i == j) ? V[e] : 2.0 * V[e];         // off-diagonal entries count twice (:121-128)
+          }
+          cum++;
+        }
+      }
+      return cum - start;
+    };
+    std::vector<int64_t> ustart(nt + 1, 0);
+    if (nt == 1) {
+      ustart[1] = run(0, true, 0);
+    } else {
+      {
+        std::vector<std::thread> th;
+        for (int64_t t = 0; t < nt; t++) th.emplace_back([&, t] { ucnt[t] = run(t, false, 0); });
+        for (auto& x : th) x.join();
+      }
+      for (int64_t t = 0; t < nt; t++) ustart[t + 1] = ustart[t] + ucnt[t];
+      std::vector<std::thread> th;
+      for (int64_t t = 0; t < nt; t++) th.emplace_back([&, t] { (void)run(t, true, ustart[t]); });
+      for (auto& x : th) x.join();
+    }
+    s->h_matptr[n_sparse] = (int)ustart[nt];
   }
-  s->h_matptr[n_sparse] = (int)cum;
   // ---- full pattern → position of (min, max) in the upper-triangular pattern (:135-156): the upper entries of column j
   // ARE column j of the triu pattern, in order; a lower entry (i > j) is searched in column i ----
   s->h_mapped.resize(nnzS);
-  for (int64_t j = 0; j < n; j++) {
-    int up = tcp[j];
-    for (int p = fcp[j]; p < fcp[j + 1]; p++) {
-      const int i = frv[p];
-      if (i <= (int)j) { s->h_mapped[p] = up++; continue; }
-      const int q = find_triu(i, (int)j);
-      if (q < 0) {
-        s->h_matptr.clear(); s->h_nzind.clear(); s->h_one.clear(); s->h_two.clear(); s->h_gids.clear();
-        fcp.clear(); frv.clear(); tcp.clear(); trv.clear(); s->h_mapped.clear();
-        return fail(s, SDPLR_ERR_INVALID_ARG, "set_sparse_coo: a constraint matrix is not symmetric: a lower-triangular entry has no "
-                                              "upper-triangular mirror in the aggregated pattern");
+  std::atomic<int> missing{0};
+  parallel_for(n, 4096, [&](int64_t j0, int64_t j1) {
+    for (int64_t j = j0; j < j1; j++) {
+      int up = tcp[j];
+      for (int p = fcp[j]; p < fcp[j + 1]; p++) {
+        const int i = frv[p];
+        if (i <= (int)j) { s->h_mapped[p] = up++; continue; }
+        const int q = find_triu(i, (int)j);
+        if (q < 0) missing.store(1, std::memory_order_relaxed);
+        s->h_mapped[p] = q;
       }
-      s->h_mapped[p] = q;
     }
+  });
+  if (missing.load()) {
+    s->h_matptr.clear(); s->h_nzind.clear(); s->h_one.clear(); s->h_two.clear(); s->h_gids.clear();
+    fcp.clear(); frv.clear(); tcp.clear(); trv.clear(); s->h_mapped.clear();
+    return fail(s, SDPLR_ERR_INVALID_ARG, "set_sparse_coo: a constraint matrix is not symmetric: a lower-triangular entry has no "
+                                          "upper-triangular mirror in the aggregated pattern");
   }
   s->n_sparse = n_sparse; s->nnzT = nnzT; s->nnzS = nnzS; s->nnzAgg = n_upper;
   s->have_sparse = true;
