@@ -255,6 +255,47 @@ int32_t sdplr_hip_approx_mineigval_lanczos(sdplr_hip_solver* s, int64_t q, const
 int32_t sdplr_hip_dual_obj(sdplr_hip_solver* s, double trace_bound, int64_t iter,
                            const double* v0, double* dual_value, double* mineig);
 
+/* ---- many small instances in lockstep: one launch for a whole batch ------------------------------------------------
+ * The reference runs exps/batch_test.txt as independent sdplr() calls (exps/exp.jl:18-72).  A driver that advances B such
+ * solves side by side hands the SAME step of all of them to the library as one call: the instances on the resident route
+ * (one workgroup owns a small instance) that share a kernel shape go out as ONE launch with one workgroup per instance
+ * — B CUs busy from one stream, one argument table up, one result table back — and every other instance of the batch is
+ * served by the single-instance entry point named in each struct, so the call is total.  Each item is exactly the
+ * argument list of that entry point; `status` is what it would have returned for that instance (the function itself
+ * returns the first non-zero status, or an argument error).  Results are bit-identical to the single-instance calls.
+ * Handles of one call must be distinct and must not be used by other threads during the call.                        */
+typedef struct sdplr_hip_fg_item {            /* sdplr_hip_fg */
+  sdplr_hip_solver* s;
+  double normC, normb;
+  int32_t gtol_relative, ptol_relative;
+  double lagrangian, grad_norm, primal_vio_norm, obj;   /* out (obj: var.obj[] as f! leaves it) */
+  int32_t status;
+} sdplr_hip_fg_item;
+int32_t sdplr_hip_batch_fg(int32_t count, sdplr_hip_fg_item* items);
+
+typedef struct sdplr_hip_major_item {         /* sdplr_hip_major_iteration */
+  sdplr_hip_solver* s;
+  double normC, normb;
+  int32_t gtol_relative, ptol_relative, use_armijo, update_lambda;
+  double sigma, cur_gtol, fprec_eps;
+  int64_t max_local_iters;
+  double time_budget_s;
+  double lagrangian, grad_norm, primal_vio_norm, last_alpha, obj;   /* out */
+  int64_t iters_done;
+  int32_t exit_reason, status;
+} sdplr_hip_major_item;
+int32_t sdplr_hip_batch_major_iteration(int32_t count, sdplr_hip_major_item* items);
+
+typedef struct sdplr_hip_dual_item {          /* sdplr_hip_dual_obj */
+  sdplr_hip_solver* s;
+  double trace_bound;
+  int64_t iter;
+  const double* v0;                           /* [n of that instance] */
+  double dual_value, mineig;                  /* out */
+  int32_t status;
+} sdplr_hip_dual_item;
+int32_t sdplr_hip_batch_dual_obj(int32_t count, sdplr_hip_dual_item* items);
+
 /* ---- high-precision eigen path / DIMACS ----------------------------------------------------------------------
  * SDP_S_eigval(var, aux, nevs, preprocessed; which, ncv, tol, maxiter)  src/coreop.jl:351-374: the nev smallest
  * (which = 0, :SA) or largest (which = 1, :LA) eigenvalues of the S left by the last 𝒜t_preprocess!.  The reference
@@ -279,7 +320,8 @@ int32_t sdplr_hip_factor_dot(sdplr_hip_solver* s, int32_t slot_a, int32_t slot_b
  * out[4] inner-loop batches launched eagerly, out[5] Lanczos graph replays, out[6] Lanczos rounds launched
  * eagerly, out[7] inner iterations run, out[8] inner loops run as ONE resident launch (small instances: one
  * workgroup owns the instance for the whole loop), out[9] Lanczos runs as one resident launch, out[10] fg! calls as
- * one resident launch.  Writes min(cap, 11) entries, *n_written says how many.                             */
+ * one resident launch, out[11] of those launches (loops, Lanczos runs, fg!) the ones this instance shared with others
+ * (sdplr_hip_batch_*).  Writes min(cap, 12) entries, *n_written says how many.                            */
 int32_t sdplr_hip_get_stats(const sdplr_hip_solver* s, int64_t* out, int32_t cap, int32_t* n_written);
 
 /* ---- per-kernel device timing (hipEvent pairs on the handle's stream) ------------------------ */

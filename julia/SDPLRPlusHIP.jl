@@ -340,20 +340,21 @@ function _sdplr(data, var::SolverVars{Ti,Tv}, aux::HIPAux, stats::SolverStats{Tv
     σ = var.σ[]
     cur_gtol = max(1.0 / σ, config.gtol)                                   # :165-169
     cur_ptol = max(1.0 / σ^0.1, config.ptol)
-    𝓛, gnorm, pnorm = fg!(data, var, aux, normC, normb, config)            # :170
+    𝓛, gnorm, pnorm = NaN, NaN, NaN     # the fg! of :170 rides the first major_iteration! (see `pending` below)
     iter, majoriter, localiter = 0, 0, 0
     use_armijo = data.has_inequalities                                     # :176
     stall_left = config.rankupd_tol
     min_gap, best_dual = 1e20, -1e20
     best_λ = copy(var.λ)
-    obj = hip_get_scalar(aux, HIP_S_OBJ)
+    obj = NaN
     report(li) = printintermediate(config.dataset, majoriter, li, iter, 𝓛, obj, σ, cur_gtol, cur_ptol, gnorm, pnorm,
                                    min_gap, best_dual)
 
     # The tail of a major iteration — λ update or σ increase (:358-369), lbfgs_clear! (:384), fg! (:389) — has no host
     # decision in it, nor has the while loop it feeds: the four travel as ONE call (major_iteration!); `pending` holds a
-    # tail that has not been sent yet: (update_λ, σ).
-    pending = nothing
+    # tail that has not been sent yet: (update_λ, σ).  The fg! of :170 and the first pass of the loop are such a call too:
+    # no λ update, σ as it stands, and lbfgs_clear! on the fresh history of lbfgs_init (:163) changes nothing.
+    pending = (false, σ)
     for _ in 1:config.maxmajoriter                                         # :185
         majoriter += 1
         localiter = 0

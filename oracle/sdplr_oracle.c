@@ -1334,3 +1334,41 @@ int32_t sdplr_oracle_symlowrank_norm(int64_t n, int64_t sc, const double* B, con
   *out = p_is_inf ? res : sqrt(res);
   return OK;
 }
+
+/* ---- the lockstep batch calls of the shared ABI: loops over the single-instance functions ------------------------- */
+int32_t sdplr_oracle_batch_fg(int32_t count, sdplr_oracle_fg_item* it) {
+  if (count < 0 || (count > 0 && !it)) return ERR_INVALID;
+  int32_t first = OK;
+  for (int32_t i = 0; i < count; i++) {
+    sdplr_oracle_fg_item* q = &it[i];
+    q->status = sdplr_oracle_fg(q->s, q->normC, q->normb, q->gtol_relative, q->ptol_relative, &q->lagrangian, &q->grad_norm,
+                                &q->primal_vio_norm);
+    if (!q->status) q->status = sdplr_oracle_get_scalar(q->s, S_OBJ, &q->obj);
+    if (q->status && !first) first = q->status;
+  }
+  return first;
+}
+int32_t sdplr_oracle_batch_major_iteration(int32_t count, sdplr_oracle_major_item* it) {
+  if (count < 0 || (count > 0 && !it)) return ERR_INVALID;
+  int32_t first = OK;
+  for (int32_t i = 0; i < count; i++) {
+    sdplr_oracle_major_item* q = &it[i];
+    q->status = sdplr_oracle_major_iteration(q->s, q->normC, q->normb, q->gtol_relative, q->ptol_relative, q->use_armijo,
+                                             q->update_lambda, q->sigma, q->cur_gtol, q->fprec_eps, q->max_local_iters,
+                                             q->time_budget_s, &q->lagrangian, &q->grad_norm, &q->primal_vio_norm,
+                                             &q->last_alpha, &q->iters_done, &q->exit_reason);
+    if (!q->status) q->status = sdplr_oracle_get_scalar(q->s, S_OBJ, &q->obj);
+    if (q->status && !first) first = q->status;
+  }
+  return first;
+}
+int32_t sdplr_oracle_batch_dual_obj(int32_t count, sdplr_oracle_dual_item* it) {
+  if (count < 0 || (count > 0 && !it)) return ERR_INVALID;
+  int32_t first = OK;
+  for (int32_t i = 0; i < count; i++) {
+    sdplr_oracle_dual_item* q = &it[i];
+    q->status = sdplr_oracle_dual_obj(q->s, q->trace_bound, q->iter, q->v0, &q->dual_value, &q->mineig);
+    if (q->status && !first) first = q->status;
+  }
+  return first;
+}

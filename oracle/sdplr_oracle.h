@@ -68,6 +68,36 @@ int32_t sdplr_oracle_major_iteration(sdplr_oracle_solver* s, double normC, doubl
                                      double* lagrangian, double* grad_norm, double* primal_vio_norm,
                                      double* last_alpha, int64_t* iters_done, int32_t* exit_reason);
 int32_t sdplr_oracle_warmup(int32_t n_handles);
+/* the lockstep batch calls of the shared ABI (include/sdplr_hip.h): here plain loops over the single-instance functions */
+typedef struct sdplr_oracle_fg_item {
+  sdplr_oracle_solver* s;
+  double normC, normb;
+  int32_t gtol_relative, ptol_relative;
+  double lagrangian, grad_norm, primal_vio_norm, obj;
+  int32_t status;
+} sdplr_oracle_fg_item;
+int32_t sdplr_oracle_batch_fg(int32_t count, sdplr_oracle_fg_item* items);
+typedef struct sdplr_oracle_major_item {
+  sdplr_oracle_solver* s;
+  double normC, normb;
+  int32_t gtol_relative, ptol_relative, use_armijo, update_lambda;
+  double sigma, cur_gtol, fprec_eps;
+  int64_t max_local_iters;
+  double time_budget_s;
+  double lagrangian, grad_norm, primal_vio_norm, last_alpha, obj;
+  int64_t iters_done;
+  int32_t exit_reason, status;
+} sdplr_oracle_major_item;
+int32_t sdplr_oracle_batch_major_iteration(int32_t count, sdplr_oracle_major_item* items);
+typedef struct sdplr_oracle_dual_item {
+  sdplr_oracle_solver* s;
+  double trace_bound;
+  int64_t iter;
+  const double* v0;
+  double dual_value, mineig;
+  int32_t status;
+} sdplr_oracle_dual_item;
+int32_t sdplr_oracle_batch_dual_obj(int32_t count, sdplr_oracle_dual_item* items);
 int32_t sdplr_oracle_set_sparse_coo(sdplr_oracle_solver* s, int64_t index_base, int64_t n_sparse,
                                     const int64_t* ent_ptr, const int64_t* I, const int64_t* J,
                                     const double* V, const int64_t* global_inds);

@@ -46,6 +46,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", default=None, help="manifest written by scripts/gen_batch_test.py")
     ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--passes", type=int, default=2, help="passes over the batch; the last one is `wall_s`")
     args = ap.parse_args()
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         # launcher: before this process touches torch or the HIP library (see bench.py)
@@ -56,6 +57,7 @@ def main():
             port = so.getsockname()[1]
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
                "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), "--gpus", str(args.gpus)]
+        cmd += ["--passes", str(args.passes)]
         if args.batch:
             cmd += ["--batch", args.batch]
         sys.exit(subprocess.call(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))))
@@ -90,15 +92,25 @@ def main():
     mine = set(batch.assign(len(graphs), world)[rank])
     datas = [builders[e0["problem"]](g) if k in mine else None for k, g in enumerate(graphs)]
     build_s = time.perf_counter() - tb0
-    t0 = time.perf_counter()
     tb = 1.0 if e0["problem"] == "LovaszTheta" else float(max(g.shape[0] for g in graphs))     # exps/test.jl:166-176
-    local = batch.solve_local(datas, rank, world, e0["rank"], concurrency=conc,
-                              ptol=e0["ptol"], objtol=e0["objtol"], seed=e0["seed"], prior_trace_bound=tb)
-    res = batch.gather(local, len(graphs), dist, device)
-    dt = time.perf_counter() - t0
+    lockstep = os.environ.get("SDPLR_BATCH_MODE", "lockstep") == "lockstep"     # ("threads": independent driver threads)
+    # Two passes over the batch: the first one also fills the library's pools (streams, pinned blocks, device blocks of the
+    # sizes this batch uses — a lockstep batch has all its handles alive at once), the second one is the steady state of a
+    # process that solves batch after batch.  Both walls are reported.
+    walls = []
+    for _ in range(max(1, args.passes)):
+        if dist is not None:
+            dist.barrier()
+        t0 = time.perf_counter()
+        local = batch.solve_local(datas, rank, world, e0["rank"], concurrency=conc, lockstep=lockstep,
+                                  ptol=e0["ptol"], objtol=e0["objtol"], seed=e0["seed"], prior_trace_bound=tb)
+        res = batch.gather(local, len(graphs), dist, device)
+        walls.append(time.perf_counter() - t0)
+    dt = walls[-1]
     if rank == 0:
-        print(json.dumps({"instances": len(graphs), "n_gpus": world, "wall_s": dt, "problem_build_s": build_s,
-                          "in_flight_per_gpu": conc, "instances_per_s": len(graphs) / dt,
+        print(json.dumps({"instances": len(graphs), "n_gpus": world, "wall_s": dt, "first_pass_wall_s": walls[0],
+                          "problem_build_s": build_s,
+                          "mode": "lockstep" if lockstep else "threads", "in_flight_per_gpu": conc, "instances_per_s": len(graphs) / dt,
                           "objectives": [round(x, 4) for x in res[:, 1]],
                           "dual_bounds": [round(x, 4) for x in res[:, 2]],
                           "iterations": [int(x) for x in res[:, 3]]}))

@@ -12,7 +12,9 @@ from typing import Callable, List, Optional, Sequence
 
 import numpy as np
 
-from .sdplr import sdplr
+from . import cabi
+from .sdplr import _ASCII_ALIASES, REQ_DUAL, REQ_FG, REQ_MAJOR, build_solver, sdplr, sdplr_steps, serve
+from .structs import BurerMonteiroConfig
 
 N_FIELDS = 5  # index, obj, max_dual_value, iter, seconds
 
@@ -23,10 +25,19 @@ def assign(n_instances: int, world: int) -> List[List[int]]:
 
 
 def solve_local(instances: Sequence, rank: int, world: int, r: int, *, abi=None, concurrency: int = 8,
-                make_data: Optional[Callable] = None, **kwargs) -> np.ndarray:
+                make_data: Optional[Callable] = None, lockstep: bool = False, **kwargs) -> np.ndarray:
     """Solve this rank's share.  `instances[k]` is an SDPData, or anything `make_data` turns into one.
-    Returns an array [n_local, N_FIELDS]."""
+    ``lockstep``: side by side through ``solve_lockstep`` (one launch per step for all of them) instead of as
+    ``concurrency`` independent driver threads.  Returns an array [n_local, N_FIELDS]."""
     mine = assign(len(instances), world)[rank]
+    if lockstep and mine:
+        datas = [make_data(instances[k]) if make_data is not None else instances[k] for k in mine]
+        res = solve_lockstep(datas, r, abi=abi, setup_workers=concurrency, printlevel=0, **kwargs)
+        for x in res:
+            if isinstance(x, Exception):
+                raise x
+        return np.asarray([[float(k), x["obj"], x["max_dual_value"], float(x["iter"]), x["totaltime"]]
+                           for k, x in zip(mine, res)], dtype=np.float64)
 
     def one(k):
         data = make_data(instances[k]) if make_data is not None else instances[k]
@@ -51,6 +62,87 @@ def solve_local(instances: Sequence, rank: int, world: int, r: int, *, abi=None,
         finally:
             sys.setswitchinterval(old_interval)
     return np.asarray(rows, dtype=np.float64)
+
+
+def serve_batch(abi, solvers, reqs) -> list:
+    """The pending request of every instance, served side by side: the requests of one kind are ONE library call
+    (``sdplr_hip_batch_*``: one kernel launch for all the small instances among them); the rest go one by one.
+    → per instance what ``sdplr.serve`` returns, or the exception its call raised."""
+    out = [None] * len(solvers)
+    for kind, call in ((REQ_MAJOR, cabi.batch_major_iteration), (REQ_DUAL, cabi.batch_dual_obj), (REQ_FG, cabi.batch_fg)):
+        ks = [k for k, q in enumerate(reqs) if q[0] == kind]
+        if ks:
+            for k, res in zip(ks, call(abi, [solvers[k] for k in ks], [reqs[k][1:] for k in ks])):
+                out[k] = res
+    for k, q in enumerate(reqs):
+        if out[k] is None:
+            try:
+                out[k] = serve(solvers[k], q)
+            except Exception as e:           # handed to that instance's stepper, like the batched calls' errors
+                out[k] = e
+    return out
+
+
+def solve_lockstep(datas: Sequence, r: int, *, abi=None, setup_workers: int = 8, **kwargs) -> list:
+    """``sdplr`` on every SDPData of ``datas`` side by side on ONE device: the solves advance in lockstep — each round
+    serves the pending device step of all live instances as one call (``serve_batch``) — instead of as independent
+    threads whose launches share the GPU only as far as its hardware queues allow.  Same control flow (``sdplr_steps``),
+    same results as ``sdplr(data=…)`` one by one.  → the list of result Dicts (an instance that failed: its exception)."""
+    abi = abi if abi is not None else cabi.load_hip()
+
+    def config_of():
+        config = BurerMonteiroConfig()
+        for key, value in kwargs.items():
+            key = _ASCII_ALIASES.get(key, key)
+            if not hasattr(config, key):
+                raise TypeError(f"unrecognized keyword argument {key}")
+            setattr(config, key, value)
+        return config
+
+    configs = [config_of() for _ in datas]
+    t0 = time.time()
+    # set-up (preprocessing, layout, uploads) is host work per instance: a few threads
+    if setup_workers > 1 and len(datas) > 1:
+        with ThreadPoolExecutor(max_workers=min(setup_workers, len(datas))) as ex:
+            solvers = list(ex.map(lambda kc: build_solver(abi, kc[0], int(r), kc[1]), zip(datas, configs)))
+    else:
+        solvers = [build_solver(abi, d, int(r), c) for d, c in zip(datas, configs)]
+    setup_dt = (time.time() - t0) / max(len(datas), 1)
+    results: list = [None] * len(datas)
+    steppers = [sdplr_steps(d, v, c) for d, v, c in zip(datas, solvers, configs)]
+    pending = {}
+
+    def advance(k, response):
+        try:
+            if response is None:
+                pending[k] = next(steppers[k])
+            elif isinstance(response, Exception):
+                pending[k] = steppers[k].throw(response)
+            else:
+                pending[k] = steppers[k].send(response)
+        except StopIteration as done:
+            pending.pop(k, None)
+            ans = done.value
+            ans["preprocess_time"] = setup_dt
+            ans["totaltime"] += setup_dt
+            results[k] = ans
+            solvers[k].close()
+        except Exception as e:
+            pending.pop(k, None)
+            results[k] = e
+            solvers[k].close()
+
+    try:
+        for k in range(len(datas)):
+            advance(k, None)
+        while pending:
+            ks = sorted(pending)
+            for k, response in zip(ks, serve_batch(abi, [solvers[k] for k in ks], [pending[k] for k in ks])):
+                advance(k, response)
+    finally:
+        for v in solvers:
+            v.close()
+    return results
 
 
 def gather(local: np.ndarray, n_instances: int, dist=None, device=None) -> np.ndarray:

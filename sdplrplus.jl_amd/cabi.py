@@ -27,11 +27,31 @@ F_RT, F_GT, F_DIRT, F_LBFGS_S, F_LBFGS_Y, F_SCRATCH = 0, 1, 2, 100, 200, 300
  V_UVT, V_TRIU_S_NZVAL, V_S_NZVAL, V_SCRATCH) = range(15)
 STAT_NAMES = ("graph_captures", "graph_capture_failures", "graph_capture_skipped", "graph_batches",
               "eager_batches", "lanczos_graph_replays", "lanczos_eager_rounds", "inner_iterations",
-              "resident_loops", "resident_lanczos", "resident_fg")
+              "resident_loops", "resident_lanczos", "resident_fg", "resident_shared_launches")
 S_SIGMA, S_OBJ, S_LBFGS_LATEST = 0, 1, 2
 
 _i32, _i64, _f64, _vp = C.c_int32, C.c_int64, C.c_double, C.c_void_p
 _pi32, _pi64, _pf64 = C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_double)
+
+
+
+class FgItem(C.Structure):            # sdplr_hip_fg_item
+    _fields_ = [("s", _vp), ("normC", _f64), ("normb", _f64), ("gtol_relative", _i32), ("ptol_relative", _i32),
+                ("lagrangian", _f64), ("grad_norm", _f64), ("primal_vio_norm", _f64), ("obj", _f64), ("status", _i32)]
+
+
+class MajorItem(C.Structure):         # sdplr_hip_major_item
+    _fields_ = [("s", _vp), ("normC", _f64), ("normb", _f64), ("gtol_relative", _i32), ("ptol_relative", _i32),
+                ("use_armijo", _i32), ("update_lambda", _i32), ("sigma", _f64), ("cur_gtol", _f64), ("fprec_eps", _f64),
+                ("max_local_iters", _i64), ("time_budget_s", _f64), ("lagrangian", _f64), ("grad_norm", _f64),
+                ("primal_vio_norm", _f64), ("last_alpha", _f64), ("obj", _f64), ("iters_done", _i64),
+                ("exit_reason", _i32), ("status", _i32)]
+
+
+class DualItem(C.Structure):          # sdplr_hip_dual_item
+    _fields_ = [("s", _vp), ("trace_bound", _f64), ("iter", _i64), ("v0", _pf64), ("dual_value", _f64),
+                ("mineig", _f64), ("status", _i32)]
+
 
 # name → argtypes (restype is int32 unless listed in _RESTYPES); this table IS the header, and
 # tests/test_cabi_symbols.py checks it against include/sdplr_hip.h.
@@ -82,6 +102,9 @@ SIGNATURES = {
                    _pf64, _pi64, _pi32],
     "major_iteration": [_vp, _f64, _f64, _i32, _i32, _i32, _i32, _f64, _f64, _f64, _i64, _f64, _pf64, _pf64, _pf64,
                         _pf64, _pi64, _pi32],
+    "batch_fg": [_i32, C.POINTER(FgItem)],
+    "batch_major_iteration": [_i32, C.POINTER(MajorItem)],
+    "batch_dual_obj": [_i32, C.POINTER(DualItem)],
     "lanczos": [_vp, _i64, _pf64, _pf64, _pf64, _pi64],
     "tridiag_mineig": [_pf64, _pf64, _i64, _pf64],
     "approx_mineigval_lanczos": [_vp, _i64, _pf64, _pf64],
@@ -500,3 +523,59 @@ class DeviceSolver:
             self._ck(self.abi.profile_get(self._h, i, buf, 128, C.byref(cnt), C.byref(ms)))
             out[buf.value.decode()] = (int(cnt.value), float(ms.value))
         return out
+
+
+# -- lockstep batches: the same step of many instances as one library call (include/sdplr_hip.h) ---------------------
+def _batch_results(abi: CABI, arr, solvers, unpack):
+    out = []
+    for k, sv in enumerate(solvers):
+        if arr[k].status != OK:
+            msg = abi.last_error(sv._h)
+            out.append(SdplrError(int(arr[k].status), msg.decode() if msg else "error"))
+        else:
+            out.append(unpack(arr[k]))
+    return out
+
+
+def batch_fg(abi: CABI, solvers, args):
+    """``fg`` of every solver in one call; args[k] = (normC, normb, gtol_relative, ptol_relative).
+    → per solver (ℒ, grad_norm, primal_vio_norm, obj), or the SdplrError its own call would have raised."""
+    arr = (FgItem * len(solvers))()
+    for k, (sv, a) in enumerate(zip(solvers, args)):
+        it = arr[k]
+        it.s = sv._h.value
+        it.normC, it.normb, it.gtol_relative, it.ptol_relative = float(a[0]), float(a[1]), int(a[2]), int(a[3])
+    abi.batch_fg(len(solvers), arr)
+    return _batch_results(abi, arr, solvers, lambda q: (q.lagrangian, q.grad_norm, q.primal_vio_norm, q.obj))
+
+
+def batch_major_iteration(abi: CABI, solvers, args):
+    """``major_iteration`` of every solver in one call; args[k] = its argument tuple.
+    → per solver (ℒ, grad_norm, primal_vio_norm, last α, iterations, exit_reason, obj) or an SdplrError."""
+    arr = (MajorItem * len(solvers))()
+    for k, (sv, a) in enumerate(zip(solvers, args)):
+        it = arr[k]
+        it.s = sv._h.value
+        (it.normC, it.normb, it.gtol_relative, it.ptol_relative, it.use_armijo, it.update_lambda, it.sigma, it.cur_gtol,
+         it.fprec_eps, it.max_local_iters, it.time_budget_s) = (
+            float(a[0]), float(a[1]), int(a[2]), int(a[3]), int(a[4]), int(a[5]), float(a[6]), float(a[7]), float(a[8]),
+            int(a[9]), float(a[10]))
+    abi.batch_major_iteration(len(solvers), arr)
+    return _batch_results(abi, arr, solvers, lambda q: (q.lagrangian, q.grad_norm, q.primal_vio_norm, q.last_alpha,
+                                                        int(q.iters_done), int(q.exit_reason), q.obj))
+
+
+def batch_dual_obj(abi: CABI, solvers, args):
+    """``dual_obj`` of every solver in one call; args[k] = (trace_bound, iter, v0) → per solver (dual_value, λ_min)."""
+    arr = (DualItem * len(solvers))()
+    keep = []
+    for k, (sv, a) in enumerate(zip(solvers, args)):
+        v0 = _f64c(a[2])
+        if v0.size != sv.n:
+            raise ValueError("v0 must have length n")
+        keep.append(v0)
+        it = arr[k]
+        it.s = sv._h.value
+        it.trace_bound, it.iter, it.v0 = float(a[0]), int(a[1]), _pd(v0)
+    abi.batch_dual_obj(len(solvers), arr)
+    return _batch_results(abi, arr, solvers, lambda q: (q.dual_value, q.mineig))

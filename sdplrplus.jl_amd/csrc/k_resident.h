@@ -227,6 +227,11 @@ struct RsFgArgs {
   double *y, *pv_raw, *pv;
   const double *lam, *lam_ub, *lb, *b;
   DevCtrl* c;
+  // batched launches (sdplr_hip_batch_fg): the norm parameters ride the argument row instead of a pushed control block,
+  // and the scalars the host reads back go to a row of a result table instead of a pulled one
+  int in_set, in_grel, in_prel;
+  double in_normC, in_normb;
+  double* out;                          // [4]: ℒ, ‖G‖, ‖primal_vio‖, obj
 };
 // the body of fg!: every thread of the resident workgroup calls it; Rl[Npad] | rrl[n] | djl[n] are LDS work arrays, sred holds
 // 3·NW doubles, c is the control block (global memory in k_rs_fg, the LDS copy in the loop's prologue)
@@ -344,14 +349,33 @@ __device__ __forceinline__ void rs_fg_body(const RsFgArgs& a, DevCtrl& c, double
   __syncthreads();
 }
 template <int LPR, int VEC>
-__global__ void __launch_bounds__(SDPLR_RS_NT)
-k_rs_fg(RsFgArgs a) {
+__device__ __forceinline__ void rs_fg_run(const RsFgArgs& a) {
   extern __shared__ __attribute__((aligned(16))) double rs_lds[];
   __shared__ double sred[3 * SDPLR_RS_NW];
   __shared__ RsFgShared sh;
   const long long N = (long long)a.n * a.r;
   const long long Npad = (N + 1) & ~1LL;
+  if (a.in_set) {
+    if (threadIdx.x == 0) {   // (set_norm_params of the single-instance entry point)
+      a.c->normC = a.in_normC; a.c->normb = a.in_normb; a.c->grel = a.in_grel; a.c->prel = a.in_prel;
+      a.c->done = 0; a.c->err = 0;
+    }
+    __syncthreads();
+  }
   rs_fg_body<LPR, VEC>(a, *a.c, rs_lds, rs_lds + Npad, rs_lds + Npad + a.n, sred, sh);
+  if (a.out != nullptr && threadIdx.x == 0) {
+    a.out[0] = a.c->L; a.out[1] = a.c->gnorm; a.out[2] = a.c->pvnorm; a.out[3] = a.c->obj;
+  }
+}
+template <int LPR, int VEC>
+__global__ void __launch_bounds__(SDPLR_RS_NT)
+k_rs_fg(RsFgArgs a) { rs_fg_run<LPR, VEC>(a); }
+// one workgroup per instance: block b takes row b of the argument table
+template <int LPR, int VEC>
+__global__ void __launch_bounds__(SDPLR_RS_NT)
+k_rs_fg_batch(const RsFgArgs* __restrict__ items) {
+  const RsFgArgs a = items[blockIdx.x];
+  rs_fg_run<LPR, VEC>(a);
 }
 
 struct RsLoopArgs {
@@ -372,6 +396,12 @@ struct RsLoopArgs {
   const double* b;
   double* lam_rw;                       // λ, writable (pre_lambda)
   long long budget_ticks;               // wall_clock64() ticks this call may run (≤ 0: no limit), src/sdplr.jl:272-277
+  // batched launches (sdplr_hip_batch_major_iteration): what the host otherwise writes into the control block before the
+  // launch rides the argument row, and what it reads back afterwards goes to a row of a result table
+  int in_set, in_grel, in_prel;
+  double in_sigma, in_gtol, in_fprec, in_normC, in_normb;
+  long long in_max_iters;
+  double* out;                          // [8]: ℒ, ‖G‖, ‖primal_vio‖, α, obj, iters, exit_reason, err
 };
 
 // constraint data of the rows a thread owns (row j = tid + q·NT): registers for q < RPT, global memory beyond
@@ -393,8 +423,7 @@ __device__ __forceinline__ RsRow rs_load_row(const RsLoopArgs& a, int j) {
 }
 
 template <int LPR, int VEC, int HM>
-__global__ void __launch_bounds__(SDPLR_RS_NT)
-k_rs_loop(RsLoopArgs a) {
+__device__ __forceinline__ void rs_loop_run(const RsLoopArgs& a) {
   extern __shared__ __attribute__((aligned(16))) double rs_lds[];   // (16-byte LDS reads: an 8-byte-aligned base behind the static LDS made every ds_read_b128 a misaligned access — 5× slower)
   __shared__ SeamLds gd;
   __shared__ double sred[(5 * HM + 2 > 10 ? 5 * HM + 2 : 10) * SDPLR_RS_NW];
@@ -420,11 +449,27 @@ k_rs_loop(RsLoopArgs a) {
   for (int t = tid; t < (int)(sizeof(DevCtrl) / 8); t += NT)
     reinterpret_cast<unsigned long long*>(&gd.c)[t] = reinterpret_cast<const unsigned long long*>(a.c)[t];
   const long long t_start = (long long)wall_clock64();
+  __syncthreads();
+  // σ as the block holds it on entry: the λ update of the prologue runs BEFORE var.σ[] is written (src/sdplr.jl:358-362
+  // come before :366-369), so it must not see the σ the argument row brings
+  const double sigma_on_entry = gd.c.sigma;
+  if (a.in_set) {   // (sdplr_hip_major_iteration: var.σ[], the loop's parameters and counters)
+    __syncthreads();
+    if (tid == 0) {
+      DevCtrl& c = gd.c;
+      c.sigma = a.in_sigma;
+      c.done = 0; c.exit_reason = 0; c.err = 0; c.use_armijo = 0;
+      c.iters = 0; c.max_iters = a.in_max_iters; c.reldelta_exit = 0; c.norms_pending = 0; c.pv2_extra = 0.0;
+      c.cur_gtol = a.in_gtol; c.fprec_eps = a.in_fprec; c.normC = a.in_normC; c.normb = a.in_normb;
+      c.grel = a.in_grel; c.prel = a.in_prel;
+      c.alpha = 0.0; c.alpha_max = 1.0;
+    }
+  }
   if (a.pre_lambda || a.pre_clear || a.pre_fg) {
     __shared__ RsFgShared fsh;
     __syncthreads();
     if (a.pre_lambda) {      // λᵢ ← min(λ_ubᵢ, λᵢ − σ·primal_vio_rawᵢ)  (src/sdplr.jl:358-362)
-      const double sigma = gd.c.sigma;
+      const double sigma = sigma_on_entry;
       for (int k = tid; k < m; k += NT) a.lam_rw[k] = fmin(a.lam_ub[k], a.lam_rw[k] - sigma * a.pv_raw[k]);
     }
     if (a.pre_clear) {       // lbfgs_clear!: s, y ← 0 (neighbours in the arena), ρ = a = 0, and with them the Gram data
@@ -837,6 +882,22 @@ k_rs_loop(RsLoopArgs a) {
   __syncthreads();
   for (int t = tid; t < (int)(sizeof(DevCtrl) / 8); t += NT)
     reinterpret_cast<unsigned long long*>(a.c)[t] = reinterpret_cast<const unsigned long long*>(&gd.c)[t];
+  if (a.out != nullptr && tid == 0) {
+    const DevCtrl& c = gd.c;
+    a.out[0] = c.L; a.out[1] = c.gnorm; a.out[2] = c.pvnorm; a.out[3] = c.alpha; a.out[4] = c.obj;
+    a.out[5] = (double)c.iters; a.out[6] = (double)c.exit_reason; a.out[7] = (double)c.err;
+  }
+}
+template <int LPR, int VEC, int HM>
+__global__ void __launch_bounds__(SDPLR_RS_NT)
+k_rs_loop(RsLoopArgs a) { rs_loop_run<LPR, VEC, HM>(a); }
+// one workgroup per instance: block b takes row b of the argument table (64 small instances: one launch on 64 CUs instead
+// of 64 launches that share the device only as far as the hardware queues allow)
+template <int LPR, int VEC, int HM>
+__global__ void __launch_bounds__(SDPLR_RS_NT)
+k_rs_loop_batch(const RsLoopArgs* __restrict__ items) {
+  const RsLoopArgs a = items[blockIdx.x];
+  rs_loop_run<LPR, VEC, HM>(a);
 }
 
 // ---- approx_mineigval_lanczos's recurrence (src/coreop.jl:473-500) in one launch -----------------------------------
@@ -967,6 +1028,7 @@ struct RsLzEllArgs {
   int dual, m;
   double* y_rw;
   const double *lam, *lam_ub, *pv_raw, *b;
+  double* out;                          // batched launches: [3] smallest eigenvalue, ⟨y, b⟩, steps
 };
 // number of eigenvalues of SymTridiagonal(d, e) below x (Sturm count), d = alpha + 1
 __device__ __forceinline__ int rs_sturm_below(const double* al, const double* be, int k, double x) {
@@ -981,8 +1043,7 @@ __device__ __forceinline__ int rs_sturm_below(const double* al, const double* be
   return cnt;
 }
 template <bool ELL_LDS>
-__global__ void __launch_bounds__(SDPLR_RS_NT)
-k_rs_lanczos_ell(RsLzEllArgs a) {
+__device__ __forceinline__ void rs_lanczos_ell_run(const RsLzEllArgs& a) {
   extern __shared__ __attribute__((aligned(16))) double rs_lds[];
   __shared__ double sred[SDPLR_RS_NW];
   __shared__ int lp[1026];     // ELL_LDS: first pair-line of each slice in the packed copy
@@ -1141,10 +1202,11 @@ k_rs_lanczos_ell(RsLzEllArgs a) {
     a.c->lz_beta_prev = beta_prev;
   }
   if (!a.dual) return;
+  double yb;
   {   // ⟨y[1:m], b⟩  (:412)
     double t = 0.0;
     for (int i = tid; i < a.m; i += NT) t += a.yvec[i] * a.b[i];
-    const double yb = bsum(t);
+    yb = bsum(t);
     if (tid == 0) a.c->descent = yb;
   }
   // The smallest eigenvalue of SymTridiagonal(alpha .+ 1, beta) minus 1 (:502-513) — the host routine's bisection
@@ -1184,6 +1246,18 @@ k_rs_lanczos_ell(RsLzEllArgs a) {
       }
       ev = 0.5 * (lo + hi) - 1.0;                                  // cancel the shift (:513)
     }
-    if (wl == 0) a.c->lz_mineig = ev;
+    if (wl == 0) {
+      a.c->lz_mineig = ev;
+      if (a.out != nullptr) { a.out[0] = ev; a.out[1] = yb; a.out[2] = (double)steps; }
+    }
   }
+}
+template <bool ELL_LDS>
+__global__ void __launch_bounds__(SDPLR_RS_NT)
+k_rs_lanczos_ell(RsLzEllArgs a) { rs_lanczos_ell_run<ELL_LDS>(a); }
+template <bool ELL_LDS>
+__global__ void __launch_bounds__(SDPLR_RS_NT)
+k_rs_lanczos_ell_batch(const RsLzEllArgs* __restrict__ items) {
+  const RsLzEllArgs a = items[blockIdx.x];
+  rs_lanczos_ell_run<ELL_LDS>(a);
 }

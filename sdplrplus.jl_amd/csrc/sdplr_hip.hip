@@ -122,6 +122,7 @@ struct sdplr_hip_solver {
   std::thread band_thread;
   int nb_tile = 0, nb_step = 1, tile_blocks = 512;
   bool use_tile = false;
+  bool tiles_deferred = false;   // an instance of the resident route: the tiles (multi-launch route) are built when first needed
   bool tile_attr_done = false;
   bool tile_panels = false;  // SDPLR_HIP_TILE_PANELS: 128-byte half-row gathers, two passes over the lists (experiment)
   bool no_updfuse = false;   // SDPLR_HIP_NO_UPDFUSE: lbfgs_update! as a kernel of its own on the singleton fast path
@@ -189,7 +190,7 @@ struct sdplr_hip_solver {
   double* scratchV = nullptr;
   // counters (sdplr_hip_get_stats)
   int64_t st_captures = 0, st_capture_failed = 0, st_capture_skipped = 0, st_graph_batches = 0,
-          st_eager_batches = 0, st_lz_graph = 0, st_lz_eager = 0, st_iters = 0, st_rs_loops = 0, st_rs_lz = 0, st_rs_fg = 0;
+          st_eager_batches = 0, st_lz_graph = 0, st_lz_eager = 0, st_iters = 0, st_rs_loops = 0, st_rs_lz = 0, st_rs_fg = 0, st_rs_shared = 0;
 
   // profiling
   bool prof_on = false;
@@ -260,7 +261,7 @@ void parallel_for(int64_t n_items, int64_t min_per_thread, F&& body) {   // body
 // hipMalloc / hipFree take process-wide locks and hipFree waits for the whole device: with eight small instances in
 // flight (BASELINE config 5: n = 800, ≈ 60 arrays per handle, a handle created and destroyed per instance) the handles
 // stalled each other in the allocator.  Blocks of ≤ 16 MiB go back to a per-device free list keyed by their exact size
-// (instances of one batch have the same sizes) instead of to the runtime, ≤ 512 MiB in all; larger blocks (the factor
+// (instances of one batch have the same sizes) instead of to the runtime, ≤ 4 GiB in all (a small instance holds ≈ 14 MB, and a lockstep batch has all of its instances alive at once); larger blocks (the factor
 // arena of a big instance) bypass the pool.  A block is only ever returned after the owning handle's stream has been
 // drained.  SDPLR_HIP_NO_POOL=1 switches the pool off.
 struct DevPool {
@@ -275,7 +276,7 @@ struct DevPool {
   std::vector<hipEvent_t> events_free;
   size_t cached = 0;
   const bool off = getenv("SDPLR_HIP_NO_POOL") != nullptr;
-  static constexpr size_t MAX_BLOCK = (size_t)16 << 20, MAX_CACHED = (size_t)512 << 20;
+  static constexpr size_t MAX_BLOCK = (size_t)16 << 20, MAX_CACHED = (size_t)4 << 30;
 };
 DevPool& pool() {
   static DevPool* p = new DevPool();   // never destroyed: the HIP runtime may be gone by the time statics are
@@ -339,7 +340,7 @@ void pool_host_ctrl_free(void* p) {
   DevPool& P = pool();
   if (!P.off) {
     std::lock_guard<std::mutex> g(P.mu);
-    if (P.pinned_free.size() < 256) {
+    if (P.pinned_free.size() < 1024) {
       P.pinned_free.push_back(p);
       return;
     }
@@ -370,7 +371,7 @@ void pool_stream_free(hipStream_t st) {   // (drained by the caller)
   if (!P.off) {
     std::lock_guard<std::mutex> g(P.mu);
     auto& v = P.streams_free[dev];
-    if (v.size() < 64) {
+    if (v.size() < 256) {   // (a lockstep batch has every instance's handle — and stream — alive at once)
       v.push_back(st);
       return;
     }
@@ -396,7 +397,7 @@ void pool_event_free(hipEvent_t e) {
   DevPool& P = pool();
   if (!P.off) {
     std::lock_guard<std::mutex> g(P.mu);
-    if (P.events_free.size() < 256) {
+    if (P.events_free.size() < 1024) {
       P.events_free.push_back(e);
       return;
     }
@@ -634,6 +635,16 @@ int sync_check(S* s) {
   HIPCK(s, hipGetLastError());
   HIPCK(s, hipStreamSynchronize(s->stream));
   return SDPLR_OK;
+}
+
+// dynamic LDS the resident loop needs (k_resident.h) and its budget; tiles_can_wait: "small enough for that route"
+constexpr size_t RS_LDS_MAX = 150 * 1024;   // dynamic LDS of a resident kernel (≈ 9.6 KB more are static: control block, reduction scratch)
+size_t rs_loop_lds(const S* s) {
+  const size_t N = (size_t)s->n * (size_t)s->r;
+  return (((N + 1) & ~(size_t)1) + 3 * (size_t)s->n) * sizeof(double);
+}
+bool tiles_can_wait(const S* s) {
+  return !s->force_graph && getenv("SDPLR_HIP_NO_RESIDENT") == nullptr && rs_loop_lds(s) <= RS_LDS_MAX;
 }
 
 int blocks_for(long long work, int per_block, int cap) {
@@ -1125,10 +1136,10 @@ int32_t sdplr_hip_set_device(int32_t device) {
 int32_t sdplr_hip_warmup(int32_t n_handles) {
   ApiShared api_guard;
   if (have_device() <= 0) return fail(nullptr, SDPLR_ERR_NO_DEVICE, "no HIP device");
-  if (n_handles < 1 || n_handles > 64) return fail(nullptr, SDPLR_ERR_INVALID_ARG, "warmup: 1 ≤ n_handles ≤ 64");
+  if (n_handles < 1 || n_handles > 256) return fail(nullptr, SDPLR_ERR_INVALID_ARG, "warmup: 1 ≤ n_handles ≤ 256");
   std::vector<hipStream_t> st(n_handles, nullptr);
   std::vector<hipEvent_t> ev(2 * (size_t)n_handles, nullptr);
-  std::vector<void*> pc(3 * (size_t)n_handles, nullptr), ch(n_handles, nullptr);
+  std::vector<void*> pc(3 * (size_t)n_handles, nullptr), ch(std::min(n_handles, 32), nullptr);
   hipError_t e = hipSuccess;
   for (auto& x : st) if (e == hipSuccess) e = pool_stream(&x);
   for (auto& x : ev) if (e == hipSuccess) e = pool_event(&x);
@@ -1666,7 +1677,10 @@ int32_t sdplr_hip_finalize(S* s) {
       // rebuilt by reset_rank
       s->h_gptr = g_ptr; s->h_gcol = g_col; s->h_gval = g_val;
       lap("diagonal lists + uploads");
-      if ((rc = build_tiles(s))) return rc;
+      // an instance small enough for the resident route never walks the tiles unless it leaves that route (rank growth,
+      // Armijo, profiling): their construction — more than half of a small instance's finalize — waits for that day
+      s->tiles_deferred = tiles_can_wait(s);
+      if (!s->tiles_deferred && (rc = build_tiles(s))) return rc;
       lap("tiles");
       s->ff.gid_g = s->h_gids[kg];
       if ((rc = upload(s, &s->ff.diagpos, diagpos))) return rc;
@@ -1807,6 +1821,10 @@ int32_t sdplr_hip_finalize(S* s) {
   if ((rc = dzero(s, &s->lr_part, (size_t)std::max(s->nb_lr, SDPLR_MAXNB) * 2 * std::max(lr.ST, 1) * s->r))) return rc;
   if ((rc = dzero(s, &s->lr_W, (size_t)2 * std::max(lr.ST, 1) * s->r))) return rc;
   if ((rc = dzero(s, &s->lr_WS, (size_t)std::max(lr.ST, 1) * s->r))) return rc;
+  if (s->tiles_deferred && !s->rs_ok) {   // not an instance of the resident route after all
+    s->tiles_deferred = false;
+    if ((rc = build_tiles(s))) return rc;
+  }
   // release host staging
   std::vector<int>().swap(s->h_nzind); std::vector<int>().swap(s->h_trv); std::vector<int>().swap(s->h_frv);
   std::vector<int>().swap(s->h_mapped); std::vector<double>().swap(s->h_one); std::vector<double>().swap(s->h_two);
@@ -1854,7 +1872,11 @@ int32_t sdplr_hip_reset_rank(S* s, int64_t new_r) {
   // everything sized by the rank is released before it is re-allocated (the graphs above hold their pointers)
   for (double** p : {&s->lr_part, &s->lr_W, &s->lr_WS, &s->scratchF[0], &s->scratchF[1]}) { dfree(s, *p); *p = nullptr; }
   s->r = new_r;
-  int rc = s->fast ? build_tiles(s) : SDPLR_OK;
+  int rc = SDPLR_OK;
+  if (s->fast) {
+    s->tiles_deferred = s->rs_ok && tiles_can_wait(s);
+    if (!s->tiles_deferred) rc = build_tiles(s);
+  }
   if (rc) return rc;
   if ((rc = alloc_factors(s))) return rc;
   const int64_t m = s->m;
@@ -2029,6 +2051,11 @@ namespace {
 // tiles taller than 8 rows need more than 64 KB of dynamic LDS per block: asked for once per (shape, handle), outside
 // any stream capture (sdplr_hip_inner_loop calls this before it enqueues anything)
 int tile_lds_attr(S* s) {
+  if (s->tiles_deferred) {   // first use of the multi-launch route by an instance that was set up for the resident one
+    s->tiles_deferred = false;
+    int rc = build_tiles(s);
+    if (rc) return rc;
+  }
   if (!s->use_tile || s->tile_attr_done) return SDPLR_OK;
   const int bytes = (int)(((size_t)SDPLR_NT * s->VEC * (s->tile.K + 1) + (size_t)(SDPLR_NT / s->LPR) * (2 * s->tile.K + 8) + (size_t)(SDPLR_NT / 64) * 2 * s->LPR * s->VEC) * sizeof(double));
   // The attribute is per function and PROCESS-wide: each instantiation keeps the largest value any handle has asked for
@@ -2481,7 +2508,6 @@ void enq_iteration_fast2(S* s) {
 
 // ---- resident route for small instances (k_resident.h) ----------------------------------------------------------
 // One workgroup owns the instance for a whole inner loop / Lanczos run: one launch per call.
-constexpr size_t RS_LDS_MAX = 150 * 1024;   // dynamic LDS of a resident kernel (≈ 9.6 KB more are static: control block, reduction scratch, palette)
 double wall_clock_hz() {   // rate of wall_clock64() on this device
   static const double hz = [] {
     int dev = 0, khz = 0;
@@ -2490,10 +2516,6 @@ double wall_clock_hz() {   // rate of wall_clock64() on this device
     return 1e3 * (double)khz;
   }();
   return hz;
-}
-size_t rs_loop_lds(const S* s) {
-  const size_t N = (size_t)s->n * (size_t)s->r;
-  return (((N + 1) & ~(size_t)1) + 3 * (size_t)s->n) * sizeof(double);
 }
 // SDPLR_HIP_FORCE_GRAPH ("treat this instance as a large one": the tests' default) and SDPLR_HIP_NO_RESIDENT keep an
 // instance on the multi-launch routes.
@@ -2532,7 +2554,7 @@ bool rs_lanczos_applies(const S* s) {
     }                                                                                                                \
   } while (0)
 
-int enq_resident_loop(S* s, double time_budget_s, bool refresh_P, bool pre_lambda = false, bool pre_clear_fg = false) {
+RsLoopArgs rs_loop_args(S* s, double time_budget_s, bool refresh_P, bool pre_lambda, bool pre_clear_fg) {
   RsLoopArgs a{};
   a.pre_lambda = pre_lambda ? 1 : 0;
   a.pre_clear = a.pre_fg = pre_clear_fg ? 1 : 0;
@@ -2549,6 +2571,22 @@ int enq_resident_loop(S* s, double time_budget_s, bool refresh_P, bool pre_lambd
   a.c = s->ctrl;
   a.refresh_P = refresh_P ? 1 : 0;
   a.budget_ticks = time_budget_s > 0 ? std::max<long long>(1, (long long)(time_budget_s * wall_clock_hz())) : 0;
+  return a;
+}
+struct RsLoopIn {   // what a major iteration writes into the control block in front of its loop
+  double sigma, gtol, fprec, normC, normb;
+  int grel, prel;
+  long long max_iters;
+};
+void rs_loop_set_in(RsLoopArgs& a, const RsLoopIn& in) {
+  a.in_set = 1;
+  a.in_sigma = in.sigma; a.in_gtol = in.gtol; a.in_fprec = in.fprec; a.in_normC = in.normC; a.in_normb = in.normb;
+  a.in_grel = in.grel; a.in_prel = in.prel; a.in_max_iters = in.max_iters;
+}
+int enq_resident_loop(S* s, double time_budget_s, bool refresh_P, bool pre_lambda = false, bool pre_clear_fg = false,
+                      const RsLoopIn* in = nullptr) {
+  RsLoopArgs a = rs_loop_args(s, time_budget_s, refresh_P, pre_lambda, pre_clear_fg);
+  if (in) rs_loop_set_in(a, *in);
   const size_t lds = rs_loop_lds(s);
   LV_DISPATCH(({ RS_SET_ATTR((k_rs_loop<LPR, VEC, 4>)); k_rs_loop<LPR, VEC, 4><<<1, SDPLR_RS_NT, lds, s->stream>>>(a); }))
   HIPCK(s, hipGetLastError());
@@ -2559,10 +2597,10 @@ int enq_resident_loop(S* s, double time_budget_s, bool refresh_P, bool pre_lambd
 // launch + wait + the host-side bookkeeping of one resident loop (the control block has been pushed by the caller);
 // pre_lambda / pre_clear_fg: the head of a major iteration rides the same launch (sdplr_hip_major_iteration)
 int run_resident_loop(S* s, double time_budget_s, bool pre_lambda, bool pre_clear_fg, double* Lio, double* gnio, double* pnio,
-                      double* last_alpha, int64_t* iters, int32_t* exit_reason) {
+                      double* last_alpha, int64_t* iters, int32_t* exit_reason, const RsLoopIn* in = nullptr) {
   static const int64_t refresh_iters = getenv("SDPLR_HIP_P_REFRESH_ITERS") ? atoll(getenv("SDPLR_HIP_P_REFRESH_ITERS")) : 256;
   const bool refresh = pre_clear_fg || !s->P_valid || s->P_age >= refresh_iters;   // (fg! rebuilds P = A_g·R itself)
-  int rc = enq_resident_loop(s, time_budget_s, refresh, pre_lambda, pre_clear_fg);
+  int rc = enq_resident_loop(s, time_budget_s, refresh, pre_lambda, pre_clear_fg, in);
   if (rc) return rc;
   s->P_valid = true;
   if (refresh) s->P_age = 0;
@@ -2721,7 +2759,7 @@ void enq_lz_step(S* s, double* uprev, double* u, double* t) {
 
 // the structured resident Lanczos (k_rs_lanczos_ell); dual: with copy2y in front and ⟨y, b⟩ + the tridiagonal's smallest
 // eigenvalue behind it — the whole of dual_obj (src/coreop.jl:376-415) in one launch
-int enq_lanczos_ell(S* s, int64_t q, bool dual) {
+RsLzEllArgs rs_lz_ell_args(S* s, int64_t q, bool dual) {
   const int64_t n = s->n;
   RsLzEllArgs a{};
   a.n = (int)n; a.q = (int)q;
@@ -2730,13 +2768,24 @@ int enq_lanczos_ell(S* s, int64_t q, bool dual) {
   a.alpha_out = s->lz_alpha; a.beta_out = s->lz_beta; a.c = s->ctrl;
   a.dual = dual ? 1 : 0; a.m = (int)s->m; a.y_rw = s->y;
   a.lam = s->lambda; a.lam_ub = s->lambda_ub; a.pv_raw = s->pv_raw; a.b = s->b;
-  const size_t base = (size_t)4 * n * sizeof(double), packed = s->rs_ell_pair_lines * 64 * sizeof(unsigned);
-  if (s->rs_ell.val == nullptr && base + packed <= RS_LDS_MAX && getenv("SDPLR_HIP_RESIDENT_LZ_STREAM") == nullptr) {
+  return a;
+}
+// dynamic LDS of the run: v, v_pre, Av, the diagonal — and, with unit weights and room for it, the packed columns
+size_t rs_lz_ell_lds(const S* s, bool* ell_in_lds) {
+  const size_t base = (size_t)4 * s->n * sizeof(double), packed = s->rs_ell_pair_lines * 64 * sizeof(unsigned);
+  *ell_in_lds = s->rs_ell.val == nullptr && base + packed <= RS_LDS_MAX && getenv("SDPLR_HIP_RESIDENT_LZ_STREAM") == nullptr;
+  return *ell_in_lds ? base + packed : base;
+}
+int enq_lanczos_ell(S* s, int64_t q, bool dual) {
+  const RsLzEllArgs a = rs_lz_ell_args(s, q, dual);
+  bool in_lds = false;
+  const size_t lds = rs_lz_ell_lds(s, &in_lds);
+  if (in_lds) {
     RS_SET_ATTR(k_rs_lanczos_ell<true>);
-    k_rs_lanczos_ell<true><<<1, SDPLR_RS_NT, base + packed, s->stream>>>(a);
+    k_rs_lanczos_ell<true><<<1, SDPLR_RS_NT, lds, s->stream>>>(a);
   } else {
     RS_SET_ATTR(k_rs_lanczos_ell<false>);
-    k_rs_lanczos_ell<false><<<1, SDPLR_RS_NT, base, s->stream>>>(a);
+    k_rs_lanczos_ell<false><<<1, SDPLR_RS_NT, lds, s->stream>>>(a);
   }
   HIPCK(s, hipGetLastError());
   s->st_rs_lz++;
@@ -2930,9 +2979,10 @@ int32_t sdplr_hip_At_right_device(S* s, const double* x, double* yd, int64_t k) 
 
 int32_t sdplr_hip_get_stats(const S* s, int64_t* out, int32_t cap, int32_t* n_written) {
   if (!s || !out || cap < 0) return SDPLR_ERR_INVALID_ARG;
-  const int64_t v[11] = {s->st_captures, s->st_capture_failed, s->st_capture_skipped, s->st_graph_batches,
-                         s->st_eager_batches, s->st_lz_graph, s->st_lz_eager, s->st_iters, s->st_rs_loops, s->st_rs_lz, s->st_rs_fg};
-  const int32_t k = std::min<int32_t>(cap, 11);
+  const int64_t v[12] = {s->st_captures, s->st_capture_failed, s->st_capture_skipped, s->st_graph_batches,
+                         s->st_eager_batches, s->st_lz_graph, s->st_lz_eager, s->st_iters, s->st_rs_loops, s->st_rs_lz, s->st_rs_fg,
+                         s->st_rs_shared};
+  const int32_t k = std::min<int32_t>(cap, 12);
   for (int32_t i = 0; i < k; i++) out[i] = v[i];
   if (n_written) *n_written = k;
   return SDPLR_OK;
@@ -2958,6 +3008,16 @@ int32_t sdplr_hip_g(S* s) {
 }  // extern "C"
 
 namespace {
+RsFgArgs rs_fg_args(S* s) {
+  RsFgArgs a{};
+  a.n = (int)s->n; a.m = (int)s->m; a.r = (int)s->r;
+  a.gid_g = s->ff.gid_g; a.row_k = s->rs_row_k; a.row_v = s->rs_row_v; a.E = s->rs_ell;
+  a.R = aslot(s->arena, AS_R); a.G = aslot(s->arena, AS_G); a.P = aslot(s->arena, 3 + 2 * (int)s->h);
+  a.y = s->y; a.pv_raw = s->pv_raw; a.pv = s->pv;
+  a.lam = s->lambda; a.lam_ub = s->lambda_ub; a.lb = s->pv_lb; a.b = s->b;
+  a.c = s->ctrl;
+  return a;
+}
 int set_norm_params(S* s, double normC, double normb, int grel, int prel) {
   int rc = pull(s);
   if (rc) return rc;
@@ -2974,13 +3034,7 @@ int32_t sdplr_hip_fg(S* s, double normC, double normb, int32_t grel, int32_t pre
   int rc = set_norm_params(s, normC, normb, grel, prel);
   if (rc) return rc;
   if (rs_fg_applies(s)) {   // resident route (k_resident.h): one launch; P = A_g·R stays for the loop that follows
-    RsFgArgs a{};
-    a.n = (int)s->n; a.m = (int)s->m; a.r = (int)s->r;
-    a.gid_g = s->ff.gid_g; a.row_k = s->rs_row_k; a.row_v = s->rs_row_v; a.E = s->rs_ell;
-    a.R = aslot(s->arena, AS_R); a.G = aslot(s->arena, AS_G); a.P = aslot(s->arena, 3 + 2 * (int)s->h);
-    a.y = s->y; a.pv_raw = s->pv_raw; a.pv = s->pv;
-    a.lam = s->lambda; a.lam_ub = s->lambda_ub; a.lb = s->pv_lb; a.b = s->b;
-    a.c = s->ctrl;
+    const RsFgArgs a = rs_fg_args(s);
     const size_t lds = rs_loop_lds(s);
     LV_DISPATCH(({ RS_SET_ATTR((k_rs_fg<LPR, VEC>)); k_rs_fg<LPR, VEC><<<1, SDPLR_RS_NT, lds, s->stream>>>(a); }))
     HIPCK(s, hipGetLastError());
@@ -3139,7 +3193,7 @@ int32_t sdplr_hip_inner_loop(S* s, double normC, double normb, int32_t grel, int
   if (!Lio || !gnio || !pnio || max_local_iters < 1) return fail(s, SDPLR_ERR_INVALID_ARG, "inner_loop: bad args");
   const bool gram_work = s->h > 0 && (s->gram_dirty || s->ynext_pending || s->sg_stale);
   ensure_gram(s);
-  int rc = tile_lds_attr(s);
+  int rc = rs_loop_applies(s, use_armijo) ? SDPLR_OK : tile_lds_attr(s);
   if (rc) return rc;
   s->hc_valid = hc_was_valid && !gram_work;   // (nothing has been enqueued since the shadow was last in step)
   if ((rc = pull_if_stale(s))) return rc;
@@ -3342,25 +3396,16 @@ int32_t sdplr_hip_major_iteration(S* s, double normC, double normb, int32_t grel
   bool resident = false;
   {
     ApiShared api_guard;
-    const bool hc_was_valid = s->finalized && s->hc_valid;
     NEED_FINAL_RW(s);
     resident = rs_loop_applies(s, use_armijo) && rs_fg_applies(s);
     if (resident) {
-      const bool was_valid = hc_was_valid;
-      s->hc_valid = was_valid;
-      int rc = pull_if_stale(s);   // (every entry point returns with its stream drained)
-      if (rc) return rc;
-      s->hc_valid = false;
-      DevCtrl* c = s->hc;
-      c->sigma = sigma;
-      c->done = 0; c->exit_reason = 0; c->err = 0; c->use_armijo = use_armijo;
-      c->iters = 0; c->max_iters = max_local_iters; c->reldelta_exit = 0; c->norms_pending = 0; c->pv2_extra = 0.0;
-      c->cur_gtol = cur_gtol; c->fprec_eps = fprec_eps; c->normC = normC; c->normb = normb;
-      c->grel = grel; c->prel = prel;
-      c->alpha = 0.0; c->alpha_max = 1.0;
-      if ((rc = push(s))) return rc;
+      // var.σ[], the loop's parameters and its counters ride the launch's arguments (the kernel writes them into its copy
+      // of the control block after the λ update has read the σ it found there): no pull / push of the block in front
+      RsLoopIn in{};
+      in.sigma = sigma; in.gtol = cur_gtol; in.fprec = fprec_eps; in.normC = normC; in.normb = normb;
+      in.grel = grel; in.prel = prel; in.max_iters = max_local_iters;
       s->sg_stale = s->ynext_pending = false;   // (cleared history: see sdplr_hip_lbfgs_clear)
-      return run_resident_loop(s, time_budget_s, update_lambda != 0, true, L, gn, pn, last_alpha, iters, exit_reason);
+      return run_resident_loop(s, time_budget_s, update_lambda != 0, true, L, gn, pn, last_alpha, iters, exit_reason, &in);
     }
   }
   int32_t rc;
@@ -3663,6 +3708,307 @@ int32_t sdplr_hip_profile_get(S* s, int32_t idx, char* name, int32_t cap, int64_
   if (name && cap > 0) snprintf(name, cap, "%s", s->prof_names[idx].c_str());
   if (launches) *launches = s->prof[idx].launches;
   if (ms) *ms = s->prof[idx].ms;
+  return SDPLR_OK;
+}
+
+}  // extern "C"
+
+// ---- batches of small instances in lockstep (include/sdplr_hip.h) -----------------------------------------------------
+// The resident instances of a batch that share a kernel shape go out as ONE launch, block b ↔ instance b: an argument table
+// up (one copy from a pinned block), one grid, a result table back (one copy), one wait.  What the single-instance entry
+// points write into / read out of each control block around their launch rides the table rows instead, so no per-instance
+// HIP call is made at all.  Everything else in the batch is served by the single-instance entry point.
+namespace {
+struct BatchBuf {   // one pinned block + one device block of ARENA_CHUNK bytes + a blocking event, from the pools
+  char* host = nullptr;
+  char* dev = nullptr;
+  hipEvent_t ev = nullptr;
+  hipError_t init() {
+    hipError_t e = pool_host_chunk((void**)&host);
+    if (e == hipSuccess) e = pool_malloc((void**)&dev, ARENA_CHUNK);
+    if (e == hipSuccess) e = pool_event(&ev);
+    return e;
+  }
+  ~BatchBuf() {
+    if (host) pool_host_chunk_free(host);
+    if (dev) pool_free(dev);
+    if (ev) pool_event_free(ev);
+  }
+};
+constexpr size_t BATCH_ALIGN = 256;
+size_t batch_up(size_t x) { return (x + BATCH_ALIGN - 1) & ~(BATCH_ALIGN - 1); }
+using ShapeKey = std::pair<int, int>;   // (LPR, VEC) — with ELL_LDS folded into the first for the Lanczos kernels
+
+bool batch_handles_distinct(const std::vector<const S*>& hs) {
+  std::vector<const S*> v;
+  for (const S* s : hs) if (s) v.push_back(s);
+  std::sort(v.begin(), v.end());
+  return std::adjacent_find(v.begin(), v.end()) == v.end();
+}
+// table up → launch → results back → wait; `launch` enqueues the grid on `st`
+template <typename Launch>
+int batch_round_trip(S* s0, BatchBuf& bb, size_t table_bytes, size_t res_off, size_t res_bytes, Launch&& launch) {
+  hipStream_t st = s0->stream;
+  HIPCK(s0, hipMemcpyAsync(bb.dev, bb.host, table_bytes, hipMemcpyHostToDevice, st));
+  launch(st);
+  HIPCK(s0, hipGetLastError());
+  HIPCK(s0, hipMemcpyAsync(bb.host + res_off, bb.dev + res_off, res_bytes, hipMemcpyDeviceToHost, st));
+  HIPCK(s0, hipEventRecord(bb.ev, st));
+  HIPCK(s0, hipEventSynchronize(bb.ev));
+  return SDPLR_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int32_t sdplr_hip_batch_fg(int32_t count, sdplr_hip_fg_item* it) {
+  if (count < 0 || (count > 0 && !it)) return fail(nullptr, SDPLR_ERR_INVALID_ARG, "batch_fg: bad args");
+  std::vector<int> single;
+  {
+    ApiShared api_guard;
+    std::vector<const S*> hs;
+    for (int i = 0; i < count; i++) hs.push_back(it[i].s);
+    if (!batch_handles_distinct(hs)) return fail(nullptr, SDPLR_ERR_INVALID_ARG, "batch_fg: a handle appears twice");
+    std::map<ShapeKey, std::vector<int>> groups;
+    for (int i = 0; i < count; i++) {
+      S* s = it[i].s;
+      it[i].status = SDPLR_OK;
+      if (s && s->finalized && rs_fg_applies(s)) groups[{s->LPR, s->VEC}].push_back(i);
+      else single.push_back(i);
+    }
+    const size_t max_rows = ARENA_CHUNK / (batch_up(sizeof(RsFgArgs)) + 64);
+    for (auto& g : groups) {
+      std::vector<int>& idx = g.second;
+      if (idx.size() < 2) { single.insert(single.end(), idx.begin(), idx.end()); continue; }
+      for (size_t lo = 0; lo < idx.size(); lo += max_rows) {
+        const size_t nb = std::min(max_rows, idx.size() - lo);
+        S* s = it[idx[lo]].s;   // (the shape all rows share: LV_DISPATCH reads s->LPR / s->VEC)
+        BatchBuf bb;
+        if (bb.init() != hipSuccess) return fail(s, SDPLR_ERR_ALLOC, "batch_fg: staging blocks");
+        RsFgArgs* tab = reinterpret_cast<RsFgArgs*>(bb.host);
+        const size_t res_off = batch_up(nb * sizeof(RsFgArgs));
+        size_t lds = 0;
+        for (size_t k = 0; k < nb; k++) {
+          const sdplr_hip_fg_item& q = it[idx[lo + k]];
+          S* sk = q.s;
+          sk->hc_valid = false;
+          RsFgArgs a = rs_fg_args(sk);
+          a.in_set = 1; a.in_normC = q.normC; a.in_normb = q.normb; a.in_grel = q.gtol_relative; a.in_prel = q.ptol_relative;
+          a.out = reinterpret_cast<double*>(bb.dev + res_off) + 4 * k;
+          tab[k] = a;
+          lds = std::max(lds, rs_loop_lds(sk));
+        }
+        const RsFgArgs* dtab = reinterpret_cast<const RsFgArgs*>(bb.dev);
+        int rc = batch_round_trip(s, bb, nb * sizeof(RsFgArgs), res_off, nb * 4 * sizeof(double), [&](hipStream_t st) {
+          LV_DISPATCH(({ RS_SET_ATTR((k_rs_fg_batch<LPR, VEC>)); k_rs_fg_batch<LPR, VEC><<<(int)nb, SDPLR_RS_NT, lds, st>>>(dtab); }))
+        });
+        const double* res = reinterpret_cast<const double*>(bb.host + res_off);
+        for (size_t k = 0; k < nb; k++) {
+          sdplr_hip_fg_item& q = it[idx[lo + k]];
+          S* sk = q.s;
+          q.status = rc;
+          if (rc) { if (sk != s) sk->err = s->err; continue; }
+          sk->P_valid = true; sk->P_age = 0; sk->S_stale = true; sk->S_from_y = true; sk->sg_stale = true;
+          sk->st_rs_fg++; sk->st_rs_shared++;
+          q.lagrangian = res[4 * k]; q.grad_norm = res[4 * k + 1]; q.primal_vio_norm = res[4 * k + 2]; q.obj = res[4 * k + 3];
+        }
+      }
+    }
+  }
+  for (int i : single) {
+    sdplr_hip_fg_item& q = it[i];
+    q.status = sdplr_hip_fg(q.s, q.normC, q.normb, q.gtol_relative, q.ptol_relative, &q.lagrangian, &q.grad_norm, &q.primal_vio_norm);
+    if (!q.status) q.status = sdplr_hip_get_scalar(q.s, SDPLR_S_OBJ, &q.obj);
+  }
+  for (int i = 0; i < count; i++) if (it[i].status) return it[i].status;
+  return SDPLR_OK;
+}
+
+int32_t sdplr_hip_batch_major_iteration(int32_t count, sdplr_hip_major_item* it) {
+  if (count < 0 || (count > 0 && !it)) return fail(nullptr, SDPLR_ERR_INVALID_ARG, "batch_major_iteration: bad args");
+  std::vector<int> single;
+  {
+    ApiShared api_guard;
+    std::vector<const S*> hs;
+    for (int i = 0; i < count; i++) hs.push_back(it[i].s);
+    if (!batch_handles_distinct(hs)) return fail(nullptr, SDPLR_ERR_INVALID_ARG, "batch_major_iteration: a handle appears twice");
+    std::map<ShapeKey, std::vector<int>> groups;
+    for (int i = 0; i < count; i++) {
+      S* s = it[i].s;
+      it[i].status = SDPLR_OK;
+      if (s && s->finalized && it[i].max_local_iters >= 1 && rs_loop_applies(s, it[i].use_armijo) && rs_fg_applies(s))
+        groups[{s->LPR, s->VEC}].push_back(i);
+      else
+        single.push_back(i);
+    }
+    const size_t max_rows = ARENA_CHUNK / (batch_up(sizeof(RsLoopArgs)) + 128);
+    for (auto& g : groups) {
+      std::vector<int>& idx = g.second;
+      if (idx.size() < 2) { single.insert(single.end(), idx.begin(), idx.end()); continue; }
+      for (size_t lo = 0; lo < idx.size(); lo += max_rows) {
+        const size_t nb = std::min(max_rows, idx.size() - lo);
+        S* s = it[idx[lo]].s;
+        BatchBuf bb;
+        if (bb.init() != hipSuccess) return fail(s, SDPLR_ERR_ALLOC, "batch_major_iteration: staging blocks");
+        RsLoopArgs* tab = reinterpret_cast<RsLoopArgs*>(bb.host);
+        const size_t res_off = batch_up(nb * sizeof(RsLoopArgs));
+        size_t lds = 0;
+        for (size_t k = 0; k < nb; k++) {
+          const sdplr_hip_major_item& q = it[idx[lo + k]];
+          S* sk = q.s;
+          sk->hc_valid = false;
+          sk->sg_stale = sk->ynext_pending = false;   // (cleared history: see sdplr_hip_lbfgs_clear)
+          RsLoopArgs a = rs_loop_args(sk, q.time_budget_s, true, q.update_lambda != 0, true);
+          RsLoopIn in{};
+          in.sigma = q.sigma; in.gtol = q.cur_gtol; in.fprec = q.fprec_eps; in.normC = q.normC; in.normb = q.normb;
+          in.grel = q.gtol_relative; in.prel = q.ptol_relative; in.max_iters = q.max_local_iters;
+          rs_loop_set_in(a, in);
+          a.out = reinterpret_cast<double*>(bb.dev + res_off) + 8 * k;
+          tab[k] = a;
+          lds = std::max(lds, rs_loop_lds(sk));
+        }
+        const RsLoopArgs* dtab = reinterpret_cast<const RsLoopArgs*>(bb.dev);
+        int rc = batch_round_trip(s, bb, nb * sizeof(RsLoopArgs), res_off, nb * 8 * sizeof(double), [&](hipStream_t st) {
+          LV_DISPATCH(({ RS_SET_ATTR((k_rs_loop_batch<LPR, VEC, 4>)); k_rs_loop_batch<LPR, VEC, 4><<<(int)nb, SDPLR_RS_NT, lds, st>>>(dtab); }))
+        });
+        const double* res = reinterpret_cast<const double*>(bb.host + res_off);
+        for (size_t k = 0; k < nb; k++) {
+          sdplr_hip_major_item& q = it[idx[lo + k]];
+          S* sk = q.s;
+          q.status = rc;
+          if (rc) { if (sk != s) sk->err = s->err; continue; }
+          const double* o = res + 8 * k;
+          const int why = (int)o[6], err = (int)o[7];
+          const int64_t iters = (int64_t)o[5];
+          // (the bookkeeping of run_resident_loop)
+          sk->P_valid = true; sk->P_age = iters; sk->S_stale = true; sk->S_from_y = true;
+          sk->st_rs_fg++; sk->st_rs_loops++; sk->st_rs_shared++; sk->gram_dirty = false;
+          sk->sg_stale = (why == EXIT_RELDELTA);
+          sk->ynext_pending = (why == EXIT_RELDELTA) && sk->h > 0;
+          if (err == SDPLR_ERR_NOT_DESCENT) {
+            int r2 = pull(sk);
+            if (!r2) { sk->hc->err = 0; sk->hc->done = 0; r2 = push(sk); }
+            q.status = r2 ? r2 : fail(sk, SDPLR_ERR_NOT_DESCENT, "Error: cubic[1] should be less than 0.");
+            continue;
+          }
+          sk->st_iters += iters;
+          q.lagrangian = o[0]; q.grad_norm = o[1]; q.primal_vio_norm = o[2]; q.last_alpha = o[3]; q.obj = o[4];
+          q.iters_done = iters; q.exit_reason = why;
+        }
+      }
+    }
+  }
+  for (int i : single) {
+    sdplr_hip_major_item& q = it[i];
+    q.status = sdplr_hip_major_iteration(q.s, q.normC, q.normb, q.gtol_relative, q.ptol_relative, q.use_armijo, q.update_lambda,
+                                         q.sigma, q.cur_gtol, q.fprec_eps, q.max_local_iters, q.time_budget_s, &q.lagrangian,
+                                         &q.grad_norm, &q.primal_vio_norm, &q.last_alpha, &q.iters_done, &q.exit_reason);
+    if (!q.status) q.status = sdplr_hip_get_scalar(q.s, SDPLR_S_OBJ, &q.obj);
+  }
+  for (int i = 0; i < count; i++) if (it[i].status) return it[i].status;
+  return SDPLR_OK;
+}
+
+int32_t sdplr_hip_batch_dual_obj(int32_t count, sdplr_hip_dual_item* it) {
+  if (count < 0 || (count > 0 && !it)) return fail(nullptr, SDPLR_ERR_INVALID_ARG, "batch_dual_obj: bad args");
+  std::vector<int> single;
+  {
+    ApiShared api_guard;
+    std::vector<const S*> hs;
+    for (int i = 0; i < count; i++) hs.push_back(it[i].s);
+    if (!batch_handles_distinct(hs)) return fail(nullptr, SDPLR_ERR_INVALID_ARG, "batch_dual_obj: a handle appears twice");
+    const bool fused_ok = getenv("SDPLR_HIP_NO_FUSED_DUAL") == nullptr;
+    std::map<int, std::vector<int>> groups;   // keyed by "the packed columns fit in LDS" (the kernel's template flag)
+    for (int i = 0; i < count; i++) {
+      S* s = it[i].s;
+      it[i].status = SDPLR_OK;
+      if (s && s->finalized && it[i].v0 && fused_ok && s->n >= 2 && rs_lanczos_ell_applies(s)) {
+        bool in_lds = false;
+        (void)rs_lz_ell_lds(s, &in_lds);
+        groups[in_lds ? 1 : 0].push_back(i);
+      } else {
+        single.push_back(i);
+      }
+    }
+    for (auto& g : groups) {
+      std::vector<int>& idx = g.second;
+      if (idx.size() < 2) { single.insert(single.end(), idx.begin(), idx.end()); continue; }
+      size_t lo = 0;
+      while (lo < idx.size()) {
+        // rows [lo, hi): table + result rows + the start vectors fit one staging block
+        size_t hi = lo, bytes = 0;
+        while (hi < idx.size()) {
+          const size_t add = batch_up(sizeof(RsLzEllArgs)) + 64 + batch_up((size_t)it[idx[hi]].s->n * sizeof(double));
+          if (hi > lo && bytes + add + 2 * BATCH_ALIGN > ARENA_CHUNK) break;
+          bytes += add;
+          hi++;
+        }
+        const size_t nb = hi - lo;
+        S* s = it[idx[lo]].s;
+        if (bytes + 2 * BATCH_ALIGN > ARENA_CHUNK) { single.push_back(idx[lo]); lo = hi; continue; }   // (one instance too large for the block)
+        BatchBuf bb;
+        if (bb.init() != hipSuccess) return fail(s, SDPLR_ERR_ALLOC, "batch_dual_obj: staging blocks");
+        RsLzEllArgs* tab = reinterpret_cast<RsLzEllArgs*>(bb.host);
+        size_t v0_off = batch_up(nb * sizeof(RsLzEllArgs));
+        size_t lds = 0;
+        int rc = SDPLR_OK;
+        std::vector<size_t> v0_at(nb);
+        for (size_t k = 0; k < nb && !rc; k++) {   // the start vectors, behind the table: they travel in the same copy
+          S* sk = it[idx[lo + k]].s;
+          v0_at[k] = v0_off;
+          memcpy(bb.host + v0_off, it[idx[lo + k]].v0, (size_t)sk->n * sizeof(double));
+          v0_off += batch_up((size_t)sk->n * sizeof(double));
+        }
+        const size_t res_off = v0_off;
+        for (size_t k = 0; k < nb && !rc; k++) {
+          const sdplr_hip_dual_item& q = it[idx[lo + k]];
+          S* sk = q.s;
+          sk->hc_valid = false;
+          const double itd = (double)std::max<int64_t>(q.iter, 100);
+          int64_t steps = (int64_t)(2 * std::ceil(std::pow(itd, 0.5) * std::log((double)sk->n)));   // src/coreop.jl:402
+          steps = std::min<int64_t>(steps, sk->n - 1);                                              // :465
+          if ((rc = ensure_lz_capacity(sk, steps))) { if (sk != s) s->err = sk->err; break; }
+          RsLzEllArgs a = rs_lz_ell_args(sk, steps, true);
+          a.v0 = reinterpret_cast<const double*>(bb.dev + v0_at[k]);
+          a.out = reinterpret_cast<double*>(bb.dev + res_off) + 4 * k;
+          tab[k] = a;
+          bool in_lds = false;
+          lds = std::max(lds, rs_lz_ell_lds(sk, &in_lds));
+        }
+        if (!rc) {
+          const RsLzEllArgs* dtab = reinterpret_cast<const RsLzEllArgs*>(bb.dev);
+          const bool in_lds = g.first == 1;
+          rc = batch_round_trip(s, bb, res_off, res_off, nb * 4 * sizeof(double), [&](hipStream_t st) {
+            if (in_lds) {
+              RS_SET_ATTR(k_rs_lanczos_ell_batch<true>);
+              k_rs_lanczos_ell_batch<true><<<(int)nb, SDPLR_RS_NT, lds, st>>>(dtab);
+            } else {
+              RS_SET_ATTR(k_rs_lanczos_ell_batch<false>);
+              k_rs_lanczos_ell_batch<false><<<(int)nb, SDPLR_RS_NT, lds, st>>>(dtab);
+            }
+          });
+        }
+        const double* res = reinterpret_cast<const double*>(bb.host + res_off);
+        for (size_t k = 0; k < nb; k++) {
+          sdplr_hip_dual_item& q = it[idx[lo + k]];
+          S* sk = q.s;
+          q.status = rc;
+          if (rc) { if (sk != s) sk->err = s->err; continue; }
+          sk->S_stale = true; sk->S_from_y = true;
+          sk->st_rs_lz++; sk->st_rs_shared++;
+          const double ev = res[4 * k], yb = res[4 * k + 1];
+          q.mineig = ev;
+          q.dual_value = -yb + q.trace_bound * std::min(ev, 0.0);                                   // :412
+        }
+        lo = hi;
+      }
+    }
+  }
+  for (int i : single) {
+    sdplr_hip_dual_item& q = it[i];
+    q.status = sdplr_hip_dual_obj(q.s, q.trace_bound, q.iter, q.v0, &q.dual_value, &q.mineig);
+  }
+  for (int i = 0; i < count; i++) if (it[i].status) return it[i].status;
   return SDPLR_OK;
 }
 

@@ -127,9 +127,42 @@ def _print_row(config, majoriter, localiter, iter_, L, obj, σ, gtol, ptol, gnor
               f"|pinf|={pnorm:.3e} gap={gap:.3e} dobj={dobj: .6e}", file=sys.stdout, flush=True)
 
 
+# The four device-side steps of _sdplr that a driver may serve for MANY instances in one library call (include/sdplr_hip.h,
+# "lockstep"): the stepper below yields them as requests instead of calling them, so that the same restatement of the
+# control flow runs one solve (``_sdplr``: every request is served at once on the instance's own handle) or a batch side by
+# side (``batch.solve_lockstep``: the same request of all instances is ONE call, one kernel launch for the whole batch).
+REQ_FG, REQ_MAJOR, REQ_INNER, REQ_DUAL = "fg", "major_iteration", "inner_loop", "dual_obj"
+
+
+def serve(var: DeviceSolver, req: tuple) -> tuple:
+    """One request of the stepper on one handle, through the single-instance entry points."""
+    kind, args = req[0], req[1:]
+    if kind == REQ_FG:
+        return var.fg(*args) + (var.obj,)
+    if kind == REQ_MAJOR:
+        return var.major_iteration(*args) + (var.obj,)
+    if kind == REQ_INNER:
+        return var.inner_loop(*args) + (var.obj,)
+    if kind == REQ_DUAL:
+        return var.dual_obj(*args)
+    raise ValueError(kind)
+
+
 def _sdplr(data: SDPData, var: DeviceSolver, config: BurerMonteiroConfig,
            native_inner_loop: bool = True) -> dict:
-    """``_sdplr`` (src/sdplr.jl:140-449).  ``var`` plays the role of (var, aux, lbfgshis, dirt)."""
+    """``_sdplr`` (src/sdplr.jl:140-449) on one handle."""
+    steps = sdplr_steps(data, var, config, native_inner_loop=native_inner_loop)
+    try:
+        req = next(steps)
+        while True:
+            req = steps.send(serve(var, req))
+    except StopIteration as done:
+        return done.value
+
+
+def sdplr_steps(data: SDPData, var: DeviceSolver, config: BurerMonteiroConfig, native_inner_loop: bool = True):
+    """``_sdplr`` (src/sdplr.jl:140-449) as a generator: yields (REQ_*, args…), receives what ``serve`` returns, and
+    returns the result Dict.  ``var`` plays the role of (var, aux, lbfgshis, dirt)."""
     n, m = data.n, data.m
     starttime = time.time()
     lastprint = starttime
@@ -141,10 +174,18 @@ def _sdplr(data: SDPData, var: DeviceSolver, config: BurerMonteiroConfig,
     grel = config.gtol_mode == "relative"
     prel = config.ptol_mode == "relative"
 
-    σ = var.σ
+    σ = σ_now = var.σ                           # (σ_now: var.σ[] as the device holds it — only this function writes it)
     cur_gtol = max(1.0 / σ, config.gtol)        # :165-169
     cur_ptol = max(1.0 / σ ** 0.1, config.ptol)
-    L_val, grad_norm, primal_vio_norm = var.fg(normC, normb, grel, prel)  # :170
+    # The tail of a major iteration — λ update or σ increase (:358-369), lbfgs_clear! (:384), fg! (:389) — is device work
+    # with no host decision in between, and so is the while loop it feeds: with the native loop the four travel as ONE
+    # call (``major_iteration``; one kernel launch on small instances).  `pending` holds a tail not yet sent.  The fg! of
+    # :170 and the first pass of the loop are such a call too: no λ update, σ as it stands, and lbfgs_clear! on the fresh
+    # history of lbfgs_init (src/sdplr.jl:163) changes nothing.
+    pending = (False, σ) if native_inner_loop else None
+    L_val = grad_norm = primal_vio_norm = obj = math.nan
+    if pending is None:
+        L_val, grad_norm, primal_vio_norm, obj = yield (REQ_FG, normC, normb, grel, prel)  # :170
 
     iter_ = 0
     majoriter = 0
@@ -157,10 +198,6 @@ def _sdplr(data: SDPData, var: DeviceSolver, config: BurerMonteiroConfig,
     best_λ = var.λ.copy()
     rng = _rng(config)
 
-    # The tail of a major iteration — λ update or σ increase (:358-369), lbfgs_clear! (:384), fg! (:389) — is device work
-    # with no host decision in between, and so is the while loop it feeds: with the native loop the four travel as ONE
-    # call (``major_iteration``; one kernel launch on small instances).  `pending` holds a tail not yet sent.
-    pending = None
     schedule = []   # per major iteration: (majoriter, inner iterations, σ, η, ω, rank) — what printintermediate shows (src/myprint.jl:17-58)
     for _ in range(config.maxmajoriter):        # :185
         majoriter += 1
@@ -169,14 +206,15 @@ def _sdplr(data: SDPData, var: DeviceSolver, config: BurerMonteiroConfig,
             budget = max(config.maxiter + 1 - iter_, 1)
             tleft = config.maxtime - (time.time() - starttime)
             if pending is not None:
-                L_val, grad_norm, primal_vio_norm, _α, localiter, _why = var.major_iteration(
-                    normC, normb, grel, prel, use_armijo, pending[0], pending[1], cur_gtol, config.fprec * EPS,
-                    budget, max(tleft, 1e-9))
+                L_val, grad_norm, primal_vio_norm, _α, localiter, _why, obj = yield (
+                    REQ_MAJOR, normC, normb, grel, prel, use_armijo, pending[0], pending[1], cur_gtol,
+                    config.fprec * EPS, budget, max(tleft, 1e-9))
+                σ_now = pending[1]
                 pending = None
                 iter_ += localiter
             elif grad_norm > cur_gtol:
-                L_val, grad_norm, primal_vio_norm, _α, localiter, _why = var.inner_loop(
-                    normC, normb, grel, prel, use_armijo, cur_gtol, config.fprec * EPS, budget,
+                L_val, grad_norm, primal_vio_norm, _α, localiter, _why, obj = yield (
+                    REQ_INNER, normC, normb, grel, prel, use_armijo, cur_gtol, config.fprec * EPS, budget,
                     max(tleft, 1e-9), L_val, grad_norm, primal_vio_norm)
                 iter_ += localiter
         else:
@@ -207,11 +245,12 @@ def _sdplr(data: SDPData, var: DeviceSolver, config: BurerMonteiroConfig,
                                max_dual_value)
                 if current_time - starttime > config.maxtime or iter_ > config.maxiter:
                     break                                       # :272-277
+            obj = var.obj
 
         current_time = time.time()
-        _print_row(config, majoriter, localiter, iter_, L_val, var.obj, var.σ, cur_gtol, cur_ptol,
+        _print_row(config, majoriter, localiter, iter_, L_val, obj, σ_now, cur_gtol, cur_ptol,
                    grad_norm, primal_vio_norm, min_duality_gap, max_dual_value)
-        schedule.append((majoriter, int(localiter), float(var.σ), float(cur_gtol), float(cur_ptol), int(var.r)))
+        schedule.append((majoriter, int(localiter), float(σ_now), float(cur_gtol), float(cur_ptol), int(var.r)))
         lastprint = current_time
         if current_time - starttime > config.maxtime:           # :298-301
             print("Warning: Time limit exceeded. Stop optimizing.", file=sys.stderr)
@@ -221,19 +260,18 @@ def _sdplr(data: SDPData, var: DeviceSolver, config: BurerMonteiroConfig,
             break
 
         rank_double = False
-        σ = var.σ
+        σ = σ_now
         if primal_vio_norm <= cur_ptol:                         # :310
             t0 = time.time()
             v0 = rng.standard_normal(n)                         # replaces randn, coreop.jl:473
             if config.eigval_highprecision:                     # coreop.jl:389-400
-                var.y = np.concatenate([-np.minimum(var.λ_ub, var.λ - var.σ * var.primal_vio_raw[:m]), [1.0]])
+                var.y = np.concatenate([-np.minimum(var.λ_ub, var.λ - σ_now * var.primal_vio_raw[:m]), [1.0]])
                 var.At_preprocess()
                 ev = SDP_S_eigval(var, 1, True, which="SA", ncv=min(100, n), tol=1e-6, maxiter=1000000,
                                   v0=v0)[0]
                 dual_value = float(-(var.y[:m] @ data.b) + config.prior_trace_bound * min(ev, 0.0))
             else:
-                dual_value, _ = var.dual_obj(config.prior_trace_bound, iter_, v0)     # :314
-            obj = var.obj
+                dual_value, _ = yield (REQ_DUAL, config.prior_trace_bound, iter_, v0)     # :314
             if dual_value > max_dual_value:                     # :324-327
                 best_λ = -var.y
                 max_dual_value = dual_value
@@ -273,12 +311,13 @@ def _sdplr(data: SDPData, var: DeviceSolver, config: BurerMonteiroConfig,
                 var.update_lambda()
             else:
                 var.σ = σ
+                σ_now = σ
 
         if rank_double:                                         # :373-382
             newr = min(barvinok_pataki(data.n, data.m), var.r * 2)    # coreop.jl:518-526
             var.reset_rank(newr)
             _load_point(var, data, newr, config)
-            σ = var.σ
+            σ = σ_now = var.σ
             cur_ptol = 1 / σ ** 0.1
             cur_gtol = 1 / σ
             min_duality_gap = 1e20
@@ -294,19 +333,19 @@ def _sdplr(data: SDPData, var: DeviceSolver, config: BurerMonteiroConfig,
         if fuse_tail:
             pending = (upd_λ, σ)                                # sent with the next pass of the while loop
         else:
-            L_val, grad_norm, primal_vio_norm = var.fg(normC, normb, grel, prel)
+            L_val, grad_norm, primal_vio_norm, obj = yield (REQ_FG, normC, normb, grel, prel)
         if majoriter == config.maxmajoriter:
             print("Warning: Major iteration limit exceeded. Stop optimizing.", file=sys.stderr)
 
-    L_val, grad_norm, primal_vio_norm = var.fg(normC, normb, grel, prel)   # :396
-    _print_row(config, majoriter, -1, iter_, L_val, var.obj, var.σ, cur_gtol, cur_ptol, grad_norm,
+    L_val, grad_norm, primal_vio_norm, obj = yield (REQ_FG, normC, normb, grel, prel)   # :396
+    _print_row(config, majoriter, -1, iter_, L_val, obj, σ_now, cur_gtol, cur_ptol, grad_norm,
                primal_vio_norm, min_duality_gap, max_dual_value)
     totaltime = time.time() - starttime
     DIMACS_errs = DIMACS_errors(data, var) if config.eval_DIMACS_errs else np.zeros(6)   # :419-425
     Rt = var.Rt
     return {                                                    # :426-448
-        "Rt": Rt, "lambda": best_λ, "Rt0": Rt0, "lambda0": λ0, "sigma": var.σ,
-        "grad_norm": grad_norm, "primal_vio": primal_vio_norm, "obj": var.obj,
+        "Rt": Rt, "lambda": best_λ, "Rt0": Rt0, "lambda0": λ0, "sigma": σ_now,
+        "grad_norm": grad_norm, "primal_vio": primal_vio_norm, "obj": obj,
         "max_dual_value": max_dual_value, "min_duality_gap": min_duality_gap,
         "totaltime": totaltime, "dual_time": dual_time, "primaltime": totaltime - dual_time,
         "iter": iter_, "majoriter": majoriter, "DIMACS_errs": DIMACS_errs, "ptol": config.ptol,

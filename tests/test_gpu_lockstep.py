@@ -1,0 +1,137 @@
+"""GPU tests of the lockstep batch calls (include/sdplr_hip.h: sdplr_hip_batch_fg / _major_iteration / _dual_obj): the
+resident instances of a batch go out as ONE launch, one workgroup per instance (k_rs_*_batch in k_resident.h).  The bar:
+bit-identical to the single-instance entry points — the same kernel body runs, only the way its arguments arrive differs —
+and the oracle's results to the tolerances of tests/test_gpu_resident.py."""
+import os
+
+import numpy as np
+import pytest
+
+import sdplrplus_jl_amd as sj
+from sdplrplus_jl_amd import batch, cabi, problems
+
+from helpers import make_data, make_solver
+
+pytestmark = pytest.mark.gpu
+
+# (the trace bound of the experiments, exps/test.jl:166-176: with the default — 1e18 — the dual bound hinges on the sign
+# of a Lanczos estimate at rounding level and such a solve is not a reproducible test case)
+KW = dict(ptol=1e-2, objtol=1e-2, maxtime=120.0, printlevel=0, prior_trace_bound=800.0)
+
+
+@pytest.fixture(autouse=True)
+def _small_instances_take_their_own_route(monkeypatch):
+    monkeypatch.delenv("SDPLR_HIP_FORCE_GRAPH", raising=False)
+    monkeypatch.delenv("SDPLR_HIP_NO_RESIDENT", raising=False)
+
+
+def gset(name):
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "gset_G1_G9.npz"))
+    return problems.maxcut_data(problems.graph_from_edges(int(z[f"{name}_n"]), z[name]))
+
+
+def same(a, b):
+    assert a["iter"] == b["iter"] and a["majoriter"] == b["majoriter"]
+    assert a["obj"] == b["obj"] and a["max_dual_value"] == b["max_dual_value"]
+    assert np.array_equal(a["Rt"], b["Rt"]) and np.array_equal(a["lambda"], b["lambda"])
+    assert a["schedule"] == b["schedule"]
+
+
+def test_batch_calls_equal_the_single_calls_bit_for_bit(hip_abi):
+    """fg → major_iteration (λ update on / off) → dual_obj on six instances of different sizes, once through the batch
+    calls and once through the single-instance calls: every output and the whole device state afterwards are equal bit
+    for bit, and the batch made one shared launch per call."""
+    specs = [("maxcut", 1, 40), ("maxcut", 2, 64), ("maxcut", 3, 25), ("cutnorm", 4, 14), ("maxcut", 5, 90), ("maxcut", 6, 33)]
+    datas = [make_data(f, s, n, 0.3)[0] for f, s, n in specs]
+    A = [make_solver(hip_abi, d, 6, seed=7)[0] for d in datas]
+    B = [make_solver(hip_abi, d, 6, seed=7)[0] for d in datas]
+    norms = [(d.normC(), float(np.linalg.norm(d.b))) for d in datas]
+    rng = np.random.default_rng(0)
+    fa = cabi.batch_fg(hip_abi, A, [(nc, nb, 1, 1) for nc, nb in norms])
+    fb = [s.fg(nc, nb, True, True) + (s.obj,) for s, (nc, nb) in zip(B, norms)]
+    assert fa == fb
+    for rnd, upd in enumerate((0, 1, 1, 0)):
+        sig = 2.0 * (rnd + 1)
+        args = [(nc, nb, 1, 1, 0, upd, sig, 1e-3, 1e-30, 7 + k, 0.0) for k, (nc, nb) in enumerate(norms)]
+        ma = cabi.batch_major_iteration(hip_abi, A, args)
+        mb = [s.major_iteration(*a) + (s.obj,) for s, a in zip(B, args)]
+        assert ma == mb, rnd
+        v0s = [rng.standard_normal(d.n) for d in datas]
+        da = cabi.batch_dual_obj(hip_abi, A, [(float(d.n), 50 * (rnd + 1), v) for d, v in zip(datas, v0s)])
+        db = [s.dual_obj(float(d.n), 50 * (rnd + 1), v) for s, d, v in zip(B, datas, v0s)]
+        assert da == db, rnd
+    for a, b in zip(A, B):
+        for name in ("Rt", "Gt", "dirt", "y", "λ", "primal_vio_raw"):
+            assert np.array_equal(getattr(a, name), getattr(b, name)), name
+        for j in range(4):
+            assert np.array_equal(a.get_factor(cabi.F_LBFGS_S + j), b.get_factor(cabi.F_LBFGS_S + j))
+            assert np.array_equal(a.get_factor(cabi.F_LBFGS_Y + j), b.get_factor(cabi.F_LBFGS_Y + j))
+        assert np.array_equal(a.get_vec(cabi.V_LBFGS_RHO), b.get_vec(cabi.V_LBFGS_RHO))
+        assert a.σ == b.σ and a.obj == b.obj
+        st = a.stats()
+        assert st["resident_shared_launches"] == 1 + 4 + 4 and st["graph_batches"] == 0 and st["eager_batches"] == 0
+        assert b.stats()["resident_shared_launches"] == 0
+    # the state the batch left is a state the single calls continue from
+    for a, b, (nc, nb) in zip(A, B, norms):
+        assert a.inner_loop(nc, nb, True, True, False, 0.0, -1e300, 3, 0.0, *a.fg(nc, nb)) == \
+            b.inner_loop(nc, nb, True, True, False, 0.0, -1e300, 3, 0.0, *b.fg(nc, nb))
+        a.close()
+        b.close()
+
+
+def test_batch_of_mixed_routes_and_shapes(hip_abi, oracle_abi, monkeypatch):
+    """One call with: resident instances of two kernel shapes (ranks 6 and 20), an instance with a low-rank constraint
+    (multi-launch route) and a lone resident shape — the call is total, every item equals its single-instance twin."""
+    specs = [("maxcut", 1, 40, 6), ("maxcut", 2, 50, 6), ("maxcut", 3, 30, 20), ("maxcut", 4, 36, 20),
+             ("minimum_bisection", 5, 24, 6), ("maxcut", 6, 28, 3)]
+    datas = [make_data(f, s, n, 0.3)[0] for f, s, n, _ in specs]
+    A = [make_solver(hip_abi, d, sp[3], seed=3)[0] for d, sp in zip(datas, specs)]
+    B = [make_solver(hip_abi, d, sp[3], seed=3)[0] for d, sp in zip(datas, specs)]
+    norms = [(d.normC(), float(np.linalg.norm(d.b))) for d in datas]
+    assert cabi.batch_fg(hip_abi, A, [(nc, nb, 1, 1) for nc, nb in norms]) == \
+        [s.fg(nc, nb, True, True) + (s.obj,) for s, (nc, nb) in zip(B, norms)]
+    args = [(nc, nb, 1, 1, int(d.has_inequalities), 1, 3.0, 1e-2, 1e-30, 12, 0.0) for d, (nc, nb) in zip(datas, norms)]
+    assert cabi.batch_major_iteration(hip_abi, A, args) == [s.major_iteration(*a) + (s.obj,) for s, a in zip(B, args)]
+    v0s = [np.random.default_rng(k).standard_normal(d.n) for k, d in enumerate(datas)]
+    assert cabi.batch_dual_obj(hip_abi, A, [(float(d.n), 100, v) for d, v in zip(datas, v0s)]) == \
+        [s.dual_obj(float(d.n), 100, v) for s, d, v in zip(B, datas, v0s)]
+    shared = [s.stats()["resident_shared_launches"] for s in A]
+    assert shared[:4] == [3, 3, 3, 3] and shared[4] == 0
+    # … and against the oracle, to the resident route's tolerances
+    for k in (0, 2):
+        o = make_solver(oracle_abi, datas[k], specs[k][3], seed=3)[0]
+        o.fg(*norms[k], True, True)
+        ro = o.major_iteration(*args[k])
+        assert np.allclose([A[k].get_scalar(cabi.S_OBJ)], [o.obj], rtol=1e-9)
+        assert np.allclose(A[k].Rt, o.Rt, rtol=1e-7, atol=1e-9) and ro[4] > 0
+        o.close()
+    for s in A + B:
+        s.close()
+
+
+def test_solve_lockstep_equals_sdplr_one_by_one(hip_abi):
+    """Nine whole solves (two Gset graphs of BASELINE config 5 among them) side by side = the nine solves one by one: same
+    iterations, objective, dual bound, R, λ and schedule, bit for bit."""
+    datas = [gset("G1"), gset("G5")]
+    for seed, n in ((1, 120), (2, 200), (3, 64), (4, 333), (5, 150), (6, 90)):
+        datas.append(make_data("maxcut", seed, n, 0.08)[0])
+    datas.append(make_data("minimum_bisection", 7, 40, 0.2)[0])
+    one = [sj.sdplr(data=d, r=10, **KW) for d in datas]
+    many = batch.solve_lockstep(datas, 10, **KW)
+    for a, b in zip(one, many):
+        assert not isinstance(b, Exception), b
+        same(a, b)
+    assert one[0]["iter"] > 50 and all(x["majoriter"] < 40 for x in one)
+
+
+def test_batch_time_budget_and_iteration_budget(hip_abi):
+    """Per-item budgets: an item with max_local_iters = 2 stops after 2 iterations (exit 2) while its neighbours run on."""
+    datas = [make_data("maxcut", s, 50, 0.2)[0] for s in (1, 2, 3)]
+    A = [make_solver(hip_abi, d, 5, seed=1)[0] for d in datas]
+    norms = [(d.normC(), float(np.linalg.norm(d.b))) for d in datas]
+    cabi.batch_fg(hip_abi, A, [(nc, nb, 1, 1) for nc, nb in norms])
+    args = [(nc, nb, 1, 1, 0, 0, 2.0, 0.0, -1e300, (2, 30, 9)[k], 0.0) for k, (nc, nb) in enumerate(norms)]
+    res = cabi.batch_major_iteration(hip_abi, A, args)
+    assert [r[4] for r in res] == [2, 30, 9] and [r[5] for r in res] == [2, 2, 2]
+    for s in A:
+        s.close()

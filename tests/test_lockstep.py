@@ -1,0 +1,100 @@
+"""The lockstep batch driver (sdplrplus.jl_amd/batch.py: solve_lockstep, serve_batch) and the stepper it drives
+(sdplr.py: sdplr_steps): B solves side by side must be B times `sdplr(data=…)`, result for result.  On the CPU the oracle's
+ABI stands in for the library (its batch calls are loops over the single-instance functions), which pins the driver's
+control flow; tests/test_gpu_lockstep.py repeats the comparison on the HIP library, where a batch call is one launch."""
+import numpy as np
+import pytest
+
+import sdplrplus_jl_amd as sj
+from sdplrplus_jl_amd import batch, cabi, problems
+from sdplrplus_jl_amd.sdplr import REQ_FG, sdplr_steps, serve, build_solver
+from sdplrplus_jl_amd.structs import BurerMonteiroConfig
+
+from helpers import make_data
+
+KW = dict(ptol=1e-2, objtol=1e-2, maxtime=60.0, printlevel=0, prior_trace_bound=30.0)
+
+
+def instances():
+    out = []
+    for seed, n in ((1, 24), (2, 30), (3, 18), (4, 30)):
+        data, *_ = make_data("maxcut", seed, n, 0.3)
+        out.append(data)
+    data, *_ = make_data("minimum_bisection", 5, 20, 0.3)      # a low-rank constraint: another route, same batch
+    out.append(data)
+    return out
+
+
+def same(a, b):
+    assert a["iter"] == b["iter"] and a["majoriter"] == b["majoriter"]
+    assert a["obj"] == b["obj"] and a["max_dual_value"] == b["max_dual_value"]
+    assert np.array_equal(a["Rt"], b["Rt"]) and np.array_equal(a["lambda"], b["lambda"])
+    assert a["schedule"] == b["schedule"]
+
+
+def test_lockstep_equals_one_by_one_on_the_oracle(oracle_abi):
+    datas = instances()
+    one = [sj.sdplr(data=d, r=4, abi=oracle_abi, **KW) for d in datas]
+    many = batch.solve_lockstep(datas, 4, abi=oracle_abi, setup_workers=2, **KW)
+    for a, b in zip(one, many):
+        same(a, b)
+
+
+def test_stepper_yields_the_documented_requests(oracle_abi):
+    data = instances()[0]
+    config = BurerMonteiroConfig()
+    for k, v in KW.items():
+        setattr(config, k, v)
+    var = build_solver(oracle_abi, data, 4, config)
+    steps = sdplr_steps(data, var, config)
+    kinds = []
+    try:
+        req = next(steps)
+        while True:
+            kinds.append(req[0])
+            req = steps.send(serve(var, req))
+    except StopIteration as done:
+        ans = done.value
+    var.close()
+    # the fg! of src/sdplr.jl:170 rides the first major_iteration; the one of :396 closes the solve
+    assert kinds[0] == "major_iteration" and kinds[-1] == REQ_FG
+    assert set(kinds) <= {"fg", "major_iteration", "inner_loop", "dual_obj"} and "dual_obj" in kinds
+    assert kinds.count("major_iteration") + kinds.count("inner_loop") == ans["majoriter"]
+
+
+def test_an_instance_that_fails_does_not_take_the_batch_down(oracle_abi, monkeypatch):
+    """The first dual_obj request of instance 1 raises; its stepper gets the exception (and ends with it), the other
+    instances finish with the results they have on their own."""
+    datas = instances()[:3]
+
+    class Boom(RuntimeError):
+        pass
+
+    victim = []
+    real_build, real_dual = batch.build_solver, cabi.batch_dual_obj
+
+    def build(abi, data, r, config):
+        s = real_build(abi, data, r, config)
+        if data is datas[1]:
+            victim.append(s)
+        return s
+
+    def failing(abi, solvers, args):
+        out = real_dual(abi, solvers, args)
+        return [Boom("injected") if sv is victim[0] else o for sv, o in zip(solvers, out)]
+
+    monkeypatch.setattr(batch, "build_solver", build)
+    monkeypatch.setattr(cabi, "batch_dual_obj", failing)
+    res = batch.solve_lockstep(datas, 4, abi=oracle_abi, setup_workers=1, **KW)
+    monkeypatch.undo()
+    assert isinstance(res[1], Boom)
+    same(sj.sdplr(data=datas[0], r=4, abi=oracle_abi, **KW), res[0])
+    same(sj.sdplr(data=datas[2], r=4, abi=oracle_abi, **KW), res[2])
+
+
+def test_batch_calls_reject_a_handle_listed_twice(hip_abi):
+    arr = (cabi.FgItem * 2)()
+    arr[0].s = arr[1].s = 12345          # (never dereferenced: the duplicate check comes first)
+    assert hip_abi.batch_fg(2, arr) == cabi.ERR_INVALID_ARG
+    assert hip_abi.batch_fg(0, None) == cabi.OK
+    assert hip_abi.batch_major_iteration(-1, None) == cabi.ERR_INVALID_ARG
