@@ -29,9 +29,11 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-# config 5 (other_configs) keeps 16 small instances in flight, each a resident launch that holds its hardware queue for
-# milliseconds: one queue per instance (ROCm's default is 4 per process).  Read when HIP starts; no effect on the headline.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+# (GPU_MAX_HW_QUEUES is left at the runtime's default: config 5 runs in lockstep — one stream carries the whole batch — and
+# a process with 16–32 hardware queues makes every launch and wait of that driver 3–6× slower.  The threaded driver that is
+# timed next to it would like one queue per instance in flight; SDPLR_BENCH_HW_QUEUES=16 gives it that.)
+if os.environ.get("SDPLR_BENCH_HW_QUEUES"):
+    os.environ["GPU_MAX_HW_QUEUES"] = os.environ["SDPLR_BENCH_HW_QUEUES"]
 
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured streaming)
 N_NODES, P_EDGE, RANK_R, GRAPH_SEED, R_SEED = 100_000, 2e-4, 32, 20240610, 0
@@ -541,6 +543,7 @@ def other_configs(sj, abi):
                               "instances": 64, "driver": "lockstep (one launch per step for the whole batch)", "wall_s": wall,
                               "instances_per_s": 64 / wall,
                               "wall_s_driver_threads": walls["threads"], "driver_threads_in_flight": conc,
+                              "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES", "default (4)"),
                               "inner_iterations_total": int(rows[:, 3].sum()), "max_abs_relative_gap": float(np.max(np.abs(gap))),
                               "route": "resident (one launch per major iteration and per dual bound)",
                               "all_converged": bool(np.all(np.abs(gap) <= 1e-2))}

@@ -1,6 +1,5 @@
 """Where a lockstep batch spends its wall time: set-up, each round's library calls, the steppers' own Python."""
 import os, sys, time
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np

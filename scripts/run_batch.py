@@ -13,9 +13,12 @@ import os
 import sys
 import time
 
-# One hardware queue per instance in flight: ROCm multiplexes a process's streams onto 4 hardware queues by default, and a
-# resident loop (one launch that runs for milliseconds) holds its queue while it runs.  Must be set before HIP starts.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+# The threaded driver (SDPLR_BATCH_MODE=threads) wants one hardware queue per instance in flight: ROCm multiplexes a
+# process's streams onto 4 hardware queues by default, and a resident loop (one launch that runs for milliseconds) holds its
+# queue while it runs.  The lockstep driver (default) carries a whole batch on one stream and is 3–6× SLOWER in a process
+# with 16–32 hardware queues (scripts/probes/lockstep_chunks.py): it keeps the default.  Must be set before HIP starts.
+if os.environ.get("SDPLR_BATCH_MODE", "lockstep") != "lockstep":
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 import numpy as np
 

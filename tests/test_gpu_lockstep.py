@@ -124,6 +124,19 @@ def test_solve_lockstep_equals_sdplr_one_by_one(hip_abi):
     assert one[0]["iter"] > 50 and all(x["majoriter"] < 40 for x in one)
 
 
+def test_lockstep_through_rank_doublings(hip_abi):
+    """Rank doublings inside a lockstep batch (reset_rank, a fresh point, then single-instance fg! / inner loop for that
+    instance while the others keep sharing launches): bit-identical to the solves one by one."""
+    datas = [make_data("maxcut", seed, n, 0.3)[0] for seed, n in ((1, 40), (2, 60), (4, 50), (5, 44))]
+    kw = dict(ptol=1e-3, objtol=1e-4, maxtime=60.0, printlevel=0, prior_trace_bound=60.0, rankupd_tol=2)
+    one = [sj.sdplr(data=d, r=2, **kw) for d in datas]
+    many = batch.solve_lockstep(datas, 2, **kw)
+    assert any(x["r"] > 2 for x in one)
+    for a, b in zip(one, many):
+        assert not isinstance(b, Exception), b
+        same(a, b)
+
+
 def test_batch_time_budget_and_iteration_budget(hip_abi):
     """Per-item budgets: an item with max_local_iters = 2 stops after 2 iterations (exit 2) while its neighbours run on."""
     datas = [make_data("maxcut", s, 50, 0.2)[0] for s in (1, 2, 3)]

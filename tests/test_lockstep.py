@@ -40,6 +40,18 @@ def test_lockstep_equals_one_by_one_on_the_oracle(oracle_abi):
         same(a, b)
 
 
+def test_lockstep_through_rank_doublings(oracle_abi):
+    """Instances that double their rank on the way (rank_update!: reset_rank + a fresh point, then fg! and an inner loop that
+    are NOT batch calls) stay in step with the others."""
+    datas = [make_data("maxcut", seed, n, 0.3)[0] for seed, n in ((1, 40), (2, 60), (4, 50))]
+    kw = dict(ptol=1e-3, objtol=1e-4, maxtime=60.0, printlevel=0, prior_trace_bound=60.0, rankupd_tol=2)
+    one = [sj.sdplr(data=d, r=2, abi=oracle_abi, **kw) for d in datas]
+    many = batch.solve_lockstep(datas, 2, abi=oracle_abi, setup_workers=1, **kw)
+    assert [x["r"] for x in one] == [4, 8, 4] or all(x["r"] > 2 for x in one)
+    for a, b in zip(one, many):
+        same(a, b)
+
+
 def test_stepper_yields_the_documented_requests(oracle_abi):
     data = instances()[0]
     config = BurerMonteiroConfig()
