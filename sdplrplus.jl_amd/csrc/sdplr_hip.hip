@@ -3784,7 +3784,10 @@ int32_t sdplr_hip_batch_fg(int32_t count, sdplr_hip_fg_item* it) {
         const size_t nb = std::min(max_rows, idx.size() - lo);
         S* s = it[idx[lo]].s;   // (the shape all rows share: LV_DISPATCH reads s->LPR / s->VEC)
         BatchBuf bb;
-        if (bb.init() != hipSuccess) return fail(s, SDPLR_ERR_ALLOC, "batch_fg: staging blocks");
+        if (bb.init() != hipSuccess) {
+          for (size_t k = 0; k < nb; k++) it[idx[lo + k]].status = SDPLR_ERR_ALLOC;
+          return fail(s, SDPLR_ERR_ALLOC, "batch_fg: staging blocks");
+        }
         RsFgArgs* tab = reinterpret_cast<RsFgArgs*>(bb.host);
         const size_t res_off = batch_up(nb * sizeof(RsFgArgs));
         size_t lds = 0;
@@ -3849,7 +3852,10 @@ int32_t sdplr_hip_batch_major_iteration(int32_t count, sdplr_hip_major_item* it)
         const size_t nb = std::min(max_rows, idx.size() - lo);
         S* s = it[idx[lo]].s;
         BatchBuf bb;
-        if (bb.init() != hipSuccess) return fail(s, SDPLR_ERR_ALLOC, "batch_major_iteration: staging blocks");
+        if (bb.init() != hipSuccess) {
+          for (size_t k = 0; k < nb; k++) it[idx[lo + k]].status = SDPLR_ERR_ALLOC;
+          return fail(s, SDPLR_ERR_ALLOC, "batch_major_iteration: staging blocks");
+        }
         RsLoopArgs* tab = reinterpret_cast<RsLoopArgs*>(bb.host);
         const size_t res_off = batch_up(nb * sizeof(RsLoopArgs));
         size_t lds = 0;
@@ -3947,7 +3953,10 @@ int32_t sdplr_hip_batch_dual_obj(int32_t count, sdplr_hip_dual_item* it) {
         S* s = it[idx[lo]].s;
         if (bytes + 2 * BATCH_ALIGN > ARENA_CHUNK) { single.push_back(idx[lo]); lo = hi; continue; }   // (one instance too large for the block)
         BatchBuf bb;
-        if (bb.init() != hipSuccess) return fail(s, SDPLR_ERR_ALLOC, "batch_dual_obj: staging blocks");
+        if (bb.init() != hipSuccess) {
+          for (size_t k = 0; k < nb; k++) it[idx[lo + k]].status = SDPLR_ERR_ALLOC;
+          return fail(s, SDPLR_ERR_ALLOC, "batch_dual_obj: staging blocks");
+        }
         RsLzEllArgs* tab = reinterpret_cast<RsLzEllArgs*>(bb.host);
         size_t v0_off = batch_up(nb * sizeof(RsLzEllArgs));
         size_t lds = 0;
