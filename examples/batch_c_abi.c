@@ -142,7 +142,7 @@ int main(int argc, char** argv) {
   }
   CK(sdplr_hip_batch_fg(B, fi), NULL); /* src/sdplr.jl:396 */
 
-  /* ---- checks: diag(RRᵀ) = 1, weak duality, a closed gap — and the known optimum where there is one ---- */
+  /* ---- checks: diag(RRᵀ) = 1, weak duality, a closed gap ---- */
   int ok = 1;
   for (int k = 0; k < B; k++) {
     double* R = malloc((size_t)(n[k] * r) * sizeof *R);
