@@ -260,7 +260,8 @@ int32_t sdplr_hip_dual_obj(sdplr_hip_solver* s, double trace_bound, int64_t iter
  * solves side by side hands the SAME step of all of them to the library as one call: the instances on the resident route
  * (one workgroup owns a small instance) that share a kernel shape go out as ONE launch with one workgroup per instance
  * — B CUs busy from one stream, one argument table up, one result table back — and every other instance of the batch is
- * served by the single-instance entry point named in each struct, so the call is total.  Each item is exactly the
+ * served by the single-instance entry point named in each struct (on a few host threads of the library's own, each handle
+ * on its stream), so the call is total.  Each item is exactly the
  * argument list of that entry point; `status` is what it would have returned for that instance (the function itself
  * returns the first non-zero status, or an argument error).  Results are bit-identical to the single-instance calls.
  * Handles of one call must be distinct and must not be used by other threads during the call.                        */

@@ -3757,6 +3757,30 @@ int batch_round_trip(S* s0, BatchBuf& bb, size_t table_bytes, size_t res_off, si
   HIPCK(s0, hipEventSynchronize(bb.ev));
   return SDPLR_OK;
 }
+// the items a batch call serves through the single-instance entry point: on a few host threads (each handle has its own
+// stream), so that a batch of instances of the multi-launch routes overlaps as the threaded driver's would
+template <typename F>
+void run_singles(const std::vector<int>& idx, F&& one) {
+  const size_t nt = std::min<size_t>(idx.size(), 8);
+  if (nt <= 1) {
+    for (int i : idx) one(i);
+    return;
+  }
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  std::atomic<size_t> next{0};
+  std::vector<std::thread> th;
+  for (size_t t = 0; t < nt; t++)
+    th.emplace_back([&] {
+      (void)hipSetDevice(dev);   // (a new thread starts on device 0)
+      for (;;) {
+        const size_t k = next.fetch_add(1);
+        if (k >= idx.size()) break;
+        one(idx[k]);
+      }
+    });
+  for (auto& x : th) x.join();
+}
 }  // namespace
 
 extern "C" {
@@ -3818,11 +3842,12 @@ int32_t sdplr_hip_batch_fg(int32_t count, sdplr_hip_fg_item* it) {
       }
     }
   }
-  for (int i : single) {
+  run_singles(single, [&](int i) {
     sdplr_hip_fg_item& q = it[i];
+    if (!q.s) { q.status = SDPLR_ERR_INVALID_ARG; return; }
     q.status = sdplr_hip_fg(q.s, q.normC, q.normb, q.gtol_relative, q.ptol_relative, &q.lagrangian, &q.grad_norm, &q.primal_vio_norm);
     if (!q.status) q.status = sdplr_hip_get_scalar(q.s, SDPLR_S_OBJ, &q.obj);
-  }
+  });
   for (int i = 0; i < count; i++) if (it[i].status) return it[i].status;
   return SDPLR_OK;
 }
@@ -3904,13 +3929,14 @@ int32_t sdplr_hip_batch_major_iteration(int32_t count, sdplr_hip_major_item* it)
       }
     }
   }
-  for (int i : single) {
+  run_singles(single, [&](int i) {
     sdplr_hip_major_item& q = it[i];
+    if (!q.s) { q.status = SDPLR_ERR_INVALID_ARG; return; }
     q.status = sdplr_hip_major_iteration(q.s, q.normC, q.normb, q.gtol_relative, q.ptol_relative, q.use_armijo, q.update_lambda,
                                          q.sigma, q.cur_gtol, q.fprec_eps, q.max_local_iters, q.time_budget_s, &q.lagrangian,
                                          &q.grad_norm, &q.primal_vio_norm, &q.last_alpha, &q.iters_done, &q.exit_reason);
     if (!q.status) q.status = sdplr_hip_get_scalar(q.s, SDPLR_S_OBJ, &q.obj);
-  }
+  });
   for (int i = 0; i < count; i++) if (it[i].status) return it[i].status;
   return SDPLR_OK;
 }
@@ -4013,10 +4039,11 @@ int32_t sdplr_hip_batch_dual_obj(int32_t count, sdplr_hip_dual_item* it) {
       }
     }
   }
-  for (int i : single) {
+  run_singles(single, [&](int i) {
     sdplr_hip_dual_item& q = it[i];
+    if (!q.s) { q.status = SDPLR_ERR_INVALID_ARG; return; }
     q.status = sdplr_hip_dual_obj(q.s, q.trace_bound, q.iter, q.v0, &q.dual_value, &q.mineig);
-  }
+  });
   for (int i = 0; i < count; i++) if (it[i].status) return it[i].status;
   return SDPLR_OK;
 }

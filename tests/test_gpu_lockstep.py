@@ -137,6 +137,21 @@ def test_lockstep_through_rank_doublings(hip_abi):
         same(a, b)
 
 
+def test_lockstep_on_the_multi_launch_routes(hip_abi, monkeypatch):
+    """Instances that are not on the resident route (switched off here; in production: larger ones, low-rank or inequality
+    constraints) are served by the single-instance entry points on a few host threads inside each batch call — same
+    results as one by one, no shared launches."""
+    monkeypatch.setenv("SDPLR_HIP_NO_RESIDENT", "1")
+    datas = [make_data("maxcut", seed, n, 0.1)[0] for seed, n in ((1, 150), (2, 220), (3, 90), (4, 300), (5, 180))]
+    datas.append(make_data("minimum_bisection", 7, 60, 0.2)[0])
+    kw = dict(KW, prior_trace_bound=300.0)
+    one = [sj.sdplr(data=d, r=8, **kw) for d in datas]
+    many = batch.solve_lockstep(datas, 8, **kw)
+    for a, b in zip(one, many):
+        assert not isinstance(b, Exception), b
+        same(a, b)
+
+
 def test_batch_time_budget_and_iteration_budget(hip_abi):
     """Per-item budgets: an item with max_local_iters = 2 stops after 2 iterations (exit 2) while its neighbours run on."""
     datas = [make_data("maxcut", s, 50, 0.2)[0] for s in (1, 2, 3)]
