@@ -32,7 +32,9 @@ def solve_local(instances: Sequence, rank: int, world: int, r: int, *, abi=None,
     mine = assign(len(instances), world)[rank]
     if lockstep and mine:
         datas = [make_data(instances[k]) if make_data is not None else instances[k] for k in mine]
-        res = solve_lockstep(datas, r, abi=abi, setup_workers=concurrency, printlevel=0, **kwargs)
+        # (set-up threads: 64 config-5 instances take 78 / 24 / 15 / 14 / 20 ms on 1 / 4 / 8 / 12 / 16 threads —
+        # scripts/probes/setup_scaling.py: beyond ≈ 8 the HIP runtime's own locks and the GIL take the gain back)
+        res = solve_lockstep(datas, r, abi=abi, setup_workers=min(concurrency, 8), printlevel=0, **kwargs)
         for x in res:
             if isinstance(x, Exception):
                 raise x
