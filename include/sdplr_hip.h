@@ -80,7 +80,7 @@ typedef struct sdplr_hip_solver sdplr_hip_solver; /* opaque handle ("HIPAux" + d
 /* ---- device management -------------------------------------------------------------------- */
 int32_t sdplr_hip_device_count(int32_t* count);
 int32_t sdplr_hip_set_device(int32_t device); /* process-wide; call before create (one rank = one GPU) */
-const char* sdplr_hip_last_error(const sdplr_hip_solver* s); /* s may be NULL: last create-time error */
+const char* sdplr_hip_last_error(const sdplr_hip_solver* s); /* s may be NULL: the calling thread's last error of a call without a handle (create, warmup, batch argument checks) */
 const char* sdplr_hip_version(void);
 int32_t sdplr_hip_device_synchronize(void); /* hipDeviceSynchronize on the current device */
 /* Optional: primes the library's pools (HIP streams, events, pinned staging) for n_handles handles alive at once, so

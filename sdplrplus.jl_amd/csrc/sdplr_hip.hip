@@ -33,7 +33,7 @@
 
 namespace {
 
-std::string g_err;
+thread_local std::string g_err;   // errors of calls without a handle (create, warmup, the batch calls' argument checks): per calling thread
 // ROCm 7.2: while one host thread records a hipGraph, HIP calls made by OTHER threads fail ("operation
 // failed due to a previous error during capture", any capture mode).  Every entry point therefore holds
 // this lock shared; a capture takes it exclusively — but only if it gets it within a bounded wait
