@@ -4,8 +4,11 @@
 // On an instance whose factor is a few tens of KB every kernel of the multi-launch routes is a launch seam: ten
 // launches of ≈ 4.5 µs per inner iteration with 255 of 256 CUs idle.  Here ONE workgroup owns the instance for a whole
 // call of the inner `while` (src/sdplr.jl:190-278): one launch runs up to max_iters iterations, every exit test is
-// taken on the device, and the host reads the control block once at the end.  A batch of instances is then a set of
-// independent single-CU launches on their own streams — 64 instances occupy 64 CUs at the same time.
+// taken on the device, and the host reads the control block once at the end.  A batch of instances is ONE grid with a
+// workgroup per instance (k_rs_*_batch: block b runs row b of an argument table through the same body, rs_*_run, that the
+// single-instance kernel runs; the scalars a single call moves through the control block ride the table rows) — 64
+// instances occupy 64 CUs at the same time from one stream (sdplr_hip_batch_*), or a set of independent single-CU
+// launches on the instances' own streams (threaded drivers).
 //
 //   * the direction D lives in LDS (n·r doubles — the SpMM W = A_g·D gathers ≈ 48 rows of it per row at LDS speed);
 //     R, G, P, W and the 2h history arrays stay in global memory, which for ≤ 1 MB of state means the XCD's L2;
