@@ -165,8 +165,16 @@ __device__ __forceinline__ void rs_ell_pass(const unsigned* __restrict__ ep, con
 // Y = X·A_g for all rows, chunks [c0, c0 + NCH): one slice per wave and trip.  TO_P: Y row-major (P = A_g·R, strided
 // 16-byte stores — once per call at most); otherwise chunk-major (Wt[(c·n + j)·VEC]: chunk c of the 64 rows of a wave is a
 // few whole lines).
-template <int VEC, int MODE, bool TO_P, int NCH>
-__device__ __forceinline__ void rs_ell_spmm_chunks(const RsEll& E, const double* Xl, int n, int r, int c0, double* out) {
+// DOTS (the loop's W = A_g·D): the lane that owns row j also forms that row's four line-search dots while W_j is in its
+// registers — ⟨R_j,D_j⟩ and ‖D_j‖² to the LDS vectors rdl / ddl, ⟨R_j,W_j⟩ and ⟨D_j,W_j⟩ into the lane's running sums rw / dw
+// (R_j is requested before the gather loop and arrives under it; D_j is in LDS) — so that no pass re-reads W and R for them.
+struct RsDots {
+  const double* R;
+  double *rdl, *ddl;
+};
+template <int VEC, int MODE, bool TO_P, int NCH, bool DOTS>
+__device__ __forceinline__ void rs_ell_spmm_chunks(const RsEll& E, const double* Xl, int n, int r, int c0, double* out,
+                                                   const RsDots& dots, double& rw, double& dw) {
   const int wave = threadIdx.x >> 6, wl = threadIdx.x & 63;
   const double one = E.one;
 #pragma nounroll
@@ -179,40 +187,79 @@ __device__ __forceinline__ void rs_ell_spmm_chunks(const RsEll& E, const double*
     const double* vp = (MODE == 2) ? E.val + (size_t)l0 * 64 + wl : nullptr;
     const int j = max(jp, 0);
     const double gd = (jp >= 0) ? E.gdiag[j] : 0.0;
+    // (R_j is asked for before the gather loop where the registers allow it — up to five chunks: with eight, the 32
+    // registers it would hold through the loop spill — and after it otherwise)
+    constexpr bool EARLY = DOTS && NCH * VEC <= 10;
+    vecd<VEC> xr[DOTS ? NCH : 1];
+    if (EARLY) {
+#pragma unroll
+      for (int c = 0; c < NCH; c++) xr[c] = ldrow<VEC>(dots.R + (long long)j * r + (c0 + c) * VEC);
+    }
     vecd<VEC> w[NCH];
     rs_ell_pass<VEC, MODE, NCH>(ep, vp, width, len, one, Xl, r, c0, j, gd, w);
+    if (DOTS && !EARLY) {
+#pragma unroll
+      for (int c = 0; c < NCH; c++) xr[c] = ldrow<VEC>(dots.R + (long long)j * r + (c0 + c) * VEC);
+    }
     if (jp >= 0) {
 #pragma unroll
       for (int c = 0; c < NCH; c++) {
         if (TO_P) strow<VEC>(out + (long long)j * r + (c0 + c) * VEC, w[c]);
         else strow<VEC>(out + ((long long)(c0 + c) * n + j) * VEC, w[c]);
       }
+      if (DOTS) {
+        double rd = 0.0, dd = 0.0;
+#pragma unroll
+        for (int c = 0; c < NCH; c++) {
+          const vecd<VEC> xd = ldrow<VEC>(Xl + (long long)j * r + (c0 + c) * VEC);
+#pragma unroll
+          for (int q = 0; q < VEC; q++) {
+            rd += xr[c].v[q] * xd.v[q];
+            dd += xd.v[q] * xd.v[q];
+            rw += xr[c].v[q] * w[c].v[q];
+            dw += xd.v[q] * w[c].v[q];
+          }
+        }
+        // (a row is owned by the same lane in every pass over the chunks: the passes after the first add to its sums)
+        dots.rdl[j] = (c0 == 0 ? 0.0 : dots.rdl[j]) + rd;
+        dots.ddl[j] = (c0 == 0 ? 0.0 : dots.ddl[j]) + dd;
+      }
     }
   }
 }
 // (the dispatch on the number of chunks sits OUTSIDE the slice loop: with the switch inside it the compiler merged the
 // heads of all its cases and the kernel needed 256 VGPRs and scratch; each case by itself takes 56–101)
-template <int VEC, int MODE, bool TO_P>
-__device__ __forceinline__ void rs_ell_spmm(const RsEll& E, const double* Xl, int n, int r, double* out) {
+template <int VEC, int MODE, bool TO_P, bool DOTS>
+__device__ __forceinline__ void rs_ell_spmm(const RsEll& E, const double* Xl, int n, int r, double* out, const RsDots& dots,
+                                            double& rw, double& dw) {
   const int NC = r / VEC;   // (VEC = 2 only for even r)
 #pragma nounroll
   for (int c0 = 0; c0 < NC; c0 += 8) {
     switch (min(NC - c0, 8)) {
-      case 1: rs_ell_spmm_chunks<VEC, MODE, TO_P, 1>(E, Xl, n, r, c0, out); break;
-      case 2: rs_ell_spmm_chunks<VEC, MODE, TO_P, 2>(E, Xl, n, r, c0, out); break;
-      case 3: rs_ell_spmm_chunks<VEC, MODE, TO_P, 3>(E, Xl, n, r, c0, out); break;
-      case 4: rs_ell_spmm_chunks<VEC, MODE, TO_P, 4>(E, Xl, n, r, c0, out); break;
-      case 5: rs_ell_spmm_chunks<VEC, MODE, TO_P, 5>(E, Xl, n, r, c0, out); break;
-      case 6: rs_ell_spmm_chunks<VEC, MODE, TO_P, 6>(E, Xl, n, r, c0, out); break;
-      case 7: rs_ell_spmm_chunks<VEC, MODE, TO_P, 7>(E, Xl, n, r, c0, out); break;
-      default: rs_ell_spmm_chunks<VEC, MODE, TO_P, 8>(E, Xl, n, r, c0, out); break;
+      case 1: rs_ell_spmm_chunks<VEC, MODE, TO_P, 1, DOTS>(E, Xl, n, r, c0, out, dots, rw, dw); break;
+      case 2: rs_ell_spmm_chunks<VEC, MODE, TO_P, 2, DOTS>(E, Xl, n, r, c0, out, dots, rw, dw); break;
+      case 3: rs_ell_spmm_chunks<VEC, MODE, TO_P, 3, DOTS>(E, Xl, n, r, c0, out, dots, rw, dw); break;
+      case 4: rs_ell_spmm_chunks<VEC, MODE, TO_P, 4, DOTS>(E, Xl, n, r, c0, out, dots, rw, dw); break;
+      case 5: rs_ell_spmm_chunks<VEC, MODE, TO_P, 5, DOTS>(E, Xl, n, r, c0, out, dots, rw, dw); break;
+      case 6: rs_ell_spmm_chunks<VEC, MODE, TO_P, 6, DOTS>(E, Xl, n, r, c0, out, dots, rw, dw); break;
+      case 7: rs_ell_spmm_chunks<VEC, MODE, TO_P, 7, DOTS>(E, Xl, n, r, c0, out, dots, rw, dw); break;
+      default: rs_ell_spmm_chunks<VEC, MODE, TO_P, 8, DOTS>(E, Xl, n, r, c0, out, dots, rw, dw); break;
     }
   }
 }
 template <int VEC, bool TO_P>
 __device__ __forceinline__ void rs_ell_spmm_any(const RsEll& E, const double* Xl, int n, int r, double* out) {
-  if (E.val == nullptr) rs_ell_spmm<VEC, 0, TO_P>(E, Xl, n, r, out);
-  else rs_ell_spmm<VEC, 2, TO_P>(E, Xl, n, r, out);
+  const RsDots none{nullptr, nullptr, nullptr};
+  double u0 = 0.0, u1 = 0.0;
+  if (E.val == nullptr) rs_ell_spmm<VEC, 0, TO_P, false>(E, Xl, n, r, out, none, u0, u1);
+  else rs_ell_spmm<VEC, 2, TO_P, false>(E, Xl, n, r, out, none, u0, u1);
+}
+// W = A_g·D chunk-major with the row dots of the line search (RsDots)
+template <int VEC>
+__device__ __forceinline__ void rs_ell_spmm_dots(const RsEll& E, const double* Xl, int n, int r, double* out, const RsDots& dots,
+                                                 double& rw, double& dw) {
+  if (E.val == nullptr) rs_ell_spmm<VEC, 0, false, true>(E, Xl, n, r, out, dots, rw, dw);
+  else rs_ell_spmm<VEC, 2, false, true>(E, Xl, n, r, out, dots, rw, dw);
 }
 
 // ---- fg! (src/coreop.jl:323-349) as one launch on the instances of the resident loop ----------------------------------
@@ -590,52 +637,21 @@ __device__ __forceinline__ void rs_loop_run(const RsLoopArgs& a) {
     __syncthreads();
     RS_STAMP(1);
     // ================= SPMM =================
-    rs_ell_spmm_any<VEC, false>(a.E, Dl, n, r, a.W);     // Wt = A_g·D, one row per lane
-    __syncthreads();
-    RS_STAMP(7);
-    // row dots, LPR lanes per row: ⟨R_j,D_j⟩, ‖D_j‖², partials of ⟨R,W⟩ (= ⟨P,D⟩: A_g symmetric) and ⟨D,W⟩
-    double acc[10];
-#pragma unroll
-    for (int k = 0; k < 10; k++) acc[k] = 0.0;
-    // (four rows per group and trip: twelve independent loads in flight per lane instead of a round trip per row)
-#pragma nounroll
-    for (int j0 = grp; j0 < n; j0 += 4 * G) {
-      vecd<VEC> xr[4], xd[4], w[4];
-#pragma unroll
-      for (int u = 0; u < 4; u++) {
-        const int j = min(j0 + u * G, n - 1);
-#pragma unroll
-        for (int k = 0; k < VEC; k++) xr[u].v[k] = xd[u].v[k] = w[u].v[k] = 0.0;
-        if (act) {
-          xr[u] = ldrow<VEC>(R + (long long)j * r + ch0);
-          xd[u] = ldrow<VEC>(Dl + (long long)j * r + ch0);
-          w[u] = ldrow<VEC>(a.W + ((long long)lane * n + j) * VEC);
-        }
-      }
-#pragma unroll
-      for (int u = 0; u < 4; u++) {
-        const int j = j0 + u * G;
-        const bool ok = j < n;    // (group-uniform)
-        double rd = 0.0, dd = 0.0;
-#pragma unroll
-        for (int k = 0; k < VEC; k++) {
-          rd += xr[u].v[k] * xd[u].v[k];
-          dd += xd[u].v[k] * xd[u].v[k];
-          if (ok) {
-            acc[8] += xr[u].v[k] * w[u].v[k];
-            acc[9] += xd[u].v[k] * w[u].v[k];
-          }
-        }
-        rd = group_sum<LPR>(rd);
-        dd = group_sum<LPR>(dd);
-        if (lane == 0 && ok) {
-          rdl[j] = rd;
-          ddl[j] = dd;
-        }
-      }
+    // Wt = A_g·D, one row per lane — and, by the lane that owns the row, ⟨R_j,D_j⟩, ‖D_j‖² (→ rdl, ddl) and this lane's part
+    // of ⟨R,W⟩ (= ⟨P,D⟩: A_g symmetric) and ⟨D,W⟩
+    double rw_sum = 0.0, dw_sum = 0.0;
+    {
+      const RsDots dots{R, rdl, ddl};
+      rs_ell_spmm_dots<VEC>(a.E, Dl, n, r, a.W, dots, rw_sum, dw_sum);
     }
     __syncthreads();
+    RS_STAMP(7);
     RS_STAMP(2);
+    double acc[10];
+#pragma unroll
+    for (int k = 0; k < 8; k++) acc[k] = 0.0;
+    acc[8] = rw_sum;
+    acc[9] = dw_sum;
     // ================= LSSUM =================
     {
       const double sigma = gd.c.sigma;
