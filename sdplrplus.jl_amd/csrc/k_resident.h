@@ -16,9 +16,8 @@
 //     one 256-byte line, 4 bytes per entry): per entry a lane issues one coalesced load, the LDS reads of the gathered
 //     row and the multiply-adds — no index hand-offs, no row pointers.  (The first version gave a row to 8 lanes, as
 //     the multi-launch kernels do: every entry then cost a wave ≈ 15 instructions for 8 entries and a dependent global
-//     round trip per 32 — 137 µs of a 171 µs iteration on Gset G1.)  W is kept chunk-major inside this kernel
-//     (Wt[c][j]: chunk c of all rows contiguous) so that the row-per-lane writer and the lanes-per-row readers both
-//     touch whole lines;
+//     round trip per 32 — 137 µs of a 171 µs iteration on Gset G1.)  The lane that owns a row also forms that row's
+//     line-search dots while W_j is in its registers; W goes out row-major and STEP streams it element by element;
 //   * per-row quantities (⟨R_j,D_j⟩, ‖D_j‖², the diagonal coefficient d_j of S) are LDS vectors; the data of the
 //     one singleton constraint attached to a row (λ, λ_ub, lb, primal_vio_raw, value) sit in the registers of the
 //     thread that owns the row for the whole call;
@@ -162,9 +161,9 @@ __device__ __forceinline__ void rs_ell_pass(const unsigned* __restrict__ ep, con
     for (int q = 0; q < VEC; q++) w[c].v[q] += x.v[q] * gd;
   }
 }
-// Y = X·A_g for all rows, chunks [c0, c0 + NCH): one slice per wave and trip.  TO_P: Y row-major (P = A_g·R, strided
-// 16-byte stores — once per call at most); otherwise chunk-major (Wt[(c·n + j)·VEC]: chunk c of the 64 rows of a wave is a
-// few whole lines).
+// Y = X·A_g for all rows, chunks [c0, c0 + NCH): one slice per wave and trip; Y row-major like every factor-shaped array
+// (a lane stores its row's chunks: 16-byte pieces of 64 different rows per store instruction — 64 KB per SpMM, and the
+// consumers stream Y element by element).
 // DOTS (the loop's W = A_g·D): the lane that owns row j also forms that row's four line-search dots while W_j is in its
 // registers — ⟨R_j,D_j⟩ and ‖D_j‖² to the LDS vectors rdl / ddl, ⟨R_j,W_j⟩ and ⟨D_j,W_j⟩ into the lane's running sums rw / dw
 // (R_j is requested before the gather loop and arrives under it; D_j is in LDS) — so that no pass re-reads W and R for them.
@@ -172,7 +171,7 @@ struct RsDots {
   const double* R;
   double *rdl, *ddl;
 };
-template <int VEC, int MODE, bool TO_P, int NCH, bool DOTS>
+template <int VEC, int MODE, int NCH, bool DOTS>
 __device__ __forceinline__ void rs_ell_spmm_chunks(const RsEll& E, const double* Xl, int n, int r, int c0, double* out,
                                                    const RsDots& dots, double& rw, double& dw) {
   const int wave = threadIdx.x >> 6, wl = threadIdx.x & 63;
@@ -204,8 +203,7 @@ __device__ __forceinline__ void rs_ell_spmm_chunks(const RsEll& E, const double*
     if (jp >= 0) {
 #pragma unroll
       for (int c = 0; c < NCH; c++) {
-        if (TO_P) strow<VEC>(out + (long long)j * r + (c0 + c) * VEC, w[c]);
-        else strow<VEC>(out + ((long long)(c0 + c) * n + j) * VEC, w[c]);
+        strow<VEC>(out + (long long)j * r + (c0 + c) * VEC, w[c]);
       }
       if (DOTS) {
         double rd = 0.0, dd = 0.0;
@@ -229,37 +227,37 @@ __device__ __forceinline__ void rs_ell_spmm_chunks(const RsEll& E, const double*
 }
 // (the dispatch on the number of chunks sits OUTSIDE the slice loop: with the switch inside it the compiler merged the
 // heads of all its cases and the kernel needed 256 VGPRs and scratch; each case by itself takes 56–101)
-template <int VEC, int MODE, bool TO_P, bool DOTS>
+template <int VEC, int MODE, bool DOTS>
 __device__ __forceinline__ void rs_ell_spmm(const RsEll& E, const double* Xl, int n, int r, double* out, const RsDots& dots,
                                             double& rw, double& dw) {
   const int NC = r / VEC;   // (VEC = 2 only for even r)
 #pragma nounroll
   for (int c0 = 0; c0 < NC; c0 += 8) {
     switch (min(NC - c0, 8)) {
-      case 1: rs_ell_spmm_chunks<VEC, MODE, TO_P, 1, DOTS>(E, Xl, n, r, c0, out, dots, rw, dw); break;
-      case 2: rs_ell_spmm_chunks<VEC, MODE, TO_P, 2, DOTS>(E, Xl, n, r, c0, out, dots, rw, dw); break;
-      case 3: rs_ell_spmm_chunks<VEC, MODE, TO_P, 3, DOTS>(E, Xl, n, r, c0, out, dots, rw, dw); break;
-      case 4: rs_ell_spmm_chunks<VEC, MODE, TO_P, 4, DOTS>(E, Xl, n, r, c0, out, dots, rw, dw); break;
-      case 5: rs_ell_spmm_chunks<VEC, MODE, TO_P, 5, DOTS>(E, Xl, n, r, c0, out, dots, rw, dw); break;
-      case 6: rs_ell_spmm_chunks<VEC, MODE, TO_P, 6, DOTS>(E, Xl, n, r, c0, out, dots, rw, dw); break;
-      case 7: rs_ell_spmm_chunks<VEC, MODE, TO_P, 7, DOTS>(E, Xl, n, r, c0, out, dots, rw, dw); break;
-      default: rs_ell_spmm_chunks<VEC, MODE, TO_P, 8, DOTS>(E, Xl, n, r, c0, out, dots, rw, dw); break;
+      case 1: rs_ell_spmm_chunks<VEC, MODE, 1, DOTS>(E, Xl, n, r, c0, out, dots, rw, dw); break;
+      case 2: rs_ell_spmm_chunks<VEC, MODE, 2, DOTS>(E, Xl, n, r, c0, out, dots, rw, dw); break;
+      case 3: rs_ell_spmm_chunks<VEC, MODE, 3, DOTS>(E, Xl, n, r, c0, out, dots, rw, dw); break;
+      case 4: rs_ell_spmm_chunks<VEC, MODE, 4, DOTS>(E, Xl, n, r, c0, out, dots, rw, dw); break;
+      case 5: rs_ell_spmm_chunks<VEC, MODE, 5, DOTS>(E, Xl, n, r, c0, out, dots, rw, dw); break;
+      case 6: rs_ell_spmm_chunks<VEC, MODE, 6, DOTS>(E, Xl, n, r, c0, out, dots, rw, dw); break;
+      case 7: rs_ell_spmm_chunks<VEC, MODE, 7, DOTS>(E, Xl, n, r, c0, out, dots, rw, dw); break;
+      default: rs_ell_spmm_chunks<VEC, MODE, 8, DOTS>(E, Xl, n, r, c0, out, dots, rw, dw); break;
     }
   }
 }
-template <int VEC, bool TO_P>
+template <int VEC>
 __device__ __forceinline__ void rs_ell_spmm_any(const RsEll& E, const double* Xl, int n, int r, double* out) {
   const RsDots none{nullptr, nullptr, nullptr};
   double u0 = 0.0, u1 = 0.0;
-  if (E.val == nullptr) rs_ell_spmm<VEC, 0, TO_P, false>(E, Xl, n, r, out, none, u0, u1);
-  else rs_ell_spmm<VEC, 2, TO_P, false>(E, Xl, n, r, out, none, u0, u1);
+  if (E.val == nullptr) rs_ell_spmm<VEC, 0, false>(E, Xl, n, r, out, none, u0, u1);
+  else rs_ell_spmm<VEC, 2, false>(E, Xl, n, r, out, none, u0, u1);
 }
-// W = A_g·D chunk-major with the row dots of the line search (RsDots)
+// W = A_g·D with the row dots of the line search (RsDots)
 template <int VEC>
 __device__ __forceinline__ void rs_ell_spmm_dots(const RsEll& E, const double* Xl, int n, int r, double* out, const RsDots& dots,
                                                  double& rw, double& dw) {
-  if (E.val == nullptr) rs_ell_spmm<VEC, 0, false, true>(E, Xl, n, r, out, dots, rw, dw);
-  else rs_ell_spmm<VEC, 2, false, true>(E, Xl, n, r, out, dots, rw, dw);
+  if (E.val == nullptr) rs_ell_spmm<VEC, 0, true>(E, Xl, n, r, out, dots, rw, dw);
+  else rs_ell_spmm<VEC, 2, true>(E, Xl, n, r, out, dots, rw, dw);
 }
 
 // ---- fg! (src/coreop.jl:323-349) as one launch on the instances of the resident loop ----------------------------------
@@ -303,7 +301,7 @@ __device__ __forceinline__ void rs_fg_body(const RsFgArgs& a, DevCtrl& c, double
   if (tid == 0) sh.has_obj_row = 0;
   for (long long e = tid; e < N; e += NT) Rl[e] = a.R[e];
   __syncthreads();
-  rs_ell_spmm_any<VEC, true>(a.E, Rl, n, r, a.P);     // P = A_g·R
+  rs_ell_spmm_any<VEC>(a.E, Rl, n, r, a.P);     // P = A_g·R
   __syncthreads();
   double acc[3] = {0.0, 0.0, 0.0};   // ⟨R, P⟩
 #pragma nounroll
@@ -552,7 +550,7 @@ __device__ __forceinline__ void rs_loop_run(const RsLoopArgs& a) {
   if (a.refresh_P && !a.pre_fg) {   // P = A_g·R (entry of the loop: R was written outside, or the incremental P is due for a refresh)
     for (long long e = tid; e < N; e += NT) Dl[e] = R[e];
     __syncthreads();
-    rs_ell_spmm_any<VEC, true>(a.E, Dl, n, r, a.P);
+    rs_ell_spmm_any<VEC>(a.E, Dl, n, r, a.P);
   }
   __syncthreads();
   bool have_upd = false, have_norms = false;
@@ -637,7 +635,7 @@ __device__ __forceinline__ void rs_loop_run(const RsLoopArgs& a) {
     __syncthreads();
     RS_STAMP(1);
     // ================= SPMM =================
-    // Wt = A_g·D, one row per lane — and, by the lane that owns the row, ⟨R_j,D_j⟩, ‖D_j‖² (→ rdl, ddl) and this lane's part
+    // W = A_g·D, one row per lane — and, by the lane that owns the row, ⟨R_j,D_j⟩, ‖D_j‖² (→ rdl, ddl) and this lane's part
     // of ⟨R,W⟩ (= ⟨P,D⟩: A_g symmetric) and ⟨D,W⟩
     double rw_sum = 0.0, dw_sum = 0.0;
     {
@@ -803,12 +801,17 @@ __device__ __forceinline__ void rs_loop_run(const RsLoopArgs& a) {
         slp[l] = aslot(a.A, AS_S0 + ((l < h) ? l : 0));
         ylp[l] = aslot(a.A, as_y0(a.A) + ((l < h) ? l : 0));
       }
-      if (act) {
+      // element by element in units of VEC doubles, like DIR (every stream fully coalesced, all lanes busy whatever the
+      // rank); the row of a unit — for d_j — advances with it
+      {
+        const long long U = N / VEC;                       // (VEC = 2 only for even r)
+        const int adv = NT * VEC, adv_q = adv / r, adv_r = adv % r;
+        int j = (tid * VEC) / r, ch = (tid * VEC) % r;
 #pragma nounroll
-        for (int j = grp; j < n; j += G) {
-          const long long e = (long long)j * r + ch0;
+        for (long long u = tid; u < U; u += NT) {
+          const long long e = u * VEC;
           const vecd<VEC> x0 = ldrow<VEC>(R + e), p0 = ldrow<VEC>(a.P + e), gold = ldrow<VEC>(Gm + e);
-          const vecd<VEC> w = ldrow<VEC>(a.W + ((long long)lane * n + j) * VEC);
+          const vecd<VEC> w = ldrow<VEC>(a.W + e);
           const vecd<VEC> d = ldrow<VEC>(Dl + e);
           vecd<VEC> sv[HM], yv[HM];
           if (upd) {
@@ -819,6 +822,9 @@ __device__ __forceinline__ void rs_loop_run(const RsLoopArgs& a) {
             }
           }
           const double dj = djl[j];
+          ch += adv_r;
+          j += adv_q;
+          if (ch >= r) { ch -= r; j++; }
           vecd<VEC> x, pp, g;
 #pragma unroll
           for (int q = 0; q < VEC; q++) {
