@@ -54,6 +54,10 @@
 #endif
 
 
+// doubles of the LDS copy of a factor-shaped array: the n rows and one more, row n, that stays zero — the SpMM sends the
+// lanes of rows shorter than their slice's longest there (rounded to an even count: 16-byte alignment of what follows)
+__host__ __device__ inline long long rs_npad(long long n, long long r) { return (n * r + r + 1) & ~1LL; }
+
 // sums of K values over the workgroup, delivered to thread 0 only (fixed order: lanes by DPP, then waves 0..NW−1)
 template <int K>
 __device__ __forceinline__ void rs_sum_to0(double (&v)[K], double* sh) {
@@ -95,11 +99,12 @@ struct RsEll {
 };
 
 // NCH chunks (VEC doubles each, from chunk c0) of Y_j = Σ_k a_jk·X_k for the 64 rows of one slice, X in LDS (row-major):
-// the products of a row are summed by increasing column, the diagonal last.  MODE 0: one off-diagonal value, 2: value
-// array.  Lanes whose row is shorter than the slice's longest multiply row 0 by zero.
+// the terms of a row are summed by increasing column, the diagonal last.  MODE 0: one off-diagonal value (the rows of X
+// are summed, the sum scaled once), 2: value array.  Lanes whose row is shorter than the slice's longest gather the zero
+// row n of X (MODE 0) or multiply row 0 by zero.
 template <int VEC, int MODE, int NCH>
 __device__ __forceinline__ void rs_ell_pass(const unsigned* __restrict__ ep, const double* __restrict__ vp, int width, int len,
-                                            double one, const double* Xl, int r, int c0, int j, double gd,
+                                            double one, const double* Xl, int r, int c0, int j, double gd, int zrow,
                                             vecd<VEC> (&w)[NCH]) {
 #pragma unroll
   for (int c = 0; c < NCH; c++)
@@ -137,16 +142,20 @@ __device__ __forceinline__ void rs_ell_pass(const unsigned* __restrict__ ep, con
       const int k = k0 + q;
       const bool on = k < len;     // (len ≤ width: also false past the slice's end)
       const unsigned e = ec[q];
-      const int col = on ? (int)(e & 0xFFFFu) : 0;
-      double v;
-      if (MODE == 0) v = on ? one : 0.0;
-      else v = on ? vc[q] : 0.0;
+      // MODE 0 (one value for every off-diagonal entry): the gathered rows are SUMMED and the sum is scaled once, after
+      // the loop — half the FP64 instructions of the multiply-add form; a lane past its row's end gathers the zero row
+      const int col = on ? (int)(e & 0xFFFFu) : (MODE == 0 ? zrow : 0);
+      double v = 0.0;
+      if (MODE != 0) v = on ? vc[q] : 0.0;
       const double* xr = Xl + (long long)col * r + c0 * VEC;
 #pragma unroll
       for (int c = 0; c < NCH; c++) {
         const vecd<VEC> x = ldrow<VEC>(xr + c * VEC);
 #pragma unroll
-        for (int qq = 0; qq < VEC; qq++) w[c].v[qq] += x.v[qq] * v;
+        for (int qq = 0; qq < VEC; qq++) {
+          if (MODE == 0) w[c].v[qq] += x.v[qq];
+          else w[c].v[qq] += x.v[qq] * v;
+        }
       }
       // (entries are consumed two at a time: left to itself the scheduler hoists the LDS reads of all PF entries —
       // PF·NCH·VEC doubles of registers — and the kernel spills)
@@ -158,7 +167,10 @@ __device__ __forceinline__ void rs_ell_pass(const unsigned* __restrict__ ep, con
   for (int c = 0; c < NCH; c++) {
     const vecd<VEC> x = ldrow<VEC>(xj + c * VEC);
 #pragma unroll
-    for (int q = 0; q < VEC; q++) w[c].v[q] += x.v[q] * gd;
+    for (int q = 0; q < VEC; q++) {
+      if (MODE == 0) w[c].v[q] *= one;
+      w[c].v[q] += x.v[q] * gd;
+    }
   }
 }
 // Y = X·A_g for all rows, chunks [c0, c0 + NCH): one slice per wave and trip; Y row-major like every factor-shaped array
@@ -195,7 +207,7 @@ __device__ __forceinline__ void rs_ell_spmm_chunks(const RsEll& E, const double*
       for (int c = 0; c < NCH; c++) xr[c] = ldrow<VEC>(dots.R + (long long)j * r + (c0 + c) * VEC);
     }
     vecd<VEC> w[NCH];
-    rs_ell_pass<VEC, MODE, NCH>(ep, vp, width, len, one, Xl, r, c0, j, gd, w);
+    rs_ell_pass<VEC, MODE, NCH>(ep, vp, width, len, one, Xl, r, c0, j, gd, n, w);
     if (DOTS && !EARLY) {
 #pragma unroll
       for (int c = 0; c < NCH; c++) xr[c] = ldrow<VEC>(dots.R + (long long)j * r + (c0 + c) * VEC);
@@ -402,7 +414,8 @@ __device__ __forceinline__ void rs_fg_run(const RsFgArgs& a) {
   __shared__ double sred[3 * SDPLR_RS_NW];
   __shared__ RsFgShared sh;
   const long long N = (long long)a.n * a.r;
-  const long long Npad = (N + 1) & ~1LL;
+  const long long Npad = rs_npad(a.n, a.r);
+  for (long long e = N + threadIdx.x; e < Npad; e += SDPLR_RS_NT) rs_lds[e] = 0.0;   // (the SpMM's zero row)
   if (a.in_set) {
     if (threadIdx.x == 0) {   // (set_norm_params of the single-instance entry point)
       a.c->normC = a.in_normC; a.c->normb = a.in_normb; a.c->grel = a.in_grel; a.c->prel = a.in_prel;
@@ -484,8 +497,9 @@ __device__ __forceinline__ void rs_loop_run(const RsLoopArgs& a) {
   int tid = tid0, grp = tid / LPR, lane = tid % LPR;
   const int n = a.n, m = a.m, r = a.r, h = a.h;
   const long long N = (long long)n * r;
-  const long long Npad = (N + 1) & ~1LL;
-  double* Dl = rs_lds;                 // [Npad] the direction (or R while P is being refreshed)
+  const long long Npad = rs_npad(n, r);
+  double* Dl = rs_lds;                 // [Npad] the direction (or R while P is being refreshed), then the zero row
+  for (long long e = N + threadIdx.x; e < Npad; e += SDPLR_RS_NT) Dl[e] = 0.0;
   double* rdl = Dl + Npad;             // [n] ⟨R_j, D_j⟩
   double* ddl = rdl + n;               // [n] ‖D_j‖²
   double* djl = ddl + n;               // [n] d_j = v_j·y[k_j]

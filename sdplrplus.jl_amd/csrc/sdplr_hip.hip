@@ -639,9 +639,8 @@ int sync_check(S* s) {
 
 // dynamic LDS the resident loop needs (k_resident.h) and its budget; tiles_can_wait: "small enough for that route"
 constexpr size_t RS_LDS_MAX = 150 * 1024;   // dynamic LDS of a resident kernel (≈ 9.6 KB more are static: control block, reduction scratch)
-size_t rs_loop_lds(const S* s) {
-  const size_t N = (size_t)s->n * (size_t)s->r;
-  return (((N + 1) & ~(size_t)1) + 3 * (size_t)s->n) * sizeof(double);
+size_t rs_loop_lds(const S* s) {   // D (with the SpMM's zero row) | ⟨R_j,D_j⟩ | ‖D_j‖² | d_j
+  return ((size_t)rs_npad(s->n, s->r) + 3 * (size_t)s->n) * sizeof(double);
 }
 bool tiles_can_wait(const S* s) {
   return !s->force_graph && getenv("SDPLR_HIP_NO_RESIDENT") == nullptr && rs_loop_lds(s) <= RS_LDS_MAX;
