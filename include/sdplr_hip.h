@@ -292,6 +292,7 @@ typedef struct sdplr_hip_dual_item {          /* sdplr_hip_dual_obj */
   double trace_bound;
   int64_t iter;
   const double* v0;                           /* [n of that instance] */
+  double* y_out;                              /* NULL, or [m+1]: var.y as dual_obj leaves it (−λ of the bound, src/sdplr.jl:325) */
   double dual_value, mineig;                  /* out */
   int32_t status;
 } sdplr_hip_dual_item;

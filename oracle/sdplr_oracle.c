@@ -1368,6 +1368,7 @@ int32_t sdplr_oracle_batch_dual_obj(int32_t count, sdplr_oracle_dual_item* it) {
   for (int32_t i = 0; i < count; i++) {
     sdplr_oracle_dual_item* q = &it[i];
     q->status = sdplr_oracle_dual_obj(q->s, q->trace_bound, q->iter, q->v0, &q->dual_value, &q->mineig);
+    if (!q->status && q->y_out) q->status = sdplr_oracle_get_vec(q->s, V_Y, q->y_out, q->s->m + 1);
     if (q->status && !first) first = q->status;
   }
   return first;

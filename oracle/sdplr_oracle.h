@@ -94,6 +94,7 @@ typedef struct sdplr_oracle_dual_item {
   double trace_bound;
   int64_t iter;
   const double* v0;
+  double* y_out;
   double dual_value, mineig;
   int32_t status;
 } sdplr_oracle_dual_item;

@@ -49,8 +49,8 @@ class MajorItem(C.Structure):         # sdplr_hip_major_item
 
 
 class DualItem(C.Structure):          # sdplr_hip_dual_item
-    _fields_ = [("s", _vp), ("trace_bound", _f64), ("iter", _i64), ("v0", _pf64), ("dual_value", _f64),
-                ("mineig", _f64), ("status", _i32)]
+    _fields_ = [("s", _vp), ("trace_bound", _f64), ("iter", _i64), ("v0", _pf64), ("y_out", _pf64),
+                ("dual_value", _f64), ("mineig", _f64), ("status", _i32)]
 
 
 # name → argtypes (restype is int32 unless listed in _RESTYPES); this table IS the header, and
@@ -566,16 +566,19 @@ def batch_major_iteration(abi: CABI, solvers, args):
 
 
 def batch_dual_obj(abi: CABI, solvers, args):
-    """``dual_obj`` of every solver in one call; args[k] = (trace_bound, iter, v0) → per solver (dual_value, λ_min)."""
+    """``dual_obj`` of every solver in one call; args[k] = (trace_bound, iter, v0) → per solver (dual_value, λ_min, y):
+    ``var.y`` as dual_obj leaves it comes back with the results (one transfer for the whole batch)."""
     arr = (DualItem * len(solvers))()
-    keep = []
+    keep, ys = [], []
     for k, (sv, a) in enumerate(zip(solvers, args)):
         v0 = _f64c(a[2])
         if v0.size != sv.n:
             raise ValueError("v0 must have length n")
         keep.append(v0)
+        ys.append(np.empty(sv.m + 1))
         it = arr[k]
         it.s = sv._h.value
-        it.trace_bound, it.iter, it.v0 = float(a[0]), int(a[1]), _pd(v0)
+        it.trace_bound, it.iter, it.v0, it.y_out = float(a[0]), int(a[1]), _pd(v0), _pd(ys[k])
     abi.batch_dual_obj(len(solvers), arr)
-    return _batch_results(abi, arr, solvers, lambda q: (q.dual_value, q.mineig))
+    out = _batch_results(abi, arr, solvers, lambda q: (q.dual_value, q.mineig))
+    return [o if isinstance(o, Exception) else o + (ys[k],) for k, o in enumerate(out)]

@@ -1078,6 +1078,7 @@ struct RsLzEllArgs {
   double* y_rw;
   const double *lam, *lam_ub, *pv_raw, *b;
   double* out;                          // batched launches: [3] smallest eigenvalue, ⟨y, b⟩, steps
+  double* y_copy;                       // batched launches: y as copy2y leaves it, once more ([m+1], or null) — the result table's
 };
 // number of eigenvalues of SymTridiagonal(d, e) below x (Sturm count), d = alpha + 1
 __device__ __forceinline__ int rs_sturm_below(const double* al, const double* be, int k, double x) {
@@ -1116,8 +1117,11 @@ __device__ __forceinline__ void rs_lanczos_ell_run(const RsLzEllArgs& a) {
   };
   if (a.dual) {   // copy2y_λ_sub_pvio!  src/coreop.jl:229-236
     const double sigma = a.c->sigma;
-    for (int i = tid; i <= a.m; i += NT)
-      a.y_rw[i] = (i == a.m) ? 1.0 : -fmin(a.lam_ub[i], a.lam[i] - sigma * a.pv_raw[i]);
+    for (int i = tid; i <= a.m; i += NT) {
+      const double yi = (i == a.m) ? 1.0 : -fmin(a.lam_ub[i], a.lam[i] - sigma * a.pv_raw[i]);
+      a.y_rw[i] = yi;
+      if (a.y_copy != nullptr) a.y_copy[i] = yi;
+    }
     __syncthreads();
   }
   const double yg = a.yvec[a.gid_g];

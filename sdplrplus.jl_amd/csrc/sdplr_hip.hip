@@ -3969,7 +3969,8 @@ int32_t sdplr_hip_batch_dual_obj(int32_t count, sdplr_hip_dual_item* it) {
         // rows [lo, hi): table + result rows + the start vectors fit one staging block
         size_t hi = lo, bytes = 0;
         while (hi < idx.size()) {
-          const size_t add = batch_up(sizeof(RsLzEllArgs)) + 64 + batch_up((size_t)it[idx[hi]].s->n * sizeof(double));
+          const size_t add = batch_up(sizeof(RsLzEllArgs)) + 64 + batch_up((size_t)it[idx[hi]].s->n * sizeof(double)) +
+                             (it[idx[hi]].y_out ? batch_up((size_t)(it[idx[hi]].s->m + 1) * sizeof(double)) : 0);
           if (hi > lo && bytes + add + 2 * BATCH_ALIGN > ARENA_CHUNK) break;
           bytes += add;
           hi++;
@@ -3994,6 +3995,15 @@ int32_t sdplr_hip_batch_dual_obj(int32_t count, sdplr_hip_dual_item* it) {
           v0_off += batch_up((size_t)sk->n * sizeof(double));
         }
         const size_t res_off = v0_off;
+        // behind the result rows: the copies of y for the items that ask for them (they come back in the same transfer)
+        size_t y_off = res_off + batch_up(nb * 4 * sizeof(double));
+        std::vector<size_t> y_at(nb, 0);
+        for (size_t k = 0; k < nb; k++)
+          if (it[idx[lo + k]].y_out) {
+            y_at[k] = y_off;
+            y_off += batch_up((size_t)(it[idx[lo + k]].s->m + 1) * sizeof(double));
+          }
+        const size_t back_bytes = y_off - res_off;
         for (size_t k = 0; k < nb && !rc; k++) {
           const sdplr_hip_dual_item& q = it[idx[lo + k]];
           S* sk = q.s;
@@ -4005,6 +4015,7 @@ int32_t sdplr_hip_batch_dual_obj(int32_t count, sdplr_hip_dual_item* it) {
           RsLzEllArgs a = rs_lz_ell_args(sk, steps, true);
           a.v0 = reinterpret_cast<const double*>(bb.dev + v0_at[k]);
           a.out = reinterpret_cast<double*>(bb.dev + res_off) + 4 * k;
+          a.y_copy = q.y_out ? reinterpret_cast<double*>(bb.dev + y_at[k]) : nullptr;
           tab[k] = a;
           bool in_lds = false;
           lds = std::max(lds, rs_lz_ell_lds(sk, &in_lds));
@@ -4012,7 +4023,7 @@ int32_t sdplr_hip_batch_dual_obj(int32_t count, sdplr_hip_dual_item* it) {
         if (!rc) {
           const RsLzEllArgs* dtab = reinterpret_cast<const RsLzEllArgs*>(bb.dev);
           const bool in_lds = g.first == 1;
-          rc = batch_round_trip(s, bb, res_off, res_off, nb * 4 * sizeof(double), [&](hipStream_t st) {
+          rc = batch_round_trip(s, bb, res_off, res_off, back_bytes, [&](hipStream_t st) {
             if (in_lds) {
               RS_SET_ATTR(k_rs_lanczos_ell_batch<true>);
               k_rs_lanczos_ell_batch<true><<<(int)nb, SDPLR_RS_NT, lds, st>>>(dtab);
@@ -4033,6 +4044,7 @@ int32_t sdplr_hip_batch_dual_obj(int32_t count, sdplr_hip_dual_item* it) {
           const double ev = res[4 * k], yb = res[4 * k + 1];
           q.mineig = ev;
           q.dual_value = -yb + q.trace_bound * std::min(ev, 0.0);                                   // :412
+          if (q.y_out) memcpy(q.y_out, bb.host + y_at[k], (size_t)(sk->m + 1) * sizeof(double));
         }
         lo = hi;
       }
@@ -4042,6 +4054,7 @@ int32_t sdplr_hip_batch_dual_obj(int32_t count, sdplr_hip_dual_item* it) {
     sdplr_hip_dual_item& q = it[i];
     if (!q.s) { q.status = SDPLR_ERR_INVALID_ARG; return; }
     q.status = sdplr_hip_dual_obj(q.s, q.trace_bound, q.iter, q.v0, &q.dual_value, &q.mineig);
+    if (!q.status && q.y_out) q.status = sdplr_hip_get_vec(q.s, SDPLR_V_Y, q.y_out, q.s->m + 1);
   });
   for (int i = 0; i < count; i++) if (it[i].status) return it[i].status;
   return SDPLR_OK;

@@ -144,7 +144,7 @@ def serve(var: DeviceSolver, req: tuple) -> tuple:
     if kind == REQ_INNER:
         return var.inner_loop(*args) + (var.obj,)
     if kind == REQ_DUAL:
-        return var.dual_obj(*args)
+        return var.dual_obj(*args) + (None,)      # (third: var.y if the driver already has it — the batched call does)
     raise ValueError(kind)
 
 
@@ -195,7 +195,7 @@ def sdplr_steps(data: SDPData, var: DeviceSolver, config: BurerMonteiroConfig, n
     duality_gap = 1e20
     min_duality_gap = 1e20
     max_dual_value = -1e20
-    best_λ = var.λ.copy()
+    best_λ = np.array(λ0, dtype=np.float64, copy=True)     # (= var.λ: the point has just been loaded)
     rng = _rng(config)
 
     schedule = []   # per major iteration: (majoriter, inner iterations, σ, η, ω, rank) — what printintermediate shows (src/myprint.jl:17-58)
@@ -264,6 +264,7 @@ def sdplr_steps(data: SDPData, var: DeviceSolver, config: BurerMonteiroConfig, n
         if primal_vio_norm <= cur_ptol:                         # :310
             t0 = time.time()
             v0 = rng.standard_normal(n)                         # replaces randn, coreop.jl:473
+            y_now = None
             if config.eigval_highprecision:                     # coreop.jl:389-400
                 var.y = np.concatenate([-np.minimum(var.λ_ub, var.λ - σ_now * var.primal_vio_raw[:m]), [1.0]])
                 var.At_preprocess()
@@ -271,9 +272,9 @@ def sdplr_steps(data: SDPData, var: DeviceSolver, config: BurerMonteiroConfig, n
                                   v0=v0)[0]
                 dual_value = float(-(var.y[:m] @ data.b) + config.prior_trace_bound * min(ev, 0.0))
             else:
-                dual_value, _ = yield (REQ_DUAL, config.prior_trace_bound, iter_, v0)     # :314
+                dual_value, _, y_now = yield (REQ_DUAL, config.prior_trace_bound, iter_, v0)     # :314
             if dual_value > max_dual_value:                     # :324-327
-                best_λ = -var.y
+                best_λ = -(y_now if y_now is not None else var.y)
                 max_dual_value = dual_value
             if config.objtol_mode == "relative":                # :328-332
                 denom = min(abs(obj), abs(max_dual_value))

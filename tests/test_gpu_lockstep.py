@@ -59,7 +59,9 @@ def test_batch_calls_equal_the_single_calls_bit_for_bit(hip_abi):
         v0s = [rng.standard_normal(d.n) for d in datas]
         da = cabi.batch_dual_obj(hip_abi, A, [(float(d.n), 50 * (rnd + 1), v) for d, v in zip(datas, v0s)])
         db = [s.dual_obj(float(d.n), 50 * (rnd + 1), v) for s, d, v in zip(B, datas, v0s)]
-        assert da == db, rnd
+        assert [x[:2] for x in da] == db, rnd
+        for x, s in zip(da, B):               # (var.y comes back with the batch's results)
+            assert np.array_equal(x[2], s.y)
     for a, b in zip(A, B):
         for name in ("Rt", "Gt", "dirt", "y", "λ", "primal_vio_raw"):
             assert np.array_equal(getattr(a, name), getattr(b, name)), name
@@ -93,8 +95,10 @@ def test_batch_of_mixed_routes_and_shapes(hip_abi, oracle_abi, monkeypatch):
     args = [(nc, nb, 1, 1, int(d.has_inequalities), 1, 3.0, 1e-2, 1e-30, 12, 0.0) for d, (nc, nb) in zip(datas, norms)]
     assert cabi.batch_major_iteration(hip_abi, A, args) == [s.major_iteration(*a) + (s.obj,) for s, a in zip(B, args)]
     v0s = [np.random.default_rng(k).standard_normal(d.n) for k, d in enumerate(datas)]
-    assert cabi.batch_dual_obj(hip_abi, A, [(float(d.n), 100, v) for d, v in zip(datas, v0s)]) == \
-        [s.dual_obj(float(d.n), 100, v) for s, d, v in zip(B, datas, v0s)]
+    da = cabi.batch_dual_obj(hip_abi, A, [(float(d.n), 100, v) for d, v in zip(datas, v0s)])
+    assert [x[:2] for x in da] == [s.dual_obj(float(d.n), 100, v) for s, d, v in zip(B, datas, v0s)]
+    for x, s in zip(da, B):
+        assert np.array_equal(x[2], s.y)
     shared = [s.stats()["resident_shared_launches"] for s in A]
     assert shared[:4] == [3, 3, 3, 3] and shared[4] == 0
     # … and against the oracle, to the resident route's tolerances
