@@ -177,7 +177,13 @@ class SDPData:
         return cls(C, None, b, constraint_types, _prebuilt=(sparse, lowrank))
 
     def normC(self) -> float:
-        """``norm(C, 2)`` (src/sdplr.jl:160): Frobenius norm."""
+        """``norm(C, 2)`` (src/sdplr.jl:160): Frobenius norm (computed once per SDPData: C does not change)."""
+        cached = getattr(self, "_normC", None)
+        if cached is None:
+            cached = self._normC = self._compute_normC()
+        return cached
+
+    def _compute_normC(self) -> float:
         if isinstance(self.C, SymLowRankMatrix):
             return self.C.norm(2)
         if isinstance(self.C, Diagonal):
