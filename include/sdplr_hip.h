@@ -258,7 +258,8 @@ int32_t sdplr_hip_dual_obj(sdplr_hip_solver* s, double trace_bound, int64_t iter
 /* ---- many small instances in lockstep: one launch for a whole batch ------------------------------------------------
  * The reference runs exps/batch_test.txt as independent sdplr() calls (exps/exp.jl:18-72).  A driver that advances B such
  * solves side by side hands the SAME step of all of them to the library as one call: the instances on the resident route
- * (one workgroup owns a small instance) that share a kernel shape go out as ONE launch with one workgroup per instance
+ * (one workgroup owns a small instance) that share a kernel shape (even ranks / odd ranks) go out as ONE launch with one
+ * workgroup per instance
  * — B CUs busy from one stream, one argument table up, one result table back — and every other instance of the batch is
  * served by the single-instance entry point named in each struct (on a few host threads of the library's own, each handle
  * on its stream), so the call is total.  Each item is exactly the

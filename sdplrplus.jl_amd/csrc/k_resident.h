@@ -301,36 +301,24 @@ struct RsFgShared {
   double yg, obj_row;
   int has_obj_row;
 };
-template <int LPR, int VEC>
+template <int VEC>
 __device__ __forceinline__ void rs_fg_body(const RsFgArgs& a, DevCtrl& c, double* Rl, double* rrl, double* djl, double* sred,
                                            RsFgShared& sh) {
-  constexpr int NT = SDPLR_RS_NT, G = NT / LPR;
-  const int tid = threadIdx.x, grp = tid / LPR, lane = tid % LPR;
+  constexpr int NT = SDPLR_RS_NT;
+  const int tid = threadIdx.x;
   const int n = a.n, m = a.m, r = a.r;
   const long long N = (long long)n * r;
-  const int ch0 = lane * VEC;
-  const bool act = ch0 < r;
   const double sigma = c.sigma, normC = c.normC, normb = c.normb;
   const int grel = c.grel, prel = c.prel;
   if (tid == 0) sh.has_obj_row = 0;
   for (long long e = tid; e < N; e += NT) Rl[e] = a.R[e];
   __syncthreads();
-  rs_ell_spmm_any<VEC>(a.E, Rl, n, r, a.P);     // P = A_g·R
-  __syncthreads();
+  // P = A_g·R; the lane that owns row j forms ‖R_j‖² (→ rrl) and its part of ⟨R, P⟩ while P_j is in its registers
   double acc[3] = {0.0, 0.0, 0.0};   // ⟨R, P⟩
-#pragma nounroll
-  for (int j = grp; j < n; j += G) {
-    double rr = 0.0;
-    if (act) {
-      const vecd<VEC> x = ldrow<VEC>(Rl + (long long)j * r + ch0), p = ldrow<VEC>(a.P + (long long)j * r + ch0);
-#pragma unroll
-      for (int k = 0; k < VEC; k++) {
-        rr += x.v[k] * x.v[k];
-        acc[0] += x.v[k] * p.v[k];
-      }
-    }
-    rr = group_sum<LPR>(rr);
-    if (lane == 0) rrl[j] = rr;
+  {
+    const RsDots dots{Rl, rrl, djl};   // (djl: scratch for the second, identical, row sum — rewritten below)
+    double same = 0.0;
+    rs_ell_spmm_dots<VEC>(a.E, Rl, n, r, a.P, dots, acc[0], same);
   }
   rs_sum_to0<1>(reinterpret_cast<double(&)[1]>(acc[0]), sred);
   __syncthreads();
@@ -382,12 +370,18 @@ __device__ __forceinline__ void rs_fg_body(const RsFgArgs& a, DevCtrl& c, double
   __syncthreads();
   const double yg = sh.yg;
   double gn = 0.0;
+  {   // element by element in units of VEC doubles; the row of a unit — for d_j — advances with it
+    const long long U = N / VEC;
+    const int adv = NT * VEC, adv_q = adv / r, adv_r = adv % r;
+    int j = (tid * VEC) / r, ch = (tid * VEC) % r;
 #pragma nounroll
-  for (int j = grp; j < n; j += G) {
-    if (act) {
-      const long long e = (long long)j * r + ch0;
+    for (long long u = tid; u < U; u += NT) {
+      const long long e = u * VEC;
       const vecd<VEC> x = ldrow<VEC>(Rl + e), p = ldrow<VEC>(a.P + e);
       const double dj = djl[j];
+      ch += adv_r;
+      j += adv_q;
+      if (ch >= r) { ch -= r; j++; }
       vecd<VEC> g;
 #pragma unroll
       for (int k = 0; k < VEC; k++) {
@@ -410,7 +404,7 @@ __device__ __forceinline__ void rs_fg_body(const RsFgArgs& a, DevCtrl& c, double
   }
   __syncthreads();
 }
-template <int LPR, int VEC>
+template <int VEC>
 __device__ __forceinline__ void rs_fg_run(const RsFgArgs& a) {
   extern __shared__ __attribute__((aligned(16))) double rs_lds[];
   __shared__ double sred[3 * SDPLR_RS_NW];
@@ -425,20 +419,20 @@ __device__ __forceinline__ void rs_fg_run(const RsFgArgs& a) {
     }
     __syncthreads();
   }
-  rs_fg_body<LPR, VEC>(a, *a.c, rs_lds, rs_lds + Npad, rs_lds + Npad + a.n, sred, sh);
+  rs_fg_body<VEC>(a, *a.c, rs_lds, rs_lds + Npad, rs_lds + Npad + a.n, sred, sh);
   if (a.out != nullptr && threadIdx.x == 0) {
     a.out[0] = a.c->L; a.out[1] = a.c->gnorm; a.out[2] = a.c->pvnorm; a.out[3] = a.c->obj;
   }
 }
-template <int LPR, int VEC>
+template <int VEC>
 __global__ void __launch_bounds__(SDPLR_RS_NT)
-k_rs_fg(RsFgArgs a) { rs_fg_run<LPR, VEC>(a); }
+k_rs_fg(RsFgArgs a) { rs_fg_run<VEC>(a); }
 // one workgroup per instance: block b takes row b of the argument table
-template <int LPR, int VEC>
+template <int VEC>
 __global__ void __launch_bounds__(SDPLR_RS_NT)
 k_rs_fg_batch(const RsFgArgs* __restrict__ items) {
   const RsFgArgs a = items[blockIdx.x];
-  rs_fg_run<LPR, VEC>(a);
+  rs_fg_run<VEC>(a);
 }
 
 struct RsLoopArgs {
@@ -485,7 +479,7 @@ __device__ __forceinline__ RsRow rs_load_row(const RsLoopArgs& a, int j) {
   return o;
 }
 
-template <int LPR, int VEC, int HM>
+template <int VEC, int HM>
 __device__ __forceinline__ void rs_loop_run(const RsLoopArgs& a) {
   extern __shared__ __attribute__((aligned(16))) double rs_lds[];   // (16-byte LDS reads: an 8-byte-aligned base behind the static LDS made every ds_read_b128 a misaligned access — 5× slower)
   __shared__ SeamLds gd;
@@ -494,9 +488,9 @@ __device__ __forceinline__ void rs_loop_run(const RsLoopArgs& a) {
   __shared__ int sh_err, sh_upd;
   static_assert(sizeof(SeamLds) + sizeof(double) * ((5 * HM + 2 > 10 ? 5 * HM + 2 : 10) * SDPLR_RS_NW + 8) <= 10 * 1024,
                 "static LDS of the resident loop: the host budgets 150 KB of dynamic LDS next to it");
-  constexpr int NT = SDPLR_RS_NT, G = NT / LPR;
+  constexpr int NT = SDPLR_RS_NT;
   const int tid0 = threadIdx.x;
-  int tid = tid0, grp = tid / LPR, lane = tid % LPR;
+  int tid = tid0;
   const int n = a.n, m = a.m, r = a.r, h = a.h;
   const long long N = (long long)n * r;
   const long long Npad = rs_npad(n, r);
@@ -505,8 +499,6 @@ __device__ __forceinline__ void rs_loop_run(const RsLoopArgs& a) {
   double* rdl = Dl + Npad;             // [n] ⟨R_j, D_j⟩
   double* ddl = rdl + n;               // [n] ‖D_j‖²
   double* djl = ddl + n;               // [n] d_j = v_j·y[k_j]
-  int ch0 = lane * VEC;
-  bool act = ch0 < r;
   double* const R = aslot(a.A, AS_R);
   double* const Gm = aslot(a.A, AS_G);
   // the control block → LDS (one coalesced load)
@@ -552,7 +544,7 @@ __device__ __forceinline__ void rs_loop_run(const RsLoopArgs& a) {
       f.n = n; f.m = m; f.r = r; f.gid_g = a.gid_g; f.row_k = a.row_k; f.row_v = a.row_v; f.E = a.E;
       f.R = R; f.G = Gm; f.P = a.P; f.y = a.y; f.pv_raw = a.pv_raw; f.pv = a.pv;
       f.lam = a.lam; f.lam_ub = a.lam_ub; f.lb = a.lb; f.b = a.b; f.c = a.c;
-      rs_fg_body<LPR, VEC>(f, gd.c, Dl, rdl, djl, sred, fsh);
+      rs_fg_body<VEC>(f, gd.c, Dl, rdl, djl, sred, fsh);
     }
   }
   // constraint data of this thread's rows: constant over the call except primal_vio_raw, which the thread owns
@@ -583,10 +575,6 @@ __device__ __forceinline__ void rs_loop_run(const RsLoopArgs& a) {
     // 116 bytes of scratch per lane without this, 217 and none with it)
     tid = tid0;
     asm volatile("" : "+v"(tid));
-    grp = tid / LPR;
-    lane = tid % LPR;
-    ch0 = lane * VEC;
-    act = ch0 < r;
     // ================= SEAM =================
     // (the Gram sums and the norms of the iteration that just ended were folded into gd.red / gd.nrm by STEP)
     if (tid == 0) {
@@ -937,16 +925,16 @@ __device__ __forceinline__ void rs_loop_run(const RsLoopArgs& a) {
     a.out[5] = (double)c.iters; a.out[6] = (double)c.exit_reason; a.out[7] = (double)c.err;
   }
 }
-template <int LPR, int VEC, int HM>
+template <int VEC, int HM>
 __global__ void __launch_bounds__(SDPLR_RS_NT)
-k_rs_loop(RsLoopArgs a) { rs_loop_run<LPR, VEC, HM>(a); }
+k_rs_loop(RsLoopArgs a) { rs_loop_run<VEC, HM>(a); }
 // one workgroup per instance: block b takes row b of the argument table (64 small instances: one launch on 64 CUs instead
 // of 64 launches that share the device only as far as the hardware queues allow)
-template <int LPR, int VEC, int HM>
+template <int VEC, int HM>
 __global__ void __launch_bounds__(SDPLR_RS_NT)
 k_rs_loop_batch(const RsLoopArgs* __restrict__ items) {
   const RsLoopArgs a = items[blockIdx.x];
-  rs_loop_run<LPR, VEC, HM>(a);
+  rs_loop_run<VEC, HM>(a);
 }
 
 // ---- approx_mineigval_lanczos's recurrence (src/coreop.jl:473-500) in one launch -----------------------------------

@@ -2519,7 +2519,7 @@ double wall_clock_hz() {   // rate of wall_clock64() on this device
 // SDPLR_HIP_FORCE_GRAPH ("treat this instance as a large one": the tests' default) and SDPLR_HIP_NO_RESIDENT keep an
 // instance on the multi-launch routes.
 bool rs_loop_applies(const S* s, int armijo) {
-  if (!s->rs_ok || armijo || s->h < 1 || s->h > 4 || s->r > (int64_t)s->LPR * s->VEC || s->prof_on) return false;
+  if (!s->rs_ok || armijo || s->h < 1 || s->h > 4 || s->prof_on) return false;
   if (s->force_graph || getenv("SDPLR_HIP_NO_RESIDENT") != nullptr) return false;
   return rs_loop_lds(s) <= RS_LDS_MAX;
 }
@@ -2530,7 +2530,7 @@ bool rs_lanczos_ell_applies(const S* s) {
   return (size_t)4 * s->n * sizeof(double) <= RS_LDS_MAX;
 }
 bool rs_fg_applies(const S* s) {
-  if (!s->rs_ok || s->r > (int64_t)s->LPR * s->VEC || s->prof_on) return false;
+  if (!s->rs_ok || s->prof_on) return false;
   if (s->force_graph || getenv("SDPLR_HIP_NO_RESIDENT") != nullptr) return false;
   return rs_loop_lds(s) <= RS_LDS_MAX;
 }
@@ -2541,6 +2541,11 @@ bool rs_lanczos_applies(const S* s) {
   if (const char* e = getenv("SDPLR_HIP_RESIDENT_LZ_NNZ")) max_nnz = atoll(e);
   return s->nnzS <= max_nnz && (size_t)3 * s->n * sizeof(double) <= RS_LDS_MAX;
 }
+// the resident kernels come in two shapes: 16-byte pieces of a row (even ranks) or 8-byte ones
+#define RS_VEC_DISPATCH(s_, CALL)                                  \
+  if ((s_)->r % 2 == 0) { constexpr int VEC = 2; CALL; }           \
+  else { constexpr int VEC = 1; CALL; }
+inline int rs_vec(const S* s) { return s->r % 2 == 0 ? 2 : 1; }
 // more than 64 KB of dynamic LDS has to be asked for: a per-function, process-wide attribute — set once per
 // instantiation, to the fixed upper bound
 #define RS_SET_ATTR(kernel)                                                                                          \
@@ -2587,7 +2592,7 @@ int enq_resident_loop(S* s, double time_budget_s, bool refresh_P, bool pre_lambd
   RsLoopArgs a = rs_loop_args(s, time_budget_s, refresh_P, pre_lambda, pre_clear_fg);
   if (in) rs_loop_set_in(a, *in);
   const size_t lds = rs_loop_lds(s);
-  LV_DISPATCH(({ RS_SET_ATTR((k_rs_loop<LPR, VEC, 4>)); k_rs_loop<LPR, VEC, 4><<<1, SDPLR_RS_NT, lds, s->stream>>>(a); }))
+  RS_VEC_DISPATCH(s, ({ RS_SET_ATTR((k_rs_loop<VEC, 4>)); k_rs_loop<VEC, 4><<<1, SDPLR_RS_NT, lds, s->stream>>>(a); }))
   HIPCK(s, hipGetLastError());
   s->st_rs_loops++;
   return SDPLR_OK;
@@ -3035,7 +3040,7 @@ int32_t sdplr_hip_fg(S* s, double normC, double normb, int32_t grel, int32_t pre
   if (rs_fg_applies(s)) {   // resident route (k_resident.h): one launch; P = A_g·R stays for the loop that follows
     const RsFgArgs a = rs_fg_args(s);
     const size_t lds = rs_loop_lds(s);
-    LV_DISPATCH(({ RS_SET_ATTR((k_rs_fg<LPR, VEC>)); k_rs_fg<LPR, VEC><<<1, SDPLR_RS_NT, lds, s->stream>>>(a); }))
+    RS_VEC_DISPATCH(s, ({ RS_SET_ATTR((k_rs_fg<VEC>)); k_rs_fg<VEC><<<1, SDPLR_RS_NT, lds, s->stream>>>(a); }))
     HIPCK(s, hipGetLastError());
     s->P_valid = true;
     s->P_age = 0;
@@ -3736,7 +3741,7 @@ struct BatchBuf {   // one pinned block + one device block of ARENA_CHUNK bytes 
 };
 constexpr size_t BATCH_ALIGN = 256;
 size_t batch_up(size_t x) { return (x + BATCH_ALIGN - 1) & ~(BATCH_ALIGN - 1); }
-using ShapeKey = std::pair<int, int>;   // (LPR, VEC) — with ELL_LDS folded into the first for the Lanczos kernels
+using ShapeKey = std::pair<int, int>;   // (0, bytes per piece of a row / 8): the two shapes of the resident kernels
 
 bool batch_handles_distinct(const std::vector<const S*>& hs) {
   std::vector<const S*> v;
@@ -3796,7 +3801,7 @@ int32_t sdplr_hip_batch_fg(int32_t count, sdplr_hip_fg_item* it) {
     for (int i = 0; i < count; i++) {
       S* s = it[i].s;
       it[i].status = SDPLR_OK;
-      if (s && s->finalized && rs_fg_applies(s)) groups[{s->LPR, s->VEC}].push_back(i);
+      if (s && s->finalized && rs_fg_applies(s)) groups[{0, rs_vec(s)}].push_back(i);
       else single.push_back(i);
     }
     const size_t max_rows = ARENA_CHUNK / (batch_up(sizeof(RsFgArgs)) + 64);
@@ -3805,7 +3810,7 @@ int32_t sdplr_hip_batch_fg(int32_t count, sdplr_hip_fg_item* it) {
       if (idx.size() < 2) { single.insert(single.end(), idx.begin(), idx.end()); continue; }
       for (size_t lo = 0; lo < idx.size(); lo += max_rows) {
         const size_t nb = std::min(max_rows, idx.size() - lo);
-        S* s = it[idx[lo]].s;   // (the shape all rows share: LV_DISPATCH reads s->LPR / s->VEC)
+        S* s = it[idx[lo]].s;   // (the shape all rows share: RS_VEC_DISPATCH reads the parity of s->r)
         BatchBuf bb;
         if (bb.init() != hipSuccess) {
           for (size_t k = 0; k < nb; k++) it[idx[lo + k]].status = SDPLR_ERR_ALLOC;
@@ -3826,7 +3831,7 @@ int32_t sdplr_hip_batch_fg(int32_t count, sdplr_hip_fg_item* it) {
         }
         const RsFgArgs* dtab = reinterpret_cast<const RsFgArgs*>(bb.dev);
         int rc = batch_round_trip(s, bb, nb * sizeof(RsFgArgs), res_off, nb * 4 * sizeof(double), [&](hipStream_t st) {
-          LV_DISPATCH(({ RS_SET_ATTR((k_rs_fg_batch<LPR, VEC>)); k_rs_fg_batch<LPR, VEC><<<(int)nb, SDPLR_RS_NT, lds, st>>>(dtab); }))
+          RS_VEC_DISPATCH(s, ({ RS_SET_ATTR((k_rs_fg_batch<VEC>)); k_rs_fg_batch<VEC><<<(int)nb, SDPLR_RS_NT, lds, st>>>(dtab); }))
         });
         const double* res = reinterpret_cast<const double*>(bb.host + res_off);
         for (size_t k = 0; k < nb; k++) {
@@ -3864,7 +3869,7 @@ int32_t sdplr_hip_batch_major_iteration(int32_t count, sdplr_hip_major_item* it)
       S* s = it[i].s;
       it[i].status = SDPLR_OK;
       if (s && s->finalized && it[i].max_local_iters >= 1 && rs_loop_applies(s, it[i].use_armijo) && rs_fg_applies(s))
-        groups[{s->LPR, s->VEC}].push_back(i);
+        groups[{0, rs_vec(s)}].push_back(i);
       else
         single.push_back(i);
     }
@@ -3899,7 +3904,7 @@ int32_t sdplr_hip_batch_major_iteration(int32_t count, sdplr_hip_major_item* it)
         }
         const RsLoopArgs* dtab = reinterpret_cast<const RsLoopArgs*>(bb.dev);
         int rc = batch_round_trip(s, bb, nb * sizeof(RsLoopArgs), res_off, nb * 8 * sizeof(double), [&](hipStream_t st) {
-          LV_DISPATCH(({ RS_SET_ATTR((k_rs_loop_batch<LPR, VEC, 4>)); k_rs_loop_batch<LPR, VEC, 4><<<(int)nb, SDPLR_RS_NT, lds, st>>>(dtab); }))
+          RS_VEC_DISPATCH(s, ({ RS_SET_ATTR((k_rs_loop_batch<VEC, 4>)); k_rs_loop_batch<VEC, 4><<<(int)nb, SDPLR_RS_NT, lds, st>>>(dtab); }))
         });
         const double* res = reinterpret_cast<const double*>(bb.host + res_off);
         for (size_t k = 0; k < nb; k++) {
