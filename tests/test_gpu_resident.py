@@ -48,7 +48,9 @@ def run(s, normC, normb, k, st, gtol=0.0, fprec=-1e300, budget=0.0):
 
 
 @pytest.mark.parametrize("family,n,r,h", [("maxcut", 12, 3, 4), ("maxcut", 40, 8, 1), ("maxcut", 40, 10, 2),
-                                          ("cutnorm", 14, 5, 4), ("maxcut", 30, 2, 3)])
+                                          ("cutnorm", 14, 5, 4), ("maxcut", 30, 2, 3),
+                                          ("maxcut", 15, 3, 2),      # n·r odd: the 16-byte units of DIR leave one element over
+                                          ("maxcut", 67, 1, 4)])     # rank one, one row more than a slice
 def test_resident_loop_iteration_by_iteration(hip_abi, oracle_abi, family, n, r, h):
     """One iteration per call, eight calls: ℒ, ‖grad‖, ‖pv‖ to 1e-8 (north_star's tolerance), R, G, y, primal_vio_raw,
     dirt (restored from s_latest on the way out), the history bookkeeping; every call must have been ONE resident
