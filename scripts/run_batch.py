@@ -86,7 +86,9 @@ def main():
     graphs = [load_graph(e["graph"]) for e in entries]
     abi.device_synchronize()   # the HIP context (≈ 0.15 s, once per process) is created before the clock starts …
     conc = int(os.environ.get("SDPLR_BATCH_CONCURRENCY", "16"))
-    assert abi.warmup(conc) == 0                                   # … with the library's stream / staging pools …
+    lockstep_mode = os.environ.get("SDPLR_BATCH_MODE", "lockstep") == "lockstep"
+    live = len(batch.assign(len(graphs), world)[rank]) if lockstep_mode else conc     # handles alive at once
+    assert abi.warmup(max(1, min(live, 256))) == 0                 # … with the library's stream / staging pools …
     import sdplrplus_jl_amd as _sj                                   # … and the device code (first launch of the module)
     _sj.sdplr(data=problems.maxcut_data(problems.gnp_graph(32, 0.3, 1)), r=2, printlevel=0, ptol=1e-1, objtol=1e-1)
     # The reference's clock (`totaltime`, src/sdplr.jl:127-131,416) starts at the sdplr() call: the problem (C, As, b —
