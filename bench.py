@@ -528,9 +528,12 @@ def other_configs(sj, abi):
     # two ways to drive the batch (sdplrplus.jl_amd/batch.py): in lockstep — every step of all 64 solves is one library
     # call, one launch with a workgroup per instance — or as `conc` independent driver threads.  One untimed pass first
     # (device code, the library's pools: a process that solves batch after batch is in this state), then the clock.
-    walls, rows = {}, None
+    walls, first, rows = {}, {}, None
+    abi.warmup(64)                                        # a stream per handle a lockstep batch keeps alive
     for mode in ("lockstep", "threads"):
+        t0 = time.perf_counter()
         batch.solve_local(datas, 0, 1, 10, concurrency=conc, lockstep=mode == "lockstep", **kw)
+        first[mode] = time.perf_counter() - t0
         abi.device_synchronize()
         t0 = time.perf_counter()
         r_ = batch.solve_local(datas, 0, 1, 10, concurrency=conc, lockstep=mode == "lockstep", **kw)
@@ -541,6 +544,7 @@ def other_configs(sj, abi):
     gap = (rows[:, 1] - rows[:, 2]) / np.minimum(np.abs(rows[:, 1]), np.abs(rows[:, 2]))
     out["config5_batch64"] = {"workload": "64 MaxCut instances n=800 (Gset G1–G9 + 55 G(800,0.06)), rank 10, ptol=objtol=1e-2, one GPU",
                               "instances": 64, "driver": "lockstep (one launch per step for the whole batch)", "wall_s": wall,
+                              "first_pass_wall_s": first["lockstep"],      # (device blocks of these sizes not yet in the library's pool)
                               "instances_per_s": 64 / wall,
                               "wall_s_driver_threads": walls["threads"], "driver_threads_in_flight": conc,
                               "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES", "default (4)"),
