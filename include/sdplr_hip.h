@@ -43,6 +43,7 @@ typedef struct sdplr_hip_solver sdplr_hip_solver; /* opaque handle ("HIPAux" + d
 #define SDPLR_ERR_STATE (-4)       /* call-order violation (e.g. operator before finalize)     */
 #define SDPLR_ERR_NO_DEVICE (-5)   /* no usable gfx950 device                                  */
 #define SDPLR_ERR_ALLOC (-6)
+#define SDPLR_ERR_UNSERVED (-7)    /* batch calls: the call returned before this item was served   */
 
 /* ---- factor slots (r×n col-major, ld = r) ---------------------------------------------------- */
 #define SDPLR_F_RT 0          /* var.Rt   src/structs.jl:195                                  */
@@ -79,13 +80,19 @@ typedef struct sdplr_hip_solver sdplr_hip_solver; /* opaque handle ("HIPAux" + d
 
 /* ---- device management -------------------------------------------------------------------- */
 int32_t sdplr_hip_device_count(int32_t* count);
-int32_t sdplr_hip_set_device(int32_t device); /* process-wide; call before create (one rank = one GPU) */
+int32_t sdplr_hip_set_device(int32_t device); /* process-wide and sticky: recorded, and every later library call — from
+                                                  any host thread — binds its thread to it; a handle remembers the device
+                                                  it was created on and its entry points rebind to THAT (one rank = one GPU) */
 const char* sdplr_hip_last_error(const sdplr_hip_solver* s); /* s may be NULL: the calling thread's last error of a call without a handle (create, warmup, batch argument checks) */
 const char* sdplr_hip_version(void);
 int32_t sdplr_hip_device_synchronize(void); /* hipDeviceSynchronize on the current device */
 /* Optional: primes the library's pools (HIP streams, events, pinned staging) for n_handles handles alive at once, so
  * that the first batch of solves does not pay for them (a HIP stream costs milliseconds to create).                */
 int32_t sdplr_hip_warmup(int32_t n_handles);
+/* The pools keep device blocks (≤ SDPLR_HIP_POOL_MAX_MB, default 4096), streams, events and pinned staging blocks of
+ * destroyed handles for the life of the process; this returns everything no live handle uses to the HIP runtime (a process
+ * that shares the GPU with torch / RCCL calls it between batches; the library calls it itself when hipMalloc runs dry). */
+int32_t sdplr_hip_trim_pools(void);
 
 /* ---- construction: replaces SolverVars + SolverAuxiliary construction ------------------------
  * src/sdplr.jl:114-123, src/structs.jl:225-263 (SolverVars), :296-361 (SolverAuxiliary),

@@ -1159,6 +1159,7 @@ int32_t sdplr_oracle_profile_enable(S* s, int32_t on) { (void)s; (void)on; retur
 int32_t sdplr_oracle_profile_filter(S* s, const char* name) { (void)s; (void)name; return OK; }
 int32_t sdplr_oracle_device_synchronize(void) { return OK; }
 int32_t sdplr_oracle_warmup(int32_t n_handles) { (void)n_handles; return OK; }
+int32_t sdplr_oracle_trim_pools(void) { return OK; }   /* (no pools on the CPU side: same ABI, nothing to do) */
 int32_t sdplr_oracle_profile_count(const S* s, int32_t* n) { (void)s; if (n) *n = 0; return OK; }
 int32_t sdplr_oracle_profile_get(S* s, int32_t idx, char* name, int32_t cap, int64_t* launches, double* ms) {
   (void)s; (void)idx; (void)name; (void)cap; (void)launches; (void)ms;

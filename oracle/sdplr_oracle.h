@@ -68,6 +68,7 @@ int32_t sdplr_oracle_major_iteration(sdplr_oracle_solver* s, double normC, doubl
                                      double* lagrangian, double* grad_norm, double* primal_vio_norm,
                                      double* last_alpha, int64_t* iters_done, int32_t* exit_reason);
 int32_t sdplr_oracle_warmup(int32_t n_handles);
+int32_t sdplr_oracle_trim_pools(void);
 /* the lockstep batch calls of the shared ABI (include/sdplr_hip.h): here plain loops over the single-instance functions */
 typedef struct sdplr_oracle_fg_item {
   sdplr_oracle_solver* s;

@@ -55,14 +55,20 @@ def solve_local(instances: Sequence, rank: int, world: int, r: int, *, abi=None,
         # A thread that comes back from the library has to take the GIL again; CPython only asks the thread that holds it
         # to let go every `switchinterval` (5 ms by default) — with 16 drivers making ≈ 100 short calls per solve that
         # wait, not the calls, was most of a small solve's wall time.
+        # (measured: no change — the waits are inside the HIP runtime — so the process-wide setting is only touched when
+        # asked for: SDPLR_BATCH_SWITCHINTERVAL=<seconds>)
+        import os
         import sys
         old_interval = sys.getswitchinterval()
-        sys.setswitchinterval(min(old_interval, 5e-5))
+        want = os.environ.get("SDPLR_BATCH_SWITCHINTERVAL")
+        if want:
+            sys.setswitchinterval(min(old_interval, float(want)))
         try:
             with ThreadPoolExecutor(max_workers=min(concurrency, len(mine))) as ex:
                 rows = list(ex.map(one, mine))
         finally:
-            sys.setswitchinterval(old_interval)
+            if want:
+                sys.setswitchinterval(old_interval)
     return np.asarray(rows, dtype=np.float64)
 
 
@@ -89,7 +95,13 @@ def solve_lockstep(datas: Sequence, r: int, *, abi=None, setup_workers: int = 8,
     """``sdplr`` on every SDPData of ``datas`` side by side on ONE device: the solves advance in lockstep — each round
     serves the pending device step of all live instances as one call (``serve_batch``) — instead of as independent
     threads whose launches share the GPU only as far as its hardware queues allow.  Same control flow (``sdplr_steps``),
-    same results as ``sdplr(data=…)`` one by one.  → the list of result Dicts (an instance that failed: its exception)."""
+    same results as ``sdplr(data=…)`` one by one.  → the list of result Dicts (an instance that failed: its exception).
+
+    Times are BATCH walls, not per-instance times: an instance's clock (``totaltime``, ``primaltime``, ``dual_time``, and the
+    ``maxtime`` budget it is tested against) starts at its first step and keeps running while the other instances of the
+    round are served, so every instance reports roughly the whole batch's wall (plus the mean set-up time).  Iterations,
+    objective, dual bound, R and λ are those of the one-by-one solve, bit for bit.  All handles live on the calling thread's
+    device (``abi.set_device`` is sticky: the set-up threads and the library's own workers bind to it)."""
     abi = abi if abi is not None else cabi.load_hip()
 
     def config_of():

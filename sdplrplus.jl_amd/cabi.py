@@ -21,6 +21,7 @@ ERR_NOT_DESCENT = -3
 ERR_STATE = -4
 ERR_NO_DEVICE = -5
 ERR_ALLOC = -6
+ERR_UNSERVED = -7   # batch calls: the call returned before this item was served
 
 F_RT, F_GT, F_DIRT, F_LBFGS_S, F_LBFGS_Y, F_SCRATCH = 0, 1, 2, 100, 200, 300
 (V_LAMBDA, V_LAMBDA_UB, V_B, V_Y, V_PV_RAW, V_PV_LB, V_PV, V_A_RD, V_A_DD, V_LBFGS_RHO, V_LBFGS_A,
@@ -62,6 +63,7 @@ SIGNATURES = {
     "version": [],
     "device_synchronize": [],
     "warmup": [_i32],
+    "trim_pools": [],
     "create": [_i64, _i64, _i64, _i64, C.POINTER(_vp)],
     "set_sparse": [_vp, _i64, _i64, _pi64, _pi64, _pf64, _pf64, _pi64, _i64, _pi64, _pi64, _i64,
                    _pi64, _pi64, _pi64],
@@ -526,7 +528,12 @@ class DeviceSolver:
 
 
 # -- lockstep batches: the same step of many instances as one library call (include/sdplr_hip.h) ---------------------
-def _batch_results(abi: CABI, arr, solvers, unpack):
+def _batch_results(abi: CABI, arr, solvers, unpack, rc: int = OK):
+    # the call's own return code: when it failed before any item was touched (argument checks, staging blocks) every item
+    # still reads ERR_UNSERVED and the message is the call's, not a handle's
+    if rc != OK and all(int(arr[k].status) in (OK, ERR_UNSERVED) for k in range(len(solvers))):
+        msg = abi.last_error(None)
+        raise SdplrError(int(rc), msg.decode() if msg else "batch call failed")
     out = []
     for k, sv in enumerate(solvers):
         if arr[k].status != OK:
@@ -545,8 +552,8 @@ def batch_fg(abi: CABI, solvers, args):
         it = arr[k]
         it.s = sv._h.value
         it.normC, it.normb, it.gtol_relative, it.ptol_relative = float(a[0]), float(a[1]), int(a[2]), int(a[3])
-    abi.batch_fg(len(solvers), arr)
-    return _batch_results(abi, arr, solvers, lambda q: (q.lagrangian, q.grad_norm, q.primal_vio_norm, q.obj))
+    rc = abi.batch_fg(len(solvers), arr)
+    return _batch_results(abi, arr, solvers, lambda q: (q.lagrangian, q.grad_norm, q.primal_vio_norm, q.obj), rc)
 
 
 def batch_major_iteration(abi: CABI, solvers, args):
@@ -560,9 +567,9 @@ def batch_major_iteration(abi: CABI, solvers, args):
          it.fprec_eps, it.max_local_iters, it.time_budget_s) = (
             float(a[0]), float(a[1]), int(a[2]), int(a[3]), int(a[4]), int(a[5]), float(a[6]), float(a[7]), float(a[8]),
             int(a[9]), float(a[10]))
-    abi.batch_major_iteration(len(solvers), arr)
+    rc = abi.batch_major_iteration(len(solvers), arr)
     return _batch_results(abi, arr, solvers, lambda q: (q.lagrangian, q.grad_norm, q.primal_vio_norm, q.last_alpha,
-                                                        int(q.iters_done), int(q.exit_reason), q.obj))
+                                                        int(q.iters_done), int(q.exit_reason), q.obj), rc)
 
 
 def batch_dual_obj(abi: CABI, solvers, args):
@@ -579,6 +586,6 @@ def batch_dual_obj(abi: CABI, solvers, args):
         it = arr[k]
         it.s = sv._h.value
         it.trace_bound, it.iter, it.v0, it.y_out = float(a[0]), int(a[1]), _pd(v0), _pd(ys[k])
-    abi.batch_dual_obj(len(solvers), arr)
-    out = _batch_results(abi, arr, solvers, lambda q: (q.dual_value, q.mineig))
+    rc = abi.batch_dual_obj(len(solvers), arr)
+    out = _batch_results(abi, arr, solvers, lambda q: (q.dual_value, q.mineig), rc)
     return [o if isinstance(o, Exception) else o + (ys[k],) for k, o in enumerate(out)]

@@ -690,6 +690,9 @@ struct DevFast {
   const int* diagpos;        // [n] position of (i,i) in the triu pattern, −1 if absent
   const int *drow_ptr, *drow_gid;   // per row: entries of the diagonal-only matrices (y index, value)
   const double* drow_val;
+#ifdef SDPLR_PROBE_TILE_HIST
+  const double* probe_hist[7];      // experiment: the streams a polynomial-in-α Gram epilogue would read (G, s_l, y_l)
+#endif
 };
 
 // per-row dots for the diagonal-only matrices and the partial of ⟨P, D⟩:
@@ -804,7 +807,12 @@ k_fast_lr_ws(DevLowRank lr, int r, double* __restrict__ W, const double* __restr
 // sum: applied in issue order, so each is an ordinary sequential sum) because in registers they pushed the fused
 // kernel to 166 VGPRs and scratch.  Skipped, as lbfgs_update! is, when the relative-decrease exit has been
 // decided (src/sdplr.jl:239-241).
-template <int LPR, int VEC, int HMU, bool COMMIT>
+// PDROP (needs HMU > 0 with G_old read from the G array, COMMIT, A_g = the cost matrix — y_g ≡ 1 — and no low-rank
+// matrices): P is neither read nor written.  With y_g fixed, G_new − G_old = 2·(α·W + d(y_new)∘R_new − d(y_old)∘R_old),
+// and G_old streams through this kernel anyway (for y_j): the gradient is carried forward incrementally, exactly as P was
+// (P += α·W), at 2N bytes less per iteration.  d(y_old) is read off y before the commit overwrites it.  G is rebuilt from
+// scratch by every fg! / g! (each major iteration) and after SDPLR_HIP_P_REFRESH_ITERS incremental steps.
+template <int LPR, int VEC, int HMU, bool COMMIT, bool PDROP = false>
 __global__ void __launch_bounds__(SDPLR_NT)
 k_fast_step2(int n, int m, DevFast ff, double* __restrict__ R, double* __restrict__ D,
              double* __restrict__ P, const double* __restrict__ W, double* Gout, int r,
@@ -860,7 +868,7 @@ k_fast_step2(int n, int m, DevFast ff, double* __restrict__ R, double* __restric
     const long long j0 = tile * TR;
     const int nrows = (int)min((long long)TR, (long long)n - j0);
     if (dn) return;
-    double djl = 0.0;
+    double djl = 0.0, djo = 0.0;     // d_j at the new / (PDROP) the old multipliers
     if (lane < nrows) {
       const long long j = j0 + lane;
       const int e0 = ff.drow_ptr[j], e1 = ff.drow_ptr[j + 1];
@@ -870,6 +878,7 @@ k_fast_step2(int n, int m, DevFast ff, double* __restrict__ R, double* __restric
           djl += ff.drow_val[e] * yvec[k];
           continue;
         }
+        if (PDROP) djo += ff.drow_val[e] * yvec[k];                 // y as the previous g! left it
         const double v = pv_raw[k] + a * (a * A_DD[k] + A_RD[k]);   // src/linesearch.jl:118
         double yk;
         if (k < m) {
@@ -888,13 +897,14 @@ k_fast_step2(int n, int m, DevFast ff, double* __restrict__ R, double* __restric
     }
     for (int i0 = 0; i0 < nrows; i0 += 2) {
       vecd<VEC> xx[2], pq[2], dd[2], ww[2], sv[2][HA], yv[2][HA];
-      double dj[2];
+      double dj[2], dq[2];
       unsigned off[2];
 #pragma unroll
       for (int u = 0; u < 2; u++) {
         const int i = min(i0 + u, nrows - 1);                        // (odd tail: row repeated, not stored twice)
         const long long j = j0 + i;
         dj[u] = __shfl(djl, i, LPR);
+        dq[u] = PDROP ? __shfl(djo, i, LPR) : 0.0;
         off[u] = (unsigned)(((unsigned long long)j * (unsigned)r + (unsigned)ch0) * 8ull);
 #pragma unroll
         for (int q = 0; q < VEC; q++) xx[u].v[q] = pq[u].v[q] = dd[u].v[q] = ww[u].v[q] = 0.0;
@@ -907,7 +917,7 @@ k_fast_step2(int n, int m, DevFast ff, double* __restrict__ R, double* __restric
             // (fused form: one 32-bit byte offset serves all eighteen row accesses — the bases are uniform,
             // the load adds them — instead of a 64-bit address pair per array; launched only when 8·n·r < 2³²)
             xx[u] = ldrow<VEC>(rowat(R, off[u]));
-            pq[u] = ldrow<VEC>(rowat(P, off[u]));
+            if (!PDROP) pq[u] = ldrow<VEC>(rowat(P, off[u]));
             dd[u] = ldrow<VEC>(rowat(D, off[u]));
             ww[u] = ldrow<VEC>(rowat(W, off[u]));
 #pragma unroll
@@ -932,7 +942,7 @@ k_fast_step2(int n, int m, DevFast ff, double* __restrict__ R, double* __restric
           const unsigned offc = off[u] + (unsigned)(ch - ch0) * 8u;   // this chunk (ranks beyond LPR·VEC: several per row)
           if (ch != ch0) {
             x = ldrow<VEC>(R + j * r + ch);
-            pp = ldrow<VEC>(P + j * r + ch);
+            if (!PDROP) pp = ldrow<VEC>(P + j * r + ch);
             d = ldrow<VEC>(D + j * r + ch);
             w = ldrow<VEC>(W + j * r + ch);
             if (HMU > 0) {
@@ -944,6 +954,23 @@ k_fast_step2(int n, int m, DevFast ff, double* __restrict__ R, double* __restric
             }
           }
           vecd<VEC> g;
+          if constexpr (PDROP) {
+            // G_new = G_old + 2·(α·W + d_new∘R_new − d_old∘R_old)   (y_g ≡ 1: A_g is the cost matrix)
+            vecd<VEC> go;
+#pragma unroll
+            for (int q = 0; q < VEC; q++) go.v[q] = 0.0;
+#pragma unroll
+            for (int l = 0; l < HMU; l++)      // slot j's stream is the G array: ±G_old (sign flipped by a fallback)
+              if (l == jslot) go = yv[u][l];
+#pragma unroll
+            for (int q = 0; q < VEC; q++) {
+              const double xo = x.v[q];
+              x.v[q] += a * d.v[q];
+              const double t = a * w.v[q] + (x.v[q] * dj[u] - xo * dq[u]);
+              g.v[q] = -gs * go.v[q] + 2.0 * t;
+              red[0] += g.v[q] * g.v[q];
+            }
+          } else {
 #pragma unroll
           for (int q = 0; q < VEC; q++) {
             x.v[q] += a * d.v[q];
@@ -961,9 +988,10 @@ k_fast_step2(int n, int m, DevFast ff, double* __restrict__ R, double* __restric
             g.v[q] *= 2.0;
             red[0] += g.v[q] * g.v[q];
           }
+          }
           if (HMU > 0) {
             strow<VEC>(rowat(R, offc), x);
-            strow<VEC>(rowat(P, offc), pp);
+            if (!PDROP) strow<VEC>(rowat(P, offc), pp);
             strow<VEC>(rowat(Gout, offc), g);
           } else {
             strow<VEC>(R + j * r + ch, x);
@@ -1205,7 +1233,11 @@ __device__ __forceinline__ double group_bcast(double v, int src) {
 // argument says; for rows wider than a DPP row (LPR ≥ 32: the hand-offs are ds_bpermute results that stay live across the
 // unrolled chunk) the 128-VGPR cap of "4" cost 20–268 bytes of scratch per lane inside the gather loop)
 template <int LPR, int VEC, int LRN>
+#ifdef SDPLR_PROBE_TILE_HIST
+__global__ void __launch_bounds__(SDPLR_NT, 2)
+#else
 __global__ void __launch_bounds__(SDPLR_NT, LPR >= 32 ? 2 : 4)
+#endif
 k_spmm_tile(DevTile tl, int n, int m, DevFast ff, const double* __restrict__ R, const double* __restrict__ D,
             const double* __restrict__ P, double* __restrict__ W, int r, const double* __restrict__ lam,
             const double* __restrict__ pv_raw, double* __restrict__ A_RD, double* __restrict__ A_DD,
@@ -1228,6 +1260,9 @@ k_spmm_tile(DevTile tl, int n, int m, DevFast ff, const double* __restrict__ R, 
                 (size_t)(threadIdx.x >> 6) * (2 * LRN * RW) + lane * VEC;
   const double sigma = c->sigma;
   double pd = 0.0, dw = 0.0;  // ⟨P,D⟩, ⟨D,W⟩
+#ifdef SDPLR_PROBE_TILE_HIST
+  double probe_acc = 0.0;
+#endif
   // LRN > 0 (single chunk only): the projections RᵀB_c and DᵀB_c of k_lr_project<…,2> for the first LRN = ST
   // low-rank columns ride on the rows the epilogue loads anyway (src/coreop.jl:125-126) — one pass over R and D
   // saved per iteration
@@ -1333,6 +1368,27 @@ k_spmm_tile(DevTile tl, int n, int m, DevFast ff, const double* __restrict__ R, 
 #pragma unroll
           for (int q = 0; q < VEC; q++) w[i].v[q] = rows[min(k + i, nrows - 1) * RW + q];
         }
+#ifdef SDPLR_PROBE_TILE_HIST
+#pragma unroll
+        for (int i0 = 0; i0 < EB; i0 += 2) {
+          vecd<VEC> hx[2][7];
+#pragma unroll
+          for (int i = 0; i < 2; i++) {
+            const long long j = j0 + min(k + i0 + i, nrows - 1);
+#pragma unroll
+            for (int l = 0; l < 7; l++) hx[i][l] = ldrow_nt<VEC>(ff.probe_hist[l] + j * r + chs);
+          }
+#pragma unroll
+          for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int l = 0; l < 7; l++)
+#pragma unroll
+              for (int q = 0; q < VEC; q++) {
+                double t1 = hx[i][l].v[q] * w[i0 + i].v[q], t2 = hx[i][l].v[q] * xd[i0 + i].v[q], t3 = hx[i][l].v[q] * xr[i0 + i].v[q];
+                probe_acc += (t1 + t2) + t3;
+              }
+        }
+#endif
         double rd[EB], dd[EB];
 #pragma unroll
         for (int i = 0; i < EB; i++) {
@@ -1464,6 +1520,9 @@ k_spmm_tile(DevTile tl, int n, int m, DevFast ff, const double* __restrict__ R, 
     slot_partials(partials, SLOT_PD)[blockIdx.x] = acc[8];
     slot_partials(partials, SLOT_DW)[blockIdx.x] = acc[9];
   }
+#ifdef SDPLR_PROBE_TILE_HIST
+  if (probe_acc == 1.2345e301) slot_partials(partials, SLOT_V0)[blockIdx.x] = probe_acc;   // keeps the probe's loads alive
+#endif
 }
 
 // ---- hub rows: one block per row of the full pattern with more than long_thresh nonzeros ------------------

@@ -43,8 +43,20 @@ thread_local std::string g_err;   // errors of calls without a handle (create, w
 using ApiMutex = std::shared_timed_mutex;
 using ApiLock = std::shared_lock<ApiMutex>;
 ApiMutex g_api_rw;
+// The device is sticky: sdplr_hip_set_device records it process-wide, a handle remembers the device it was created on,
+// and every entry point binds the CALLING thread to that device before it touches HIP (hipSetDevice is per thread and
+// a new thread starts on device 0 — a thread pool setting handles up would otherwise put their streams, pools and arenas
+// on GPU 0 whatever the rank).
+std::atomic<int> g_device{-1};
+inline void bind_device(int dev) {
+  if (dev < 0) return;
+  int cur = -1;
+  if (hipGetDevice(&cur) != hipSuccess || cur != dev) (void)hipSetDevice(dev);
+}
 struct ApiShared {
   ApiLock l{g_api_rw};
+  ApiShared() { bind_device(g_device.load(std::memory_order_relaxed)); }
+  explicit ApiShared(int dev) { bind_device(dev >= 0 ? dev : g_device.load(std::memory_order_relaxed)); }
 };
 int capture_wait_ms() {
   static const int ms = getenv("SDPLR_HIP_CAPTURE_WAIT_MS") ? std::max(0, atoi(getenv("SDPLR_HIP_CAPTURE_WAIT_MS"))) : 50;
@@ -101,6 +113,7 @@ struct sdplr_hip_solver {
     char* zdev = nullptr;     // zero-filled arrays: a chunk of their own, one device fill at commit (nothing crosses PCIe)
     size_t zcap = 0, zused = 0;
   } up;
+  int device = -1;           // the HIP device this handle lives on (bound at create; every entry point rebinds the calling thread)
   std::vector<void*> allocs;
   DevSparse sp{};
   DevLowRank lr{};
@@ -125,6 +138,13 @@ struct sdplr_hip_solver {
   bool tiles_deferred = false;   // an instance of the resident route: the tiles (multi-launch route) are built when first needed
   bool tile_attr_done = false;
   bool tile_panels = false;  // SDPLR_HIP_TILE_PANELS: 128-byte half-row gathers, two passes over the lists (experiment)
+  bool no_pdrop = false;     // SDPLR_HIP_NO_PDROP: the step kernel keeps P = A_g·R (P += α·W) instead of carrying G forward
+  bool pdrop_now = false;    // this inner loop runs the P-less step kernel (decided at loop entry)
+  // G is the gradient at the device's (R, λ, σ) with y as its g! left it: true after fg! / g! / an inner loop, cleared by
+  // every other entry point that enqueues work (NEED_FINAL_RW).  The P-less step kernel carries G forward incrementally
+  // and needs that; when in doubt the loop takes the P-based kernel, which rebuilds G from P and y.
+  bool G_consistent = false;
+  int64_t G_age = 0;         // incremental steps since G was last formed from scratch
   bool no_updfuse = false;   // SDPLR_HIP_NO_UPDFUSE: lbfgs_update! as a kernel of its own on the singleton fast path
   int gram_nb = 1;           // number of Gram partials the latest enqueued producer writes (k_lbfgs_update / fused step)
   bool force_graph = false;  // SDPLR_HIP_FORCE_GRAPH: hipGraph batches on small instances too (the tests' default)
@@ -167,7 +187,7 @@ struct sdplr_hip_solver {
   int nb_dense = 1, nb_m = 1, nb_sddmm = 1, nb_spmm = 1, nb_spmv = 1, nb_nnzT = 1, nb_nnzS = 1, nb_n = 1;
 
   // captured batch of inner iterations (hipGraph), per line-search kind; rebuilt after reset_rank
-  hipGraphExec_t graph_exec[2] = {nullptr, nullptr};
+  hipGraphExec_t graph_exec[3] = {nullptr, nullptr, nullptr};   // exact line search, Armijo, exact with the P-less step kernel
   int graph_iters = 8;
   bool graph_disabled = false;
   hipGraphExec_t lz_graph = nullptr;   // three Lanczos steps (one rotation of the vector buffers)
@@ -205,6 +225,7 @@ struct sdplr_hip_solver {
 
 namespace {
 using S = sdplr_hip_solver;
+inline int dev_of(const S* s) { return s ? s->device : -1; }
 void ensure_S(S* s);
 
 int fail(S* s, int code, const std::string& msg) {
@@ -223,10 +244,11 @@ int fail(S* s, int code, const std::string& msg) {
     if (!(s)->finalized) return fail((s), SDPLR_ERR_STATE, "not finalized");     \
   } while (0)
 // entry points that enqueue kernels: the host shadow of the control block is stale until the next pull
-#define NEED_FINAL_RW(s)       \
-  do {                         \
-    NEED_FINAL(s);             \
-    (s)->hc_valid = false;     \
+#define NEED_FINAL_RW(s)          \
+  do {                            \
+    NEED_FINAL(s);                \
+    (s)->hc_valid = false;        \
+    (s)->G_consistent = false;    \
   } while (0)
 
 int have_device() {
@@ -273,15 +295,19 @@ struct DevPool {
   // streams and events of destroyed handles: hipStreamCreate / hipStreamDestroy cost 1–2 ms each, more than the rest of
   // finalize on a small instance (a batch creates and destroys a handle per instance)
   std::map<int, std::vector<hipStream_t>> streams_free;
-  std::vector<hipEvent_t> events_free;
+  std::map<int, std::vector<hipEvent_t>> events_free;   // (an event belongs to the device it was created on)
   size_t cached = 0;
   const bool off = getenv("SDPLR_HIP_NO_POOL") != nullptr;
-  static constexpr size_t MAX_BLOCK = (size_t)16 << 20, MAX_CACHED = (size_t)4 << 30;
+  static constexpr size_t MAX_BLOCK = (size_t)16 << 20;
+  // most bytes of device memory kept cached (SDPLR_HIP_POOL_MAX_MB; default 4 GiB: a lockstep batch has all of its
+  // instances alive at once); a process that shares the GPU with other allocators can lower it or call sdplr_hip_trim_pools
+  const size_t MAX_CACHED = getenv("SDPLR_HIP_POOL_MAX_MB") ? (size_t)std::max(0LL, atoll(getenv("SDPLR_HIP_POOL_MAX_MB"))) << 20 : (size_t)4 << 30;
 };
 DevPool& pool() {
   static DevPool* p = new DevPool();   // never destroyed: the HIP runtime may be gone by the time statics are
   return *p;
 }
+void pool_trim();
 hipError_t pool_malloc(void** out, size_t bytes) {
   DevPool& P = pool();
   bytes = (std::max<size_t>(bytes, 1) + 255) / 256 * 256;
@@ -299,6 +325,11 @@ hipError_t pool_malloc(void** out, size_t bytes) {
     }
   }
   hipError_t e = hipMalloc(out, bytes);
+  if (e == hipErrorOutOfMemory && !P.off) {   // give the cached blocks back and try once more
+    (void)hipGetLastError();
+    pool_trim();
+    e = hipMalloc(out, bytes);
+  }
   if (e == hipSuccess && !P.off) {
     std::lock_guard<std::mutex> g(P.mu);
     P.live[*out] = {dev, bytes};
@@ -314,7 +345,7 @@ void pool_free(void* p) {
     if (it != P.live.end()) {
       const auto key = it->second;
       P.live.erase(it);
-      if (key.second <= DevPool::MAX_BLOCK && P.cached + key.second <= DevPool::MAX_CACHED) {
+      if (key.second <= DevPool::MAX_BLOCK && P.cached + key.second <= P.MAX_CACHED) {
         P.free_blocks[key].push_back(p);
         P.cached += key.second;
         return;
@@ -380,11 +411,14 @@ void pool_stream_free(hipStream_t st) {   // (drained by the caller)
 }
 hipError_t pool_event(hipEvent_t* out) {
   DevPool& P = pool();
+  int dev = 0;
+  (void)hipGetDevice(&dev);
   if (!P.off) {
     std::lock_guard<std::mutex> g(P.mu);
-    if (!P.events_free.empty()) {
-      *out = P.events_free.back();
-      P.events_free.pop_back();
+    auto& v = P.events_free[dev];
+    if (!v.empty()) {
+      *out = v.back();
+      v.pop_back();
       return hipSuccess;
     }
   }
@@ -395,14 +429,43 @@ hipError_t pool_event(hipEvent_t* out) {
 void pool_event_free(hipEvent_t e) {
   if (!e) return;
   DevPool& P = pool();
+  int dev = 0;
+  (void)hipGetDevice(&dev);
   if (!P.off) {
     std::lock_guard<std::mutex> g(P.mu);
-    if (P.events_free.size() < 1024) {
-      P.events_free.push_back(e);
+    auto& v = P.events_free[dev];
+    if (v.size() < 1024) {
+      v.push_back(e);
       return;
     }
   }
   (void)hipEventDestroy(e);
+}
+// everything the pools hold and no handle uses goes back to the runtime (sdplr_hip_trim_pools; also tried once when an
+// allocation fails for lack of memory)
+void pool_trim() {
+  DevPool& P = pool();
+  std::map<std::pair<int, size_t>, std::vector<void*>> blocks;
+  std::vector<void*> pinned, chunks;
+  std::map<int, std::vector<hipStream_t>> streams;
+  std::map<int, std::vector<hipEvent_t>> events;
+  {
+    std::lock_guard<std::mutex> g(P.mu);
+    blocks.swap(P.free_blocks);
+    pinned.swap(P.pinned_free);
+    chunks.swap(P.pinned_chunks_free);
+    streams.swap(P.streams_free);
+    events.swap(P.events_free);
+    P.cached = 0;
+  }
+  int cur = 0;
+  (void)hipGetDevice(&cur);
+  for (auto& kv : blocks) { (void)hipSetDevice(kv.first.first); for (void* q : kv.second) (void)hipFree(q); }
+  for (auto& kv : streams) { (void)hipSetDevice(kv.first); for (hipStream_t st : kv.second) (void)hipStreamDestroy(st); }
+  for (auto& kv : events) { (void)hipSetDevice(kv.first); for (hipEvent_t e : kv.second) (void)hipEventDestroy(e); }
+  (void)hipSetDevice(cur);
+  for (void* q : pinned) (void)hipHostFree(q);
+  for (void* q : chunks) (void)hipHostFree(q);
 }
 
 template <typename T>
@@ -1067,6 +1130,12 @@ int build_rs_ell(S* s, const std::vector<int>& g_ptr, const std::vector<int>& g_
 bool step_fuses_update(const S* s) {
   return s->h >= 1 && s->h <= 4 && s->n * s->r * 8 < (1LL << 32) && !s->no_updfuse;
 }
+// k_fast_step2<…, PDROP>: the singleton fast path with A_g = the cost matrix (y_g ≡ 1), no low-rank matrices, the update
+// fused and G_old read from the G array
+bool step_can_drop_P(const S* s) {
+  return s->fast && s->fast_singleton && step_fuses_update(s) && !s->dot_descent && s->ff.gid_g == (int)s->m && s->lr.ST == 0 &&
+         !s->no_pdrop;
+}
 
 int alloc_factors(S* s) {
   s->N = s->n * s->r;
@@ -1126,6 +1195,7 @@ int32_t sdplr_hip_set_device(int32_t device) {
   if (have_device() <= 0) return fail(nullptr, SDPLR_ERR_NO_DEVICE, "no HIP device");
   hipError_t e = hipSetDevice(device);
   if (e != hipSuccess) return fail(nullptr, SDPLR_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(e));
+  g_device.store(device, std::memory_order_relaxed);   // sticky: every later call without a handle, from any thread, binds to it
   return SDPLR_OK;
 }
 
@@ -1152,6 +1222,14 @@ int32_t sdplr_hip_warmup(int32_t n_handles) {
   return SDPLR_OK;
 }
 
+// Returns what the library's pools cache and no handle uses to the runtime: device blocks, streams, events, pinned blocks.
+int32_t sdplr_hip_trim_pools(void) {
+  ApiShared api_guard;
+  if (have_device() <= 0) return fail(nullptr, SDPLR_ERR_NO_DEVICE, "no HIP device");
+  pool_trim();
+  return SDPLR_OK;
+}
+
 int32_t sdplr_hip_create(int64_t n, int64_t m, int64_t r, int64_t h, sdplr_hip_solver** out) {
   ApiShared api_guard;
   if (!out) return fail(nullptr, SDPLR_ERR_INVALID_ARG, "create: null out");
@@ -1163,6 +1241,7 @@ int32_t sdplr_hip_create(int64_t n, int64_t m, int64_t r, int64_t h, sdplr_hip_s
   if (have_device() <= 0) return fail(nullptr, SDPLR_ERR_NO_DEVICE, "no usable HIP device (libsdplr_hip has no CPU fallback)");
   S* s = new S();
   s->n = n; s->m = m; s->r = r; s->h = h;
+  if (hipGetDevice(&s->device) != hipSuccess) s->device = 0;   // (the guard above has bound this thread to the sticky device)
   *out = s;
   return SDPLR_OK;
 }
@@ -1171,7 +1250,7 @@ int32_t sdplr_hip_set_sparse(S* s, int64_t base, int64_t n_sparse, const int64_t
                              const int64_t* nzind, const double* one, const double* two,
                              const int64_t* gids, int64_t nnzT, const int64_t* tcp, const int64_t* trv,
                              int64_t nnzS, const int64_t* fcp, const int64_t* frv, const int64_t* mapped) {
-  ApiShared api_guard;
+  ApiShared api_guard(dev_of(s));
   if (!s) return fail(nullptr, SDPLR_ERR_INVALID_ARG, "null handle");
   if (s->finalized || s->have_sparse) return fail(s, SDPLR_ERR_STATE, "set_sparse: already set / finalized");
   if (base != 0 && base != 1) return fail(s, SDPLR_ERR_INVALID_ARG, "set_sparse: index_base must be 0 or 1");
@@ -1228,7 +1307,7 @@ int32_t sdplr_hip_set_sparse(S* s, int64_t base, int64_t n_sparse, const int64_t
 // per-matrix walk, a binary search only where the reference has one (:110-119, :143-156).
 int32_t sdplr_hip_set_sparse_coo(S* s, int64_t base, int64_t n_sparse, const int64_t* ent_ptr, const int64_t* I,
                                  const int64_t* J, const double* V, const int64_t* gids) {
-  ApiShared api_guard;
+  ApiShared api_guard(dev_of(s));
   if (!s) return fail(nullptr, SDPLR_ERR_INVALID_ARG, "null handle");
   if (s->finalized || s->have_sparse) return fail(s, SDPLR_ERR_STATE, "set_sparse_coo: already set / finalized");
   if (base != 0 && base != 1) return fail(s, SDPLR_ERR_INVALID_ARG, "set_sparse_coo: index_base must be 0 or 1");
@@ -1395,7 +1474,7 @@ int32_t sdplr_hip_get_layout(const S* s, int32_t which, int64_t* out_i, double* 
 }
 
 int32_t sdplr_hip_add_symlowrank(S* s, int64_t base, int64_t gid, int64_t sc, const double* B, const double* D) {
-  ApiShared api_guard;
+  ApiShared api_guard(dev_of(s));
   if (!s) return fail(nullptr, SDPLR_ERR_INVALID_ARG, "null handle");
   if (s->finalized) return fail(s, SDPLR_ERR_STATE, "add_symlowrank: already finalized");
   if (sc < 1 || !B || !D || gid - base < 0 || gid - base > s->m) return fail(s, SDPLR_ERR_INVALID_ARG, "add_symlowrank: bad args");
@@ -1408,7 +1487,7 @@ int32_t sdplr_hip_add_symlowrank(S* s, int64_t base, int64_t gid, int64_t sc, co
 }
 
 int32_t sdplr_hip_finalize(S* s) {
-  ApiShared api_guard;
+  ApiShared api_guard(dev_of(s));
   if (!s) return fail(nullptr, SDPLR_ERR_INVALID_ARG, "null handle");
   if (s->finalized) return fail(s, SDPLR_ERR_STATE, "finalize: already finalized");
   const int64_t n = s->n, m = s->m;
@@ -1569,6 +1648,7 @@ int32_t sdplr_hip_finalize(S* s) {
   s->no_lrfuse = getenv("SDPLR_HIP_NO_LRFUSE") != nullptr;
   s->force_graph = getenv("SDPLR_HIP_FORCE_GRAPH") != nullptr;
   s->no_updfuse = getenv("SDPLR_HIP_NO_UPDFUSE") != nullptr;
+  s->no_pdrop = getenv("SDPLR_HIP_NO_PDROP") != nullptr;
   s->tile_panels = getenv("SDPLR_HIP_TILE_PANELS") != nullptr;
   if (s->have_sparse && getenv("SDPLR_HIP_NO_FAST") == nullptr) {
     std::vector<int> general;
@@ -1836,7 +1916,7 @@ int32_t sdplr_hip_finalize(S* s) {
 }
 
 int32_t sdplr_hip_destroy(S* s) {
-  ApiShared api_guard;
+  ApiShared api_guard(dev_of(s));
   if (!s) return SDPLR_OK;
   if (s->band_thread.joinable()) s->band_thread.join();
   if (s->stream) (void)hipStreamSynchronize(s->stream);
@@ -1854,19 +1934,20 @@ int32_t sdplr_hip_destroy(S* s) {
     if (s->snap_ev[k]) pool_event_free(s->snap_ev[k]);
     if (s->graph_exec[k]) (void)hipGraphExecDestroy(s->graph_exec[k]);
   }
+  if (s->graph_exec[2]) (void)hipGraphExecDestroy(s->graph_exec[2]);
   if (s->stream) { (void)hipStreamSynchronize(s->stream); pool_stream_free(s->stream); }
   delete s;
   return SDPLR_OK;
 }
 
 int32_t sdplr_hip_reset_rank(S* s, int64_t new_r) {
-  ApiShared api_guard;
+  ApiShared api_guard(dev_of(s));
   NEED_FINAL_RW(s);
   if (new_r < 1 || s->n * new_r >= (1LL << 40)) return fail(s, SDPLR_ERR_INVALID_ARG, "reset_rank: bad rank");
   HIPCK(s, hipStreamSynchronize(s->stream));
   if (s->arena.base) pool_free(s->arena.base);
   s->arena.base = nullptr;
-  for (int k = 0; k < 2; k++)
+  for (int k = 0; k < 3; k++)
     if (s->graph_exec[k]) { (void)hipGraphExecDestroy(s->graph_exec[k]); s->graph_exec[k] = nullptr; }
   // everything sized by the rank is released before it is re-allocated (the graphs above hold their pointers)
   for (double** p : {&s->lr_part, &s->lr_W, &s->lr_WS, &s->scratchF[0], &s->scratchF[1]}) { dfree(s, *p); *p = nullptr; }
@@ -1901,8 +1982,9 @@ int32_t sdplr_hip_reset_rank(S* s, int64_t new_r) {
 // state transfer
 // ================================================================================================
 int32_t sdplr_hip_set_factor(S* s, int32_t slot, const double* h) {
-  ApiShared api_guard;
+  ApiShared api_guard(dev_of(s));
   NEED_FINAL(s);
+  s->G_consistent = false;   // (the host writes state behind G's back)
   double* p = factor_ptr(s, slot);
   if (!p || !h) return fail(s, SDPLR_ERR_INVALID_ARG, "set_factor: bad slot");
   {
@@ -1913,7 +1995,7 @@ int32_t sdplr_hip_set_factor(S* s, int32_t slot, const double* h) {
   return SDPLR_OK;
 }
 int32_t sdplr_hip_get_factor(S* s, int32_t slot, double* h) {
-  ApiShared api_guard;
+  ApiShared api_guard(dev_of(s));
   NEED_FINAL(s);
   double* p = factor_ptr(s, slot);
   if (!p || !h) return fail(s, SDPLR_ERR_INVALID_ARG, "get_factor: bad slot");
@@ -1953,8 +2035,9 @@ double* vec_ptr(S* s, int32_t which, int64_t* len, bool* in_ctrl) {
 
 extern "C" {
 int32_t sdplr_hip_set_vec(S* s, int32_t which, const double* h, int64_t len) {
-  ApiShared api_guard;
+  ApiShared api_guard(dev_of(s));
   NEED_FINAL(s);
+  s->G_consistent = false;   // (the host writes state behind G's back)
   int64_t L; bool in_ctrl;
   double* p = vec_ptr(s, which, &L, &in_ctrl);
   if (L < 0 || len != L || (!h && L > 0)) return fail(s, SDPLR_ERR_INVALID_ARG, "set_vec: bad slot/length");
@@ -1975,7 +2058,7 @@ int32_t sdplr_hip_set_vec(S* s, int32_t which, const double* h, int64_t len) {
   return SDPLR_OK;
 }
 int32_t sdplr_hip_get_vec(S* s, int32_t which, double* h, int64_t len) {
-  ApiShared api_guard;
+  ApiShared api_guard(dev_of(s));
   NEED_FINAL(s);
   int64_t L; bool in_ctrl;
   double* p = vec_ptr(s, which, &L, &in_ctrl);
@@ -1993,8 +2076,9 @@ int32_t sdplr_hip_get_vec(S* s, int32_t which, double* h, int64_t len) {
   return SDPLR_OK;
 }
 int32_t sdplr_hip_set_scalar(S* s, int32_t which, double v) {
-  ApiShared api_guard;
+  ApiShared api_guard(dev_of(s));
   NEED_FINAL(s);
+  s->G_consistent = false;   // (the host writes state behind G's back)
   int rc = pull_if_stale(s);
   if (rc) return rc;
   if (which == SDPLR_S_SIGMA) s->hc->sigma = v;
@@ -2007,7 +2091,7 @@ int32_t sdplr_hip_set_scalar(S* s, int32_t which, double v) {
   return push(s);
 }
 int32_t sdplr_hip_get_scalar(S* s, int32_t which, double* v) {
-  ApiShared api_guard;
+  ApiShared api_guard(dev_of(s));
   NEED_FINAL(s);
   if (!v) return fail(s, SDPLR_ERR_INVALID_ARG, "get_scalar: null");
   int rc = pull_if_stale(s);
@@ -2463,6 +2547,13 @@ void enq_iteration_fast2(S* s) {
   const bool upd_fused = step_fuses_update(s);
   s->gram_nb = upd_fused ? s->nb_step : s->nb_upd;
   enq_lbfgs_dir(s, 1, 1, 1, upd_fused && !s->dot_descent);                            // :197-205
+#ifdef SDPLR_PROBE_TILE_HIST
+  s->ff.probe_hist[0] = G;
+  for (int l = 0; l < 3; l++) {
+    s->ff.probe_hist[1 + l] = aslot(s->arena, AS_S0 + std::min<int>(l, (int)s->h - 1));
+    s->ff.probe_hist[4 + l] = aslot(s->arena, as_y0(s->arena) + std::min<int>(l, (int)s->h - 1));
+  }
+#endif
   {
     ProfScope ps(s, "spmm_W");   // W = A_g·D + row dots + line-search sums of the row-attached constraints
     if (s->use_tile && s->tile_lpr == s->LPR && s->n * s->r * 8 < (1LL << 32)) {
@@ -2496,7 +2587,9 @@ void enq_iteration_fast2(S* s) {
   // two kernels — 166 VGPRs and scratch — and dropped)
   {
     ProfScope ps(s, "fast_step");                                                     // :219-234
-    if (upd_fused) {   // … and lbfgs_update! (:244-246) in the same pass
+    if (upd_fused && s->pdrop_now) {   // … P-less: G carried forward from G_old (k_sparse.h, PDROP)
+      LV_DISPATCH((k_fast_step2<LPR, VEC, 4, true, true><<<s->nb_step, SDPLR_NT, 5 * 4 * SDPLR_NT * sizeof(double), s->stream>>>((int)s->n, (int)s->m, s->ff, R, D, P, W, G, (int)s->r, s->y, s->lambda, s->lambda_ub, s->pv_raw, s->pv_lb, s->pv, s->A_RD, s->A_DD, s->lr, s->lr_WS, s->partials, s->ctrl, 1, s->arena, (int)s->h, 1)))
+    } else if (upd_fused) {   // … and lbfgs_update! (:244-246) in the same pass
       LV_DISPATCH((k_fast_step2<LPR, VEC, 4, true><<<s->nb_step, SDPLR_NT, 5 * 4 * SDPLR_NT * sizeof(double), s->stream>>>((int)s->n, (int)s->m, s->ff, R, D, P, W, G, (int)s->r, s->y, s->lambda, s->lambda_ub, s->pv_raw, s->pv_lb, s->pv, s->A_RD, s->A_DD, s->lr, s->lr_WS, s->partials, s->ctrl, 1, s->arena, (int)s->h, s->dot_descent ? 0 : 1)))
     } else {
       LV_DISPATCH((k_fast_step2<LPR, VEC, 0, true><<<s->nb_step, SDPLR_NT, 0, s->stream>>>((int)s->n, (int)s->m, s->ff, R, D, P, W, G, (int)s->r, s->y, s->lambda, s->lambda_ub, s->pv_raw, s->pv_lb, s->pv, s->A_RD, s->A_DD, s->lr, s->lr_WS, s->partials, s->ctrl, 1, s->arena, (int)s->h, 0)))
@@ -2919,7 +3012,7 @@ int run_lanczos(S* s, int64_t q, const double* v0, double* alpha, double* beta, 
 extern "C" {
 
 int32_t sdplr_hip_A(S* s, int32_t u_slot, int32_t v_slot, int32_t out_vec) {
-  ApiShared api_guard;
+  ApiShared api_guard(dev_of(s));
   NEED_FINAL_RW(s);
   double* U = factor_ptr(s, u_slot);
   double* V = v_slot >= 0 ? factor_ptr(s, v_slot) : nullptr;
@@ -2934,14 +3027,14 @@ int32_t sdplr_hip_A(S* s, int32_t u_slot, int32_t v_slot, int32_t out_vec) {
   return sync_check(s);
 }
 int32_t sdplr_hip_At_preprocess(S* s) {
-  ApiShared api_guard;
+  ApiShared api_guard(dev_of(s));
   NEED_FINAL_RW(s);
   enq_At_preprocess(s, 0);
   s->S_stale = false;
   return sync_check(s);
 }
 int32_t sdplr_hip_At_left(S* s, int32_t ys, int32_t xs) {
-  ApiShared api_guard;
+  ApiShared api_guard(dev_of(s));
   NEED_FINAL_RW(s);
   double *Y = factor_ptr(s, ys), *X = factor_ptr(s, xs);
   if (!Y || !X || Y == X) return fail(s, SDPLR_ERR_INVALID_ARG, "At_left: bad slots");
@@ -2951,7 +3044,7 @@ int32_t sdplr_hip_At_left(S* s, int32_t ys, int32_t xs) {
   return sync_check(s);
 }
 int32_t sdplr_hip_At_right(S* s, const double* x, double* yh, int64_t k) {
-  ApiShared api_guard;
+  ApiShared api_guard(dev_of(s));
   NEED_FINAL_RW(s);
   if (!x || !yh || k < 1) return fail(s, SDPLR_ERR_INVALID_ARG, "At_right: bad args");
   ensure_S(s);
@@ -2966,7 +3059,7 @@ int32_t sdplr_hip_At_right(S* s, const double* x, double* yh, int64_t k) {
 }
 
 int32_t sdplr_hip_At_right_device(S* s, const double* x, double* yd, int64_t k) {
-  ApiShared api_guard;
+  ApiShared api_guard(dev_of(s));
   NEED_FINAL_RW(s);
   if (!x || !yd || k < 1 || x == yd) return fail(s, SDPLR_ERR_INVALID_ARG, "At_right_device: bad args");
   hipPointerAttribute_t ax{}, ay{};
@@ -2993,7 +3086,7 @@ int32_t sdplr_hip_get_stats(const S* s, int64_t* out, int32_t cap, int32_t* n_wr
 }
 
 int32_t sdplr_hip_f(S* s, double* L) {
-  ApiShared api_guard;
+  ApiShared api_guard(dev_of(s));
   NEED_FINAL_RW(s);
   enq_f(s);
   int rc = pull(s);
@@ -3002,11 +3095,13 @@ int32_t sdplr_hip_f(S* s, double* L) {
   return sync_check(s);
 }
 int32_t sdplr_hip_g(S* s) {
-  ApiShared api_guard;
+  ApiShared api_guard(dev_of(s));
   NEED_FINAL_RW(s);
   enq_g(s, 0, false);
   s->S_stale = false;
   s->sg_stale = true;
+  s->G_consistent = true;
+  s->G_age = 0;
   return sync_check(s);
 }
 }  // extern "C"
@@ -3033,7 +3128,7 @@ int set_norm_params(S* s, double normC, double normb, int grel, int prel) {
 
 extern "C" {
 int32_t sdplr_hip_fg(S* s, double normC, double normb, int32_t grel, int32_t prel, double* L, double* gn, double* pn) {
-  ApiShared api_guard;
+  ApiShared api_guard(dev_of(s));
   NEED_FINAL_RW(s);
   int rc = set_norm_params(s, normC, normb, grel, prel);
   if (rc) return rc;
@@ -3063,6 +3158,8 @@ int32_t sdplr_hip_fg(S* s, double normC, double normb, int32_t grel, int32_t pre
     k_norms<<<1, SDPLR_NT, 0, s->stream>>>(s->ctrl, s->nb_spmm + std::min(s->sp.n_long_rows, 256), s->nb_m, 0, 0, s->partials);
   }
   s->sg_stale = true;
+  s->G_consistent = true;
+  s->G_age = 0;
   if ((rc = pull(s))) return rc;
   if (L) *L = s->hc->L;
   if (gn) *gn = s->hc->gnorm;
@@ -3070,7 +3167,7 @@ int32_t sdplr_hip_fg(S* s, double normC, double normb, int32_t grel, int32_t pre
   return sync_check(s);
 }
 int32_t sdplr_hip_norms(S* s, double normC, double normb, int32_t grel, int32_t prel, double* gn, double* pn) {
-  ApiShared api_guard;
+  ApiShared api_guard(dev_of(s));
   NEED_FINAL_RW(s);
   int rc = set_norm_params(s, normC, normb, grel, prel);
   if (rc) return rc;
@@ -3086,7 +3183,7 @@ int32_t sdplr_hip_norms(S* s, double normC, double normb, int32_t grel, int32_t 
   return sync_check(s);
 }
 int32_t sdplr_hip_axpy_R(S* s, double alpha) {
-  ApiShared api_guard;
+  ApiShared api_guard(dev_of(s));
   NEED_FINAL_RW(s);
   int rc = pull(s);
   if (rc) return rc;
@@ -3097,7 +3194,7 @@ int32_t sdplr_hip_axpy_R(S* s, double alpha) {
   return sync_check(s);
 }
 int32_t sdplr_hip_update_lambda(S* s) {
-  ApiShared api_guard;
+  ApiShared api_guard(dev_of(s));
   NEED_FINAL_RW(s);
   k_update_lambda<<<s->nb_m, SDPLR_NT, 0, s->stream>>>(s->ctrl, (int)s->m, s->lambda, s->lambda_ub, s->pv_raw);
   return sync_check(s);
@@ -3105,7 +3202,7 @@ int32_t sdplr_hip_update_lambda(S* s) {
 
 // ---- L-BFGS ------------------------------------------------------------------------------------------
 int32_t sdplr_hip_lbfgs_clear(S* s) {
-  ApiShared api_guard;
+  ApiShared api_guard(dev_of(s));
   NEED_FINAL_RW(s);
   // the 2h history slots are neighbours in the arena: one fill (a small solve clears the history once per major iteration)
   if (s->h > 0) HIPCK(s, hipMemsetAsync(aslot(s->arena, AS_S0), 0, (size_t)2 * s->h * s->arena.stride * sizeof(double), s->stream));
@@ -3119,7 +3216,7 @@ int32_t sdplr_hip_lbfgs_clear(S* s) {
   return push(s);
 }
 int32_t sdplr_hip_lbfgs_dir(S* s, int32_t negate, double* descent) {
-  ApiShared api_guard;
+  ApiShared api_guard(dev_of(s));
   NEED_FINAL_RW(s);
   ensure_gram(s);
   enq_lbfgs_dir(s, negate ? 1 : 0, 0, 0);
@@ -3130,14 +3227,14 @@ int32_t sdplr_hip_lbfgs_dir(S* s, int32_t negate, double* descent) {
   return sync_check(s);
 }
 int32_t sdplr_hip_descent_fallback(S* s) {
-  ApiShared api_guard;
+  ApiShared api_guard(dev_of(s));
   NEED_FINAL_RW(s);
   k_neg_copy<<<s->nb_dense, SDPLR_NT, 0, s->stream>>>(aslot(s->arena, AS_G), aslot(s->arena, AS_D), s->N);
   s->sg_stale = true;
   return sync_check(s);
 }
 int32_t sdplr_hip_lbfgs_update(S* s, double stepsize) {
-  ApiShared api_guard;
+  ApiShared api_guard(dev_of(s));
   NEED_FINAL_RW(s);
   if (s->h == 0) return SDPLR_OK;
   if (s->gram_dirty) {  // rows other than the updated one must be valid first
@@ -3176,12 +3273,12 @@ static int32_t linesearch_common(S* s, int armijo, double alpha_max, double* alp
   return sync_check(s);
 }
 int32_t sdplr_hip_linesearch(S* s, double alpha_max, double* alpha, double* L) {
-  ApiShared api_guard;
+  ApiShared api_guard(dev_of(s));
   NEED_FINAL_RW(s);
   return linesearch_common(s, 0, alpha_max, alpha, L);
 }
 int32_t sdplr_hip_linesearch_armijo(S* s, double alpha_max, double* alpha, double* L) {
-  ApiShared api_guard;
+  ApiShared api_guard(dev_of(s));
   NEED_FINAL_RW(s);
   return linesearch_common(s, 1, alpha_max, alpha, L);
 }
@@ -3192,7 +3289,9 @@ int32_t sdplr_hip_inner_loop(S* s, double normC, double normb, int32_t grel, int
                              double* Lio, double* gnio, double* pnio, double* last_alpha, int64_t* iters,
                              int32_t* exit_reason) {
   ApiLock api_lock(g_api_rw);
+  bind_device(dev_of(s));
   const bool hc_was_valid = s && s->finalized && s->hc_valid;
+  const bool G_was_consistent = s && s->finalized && s->G_consistent;
   NEED_FINAL_RW(s);
   if (!Lio || !gnio || !pnio || max_local_iters < 1) return fail(s, SDPLR_ERR_INVALID_ARG, "inner_loop: bad args");
   const bool gram_work = s->h > 0 && (s->gram_dirty || s->ynext_pending || s->sg_stale);
@@ -3219,9 +3318,18 @@ int32_t sdplr_hip_inner_loop(S* s, double normC, double normb, int32_t grel, int
     // budget too — is taken on the device, the host reads the control block once
     return run_resident_loop(s, time_budget_s, false, false, Lio, gnio, pnio, last_alpha, iters, exit_reason);
   }
-  const int ar = use_armijo ? 1 : 0;
   const bool fastp = s->fast;
   const bool fast2 = fastp && s->fast_singleton && !use_armijo;
+  static const int64_t refresh_iters = getenv("SDPLR_HIP_P_REFRESH_ITERS") ? atoll(getenv("SDPLR_HIP_P_REFRESH_ITERS")) : 256;
+  // the P-less step kernel carries G forward: only from a G known to be the gradient at the device's state, and only for
+  // so many steps before G is formed from scratch again (every fg! does that anyway)
+  s->pdrop_now = fast2 && step_can_drop_P(s) && G_was_consistent;
+  if (s->pdrop_now && s->G_age >= refresh_iters) {
+    enq_g(s, 0, false);          // g! from scratch (src/coreop.jl:305-317): same y, S assembled, G = 2·R·S
+    s->S_stale = false;
+    s->G_age = 0;
+  }
+  const int ar = use_armijo ? 1 : (s->pdrop_now ? 2 : 0);
   const bool edgep = !fastp && edge_applies(s, use_armijo);
   auto enq_iter = [&]() {
     if (fast2) enq_iteration_fast2(s);
@@ -3232,8 +3340,9 @@ int32_t sdplr_hip_inner_loop(S* s, double normC, double normb, int32_t grel, int
   // the structured loops leave y current and S unassembled: said before the first enqueue, so that an error return on the
   // way cannot leave a stale S marked as assembled
   if (fastp || edgep) { s->S_stale = true; s->S_from_y = true; }
-  if (fastp) {
-    static const int64_t refresh_iters = getenv("SDPLR_HIP_P_REFRESH_ITERS") ? atoll(getenv("SDPLR_HIP_P_REFRESH_ITERS")) : 256;
+  if (s->pdrop_now) {
+    s->P_valid = false;          // P is neither read nor kept up to date by this loop
+  } else if (fastp) {
     if (!s->P_valid || s->P_age >= refresh_iters) {
       enq_fast_refresh_P(s);
       s->P_valid = true;
@@ -3381,6 +3490,8 @@ int32_t sdplr_hip_inner_loop(S* s, double normC, double normb, int32_t grel, int
   }
   s->st_iters += c->iters;
   s->P_age += c->iters;
+  s->G_age = s->pdrop_now ? s->G_age + c->iters : 0;   // (the P-based kernels form G from P and y at every step)
+  s->G_consistent = true;                              // g! has run at the loop's last point
   *Lio = c->L; *gnio = c->gnorm; *pnio = c->pvnorm;
   if (last_alpha) *last_alpha = c->alpha;
   if (iters) *iters = c->iters;
@@ -3399,7 +3510,7 @@ int32_t sdplr_hip_major_iteration(S* s, double normC, double normb, int32_t grel
   if (!L || !gn || !pn || max_local_iters < 1) return fail(s, SDPLR_ERR_INVALID_ARG, "major_iteration: bad args");
   bool resident = false;
   {
-    ApiShared api_guard;
+    ApiShared api_guard(dev_of(s));
     NEED_FINAL_RW(s);
     resident = rs_loop_applies(s, use_armijo) && rs_fg_applies(s);
     if (resident) {
@@ -3427,7 +3538,7 @@ int32_t sdplr_hip_major_iteration(S* s, double normC, double normb, int32_t grel
 
 // ---- Lanczos / dual bound ------------------------------------------------------------------------------
 int32_t sdplr_hip_lanczos(S* s, int64_t q, const double* v0, double* alpha, double* beta, int64_t* steps) {
-  ApiShared api_guard;
+  ApiShared api_guard(dev_of(s));
   NEED_FINAL_RW(s);
   if (!v0 || !alpha || !beta || !steps || q < 1) return fail(s, SDPLR_ERR_INVALID_ARG, "lanczos: bad args");
   ensure_S(s);
@@ -3460,14 +3571,14 @@ static int32_t approx_mineig_impl(S* s, int64_t q, const double* v0, double* min
   return sdplr_hip_tridiag_mineig(al.data(), be.data(), steps, mineig);
 }
 int32_t sdplr_hip_approx_mineigval_lanczos(S* s, int64_t q, const double* v0, double* mineig) {
-  ApiShared api_guard;
+  ApiShared api_guard(dev_of(s));
   NEED_FINAL_RW(s);
   if (!v0 || !mineig || q < 1) return fail(s, SDPLR_ERR_INVALID_ARG, "approx_mineigval_lanczos: bad args");
   ensure_S(s);
   return approx_mineig_impl(s, q, v0, mineig, &api_guard.l);
 }
 int32_t sdplr_hip_dual_obj(S* s, double trace_bound, int64_t iter, const double* v0, double* dual_value, double* mineig) {
-  ApiShared api_guard;
+  ApiShared api_guard(dev_of(s));
   NEED_FINAL_RW(s);
   if (!v0) return fail(s, SDPLR_ERR_INVALID_ARG, "dual_obj: null v0");
   if (rs_lanczos_ell_applies(s) && s->n >= 2 && getenv("SDPLR_HIP_NO_FUSED_DUAL") == nullptr) {
@@ -3564,7 +3675,7 @@ extern "C" {
 // SDP_S_eigval, src/coreop.jl:351-374 — see include/sdplr_hip.h
 int32_t sdplr_hip_S_eigval(S* s, int64_t nev, int32_t which, int64_t ncv_in, double tol, int64_t maxiter,
                            const double* v0, double* evals, int64_t* n_matvec, int64_t* n_converged) {
-  ApiShared api_guard;
+  ApiShared api_guard(dev_of(s));
   NEED_FINAL_RW(s);
   const int64_t n = s->n;
   if (!evals || nev < 1 || nev > n || (which != 0 && which != 1) || maxiter < 1)
@@ -3672,7 +3783,7 @@ int32_t sdplr_hip_S_eigval(S* s, int64_t nev, int32_t which, int64_t ncv_in, dou
 
 // dot of two factor-shaped arrays on the device (err6 = dot(Rt, Rt·S), src/coreop.jl:449)
 int32_t sdplr_hip_factor_dot(S* s, int32_t slot_a, int32_t slot_b, double* out) {
-  ApiShared api_guard;
+  ApiShared api_guard(dev_of(s));
   NEED_FINAL_RW(s);
   double *a = factor_ptr(s, slot_a), *b = factor_ptr(s, slot_b);
   if (!a || !b || !out) return fail(s, SDPLR_ERR_INVALID_ARG, "factor_dot: bad args");
@@ -3686,7 +3797,7 @@ int32_t sdplr_hip_factor_dot(S* s, int32_t slot_a, int32_t slot_b, double* out) 
 
 // ---- profiling ---------------------------------------------------------------------------------------
 int32_t sdplr_hip_profile_enable(S* s, int32_t on) {
-  ApiShared api_guard;
+  ApiShared api_guard(dev_of(s));
   NEED_FINAL(s);
   prof_drain(s);
   for (auto& p : s->prof) p = ProfEntry();
@@ -3694,7 +3805,7 @@ int32_t sdplr_hip_profile_enable(S* s, int32_t on) {
   return SDPLR_OK;
 }
 int32_t sdplr_hip_profile_filter(S* s, const char* name) {
-  ApiShared api_guard;
+  ApiShared api_guard(dev_of(s));
   NEED_FINAL(s);
   s->prof_filter = name ? name : "";
   return SDPLR_OK;
@@ -3705,7 +3816,7 @@ int32_t sdplr_hip_profile_count(const S* s, int32_t* n_entries) {
   return SDPLR_OK;
 }
 int32_t sdplr_hip_profile_get(S* s, int32_t idx, char* name, int32_t cap, int64_t* launches, double* ms) {
-  ApiShared api_guard;
+  ApiShared api_guard(dev_of(s));
   NEED_FINAL(s);
   if (idx < 0 || idx >= (int32_t)s->prof_names.size()) return fail(s, SDPLR_ERR_INVALID_ARG, "profile_get: bad index");
   prof_drain(s);
@@ -3743,6 +3854,16 @@ constexpr size_t BATCH_ALIGN = 256;
 size_t batch_up(size_t x) { return (x + BATCH_ALIGN - 1) & ~(BATCH_ALIGN - 1); }
 using ShapeKey = std::pair<int, int>;   // (0, bytes per piece of a row / 8): the two shapes of the resident kernels
 
+// one grid dereferences every handle's arrays and runs on the first handle's stream: all handles on ONE device
+bool batch_one_device(const std::vector<const S*>& hs, int* dev) {
+  *dev = -1;
+  for (const S* s : hs) {
+    if (!s) continue;
+    if (*dev < 0) *dev = s->device;
+    else if (s->device != *dev) return false;
+  }
+  return true;
+}
 bool batch_handles_distinct(const std::vector<const S*>& hs) {
   std::vector<const S*> v;
   for (const S* s : hs) if (s) v.push_back(s);
@@ -3750,6 +3871,11 @@ bool batch_handles_distinct(const std::vector<const S*>& hs) {
   return std::adjacent_find(v.begin(), v.end()) == v.end();
 }
 // table up → launch → results back → wait; `launch` enqueues the grid on `st`
+// INVARIANT the shared grid relies on: it runs on the FIRST handle's stream and touches the arenas and control blocks of
+// all the others with no event dependency on their streams.  That is correct because every entry point of this library
+// drains its handle's stream before it returns (pull / pull_blocking / the D2H copies of the results), so no handle of
+// the batch has work in flight when a batch call starts, and this function itself waits for the grid before returning.
+// An entry point that returned with work still enqueued would have to record an event here for each participant.
 template <typename Launch>
 int batch_round_trip(S* s0, BatchBuf& bb, size_t table_bytes, size_t res_off, size_t res_bytes, Launch&& launch) {
   hipStream_t st = s0->stream;
@@ -3792,15 +3918,19 @@ extern "C" {
 int32_t sdplr_hip_batch_fg(int32_t count, sdplr_hip_fg_item* it) {
   if (count < 0 || (count > 0 && !it)) return fail(nullptr, SDPLR_ERR_INVALID_ARG, "batch_fg: bad args");
   std::vector<int> single;
+  // an item keeps SDPLR_ERR_UNSERVED until it has actually been served: a call that returns early (argument checks, staging
+  // blocks) must not leave OK beside zeroed outputs
+  for (int i = 0; i < count; i++) it[i].status = SDPLR_ERR_UNSERVED;
   {
-    ApiShared api_guard;
     std::vector<const S*> hs;
     for (int i = 0; i < count; i++) hs.push_back(it[i].s);
-    if (!batch_handles_distinct(hs)) return fail(nullptr, SDPLR_ERR_INVALID_ARG, "batch_fg: a handle appears twice");
+    if (!batch_handles_distinct(hs)) return fail(nullptr, SDPLR_ERR_INVALID_ARG, "batch_fg: a handle appears twice");   // (before any handle is dereferenced)
+    int dev = -1;
+    if (!batch_one_device(hs, &dev)) return fail(nullptr, SDPLR_ERR_INVALID_ARG, "batch_fg: the handles live on different devices");
+    ApiShared api_guard(dev);
     std::map<ShapeKey, std::vector<int>> groups;
     for (int i = 0; i < count; i++) {
       S* s = it[i].s;
-      it[i].status = SDPLR_OK;
       if (s && s->finalized && rs_fg_applies(s)) groups[{0, rs_vec(s)}].push_back(i);
       else single.push_back(i);
     }
@@ -3859,15 +3989,19 @@ int32_t sdplr_hip_batch_fg(int32_t count, sdplr_hip_fg_item* it) {
 int32_t sdplr_hip_batch_major_iteration(int32_t count, sdplr_hip_major_item* it) {
   if (count < 0 || (count > 0 && !it)) return fail(nullptr, SDPLR_ERR_INVALID_ARG, "batch_major_iteration: bad args");
   std::vector<int> single;
+  // an item keeps SDPLR_ERR_UNSERVED until it has actually been served: a call that returns early (argument checks, staging
+  // blocks) must not leave OK beside zeroed outputs
+  for (int i = 0; i < count; i++) it[i].status = SDPLR_ERR_UNSERVED;
   {
-    ApiShared api_guard;
     std::vector<const S*> hs;
     for (int i = 0; i < count; i++) hs.push_back(it[i].s);
-    if (!batch_handles_distinct(hs)) return fail(nullptr, SDPLR_ERR_INVALID_ARG, "batch_major_iteration: a handle appears twice");
+    if (!batch_handles_distinct(hs)) return fail(nullptr, SDPLR_ERR_INVALID_ARG, "batch_major_iteration: a handle appears twice");   // (before any handle is dereferenced)
+    int dev = -1;
+    if (!batch_one_device(hs, &dev)) return fail(nullptr, SDPLR_ERR_INVALID_ARG, "batch_major_iteration: the handles live on different devices");
+    ApiShared api_guard(dev);
     std::map<ShapeKey, std::vector<int>> groups;
     for (int i = 0; i < count; i++) {
       S* s = it[i].s;
-      it[i].status = SDPLR_OK;
       if (s && s->finalized && it[i].max_local_iters >= 1 && rs_loop_applies(s, it[i].use_armijo) && rs_fg_applies(s))
         groups[{0, rs_vec(s)}].push_back(i);
       else
@@ -3948,16 +4082,20 @@ int32_t sdplr_hip_batch_major_iteration(int32_t count, sdplr_hip_major_item* it)
 int32_t sdplr_hip_batch_dual_obj(int32_t count, sdplr_hip_dual_item* it) {
   if (count < 0 || (count > 0 && !it)) return fail(nullptr, SDPLR_ERR_INVALID_ARG, "batch_dual_obj: bad args");
   std::vector<int> single;
+  // an item keeps SDPLR_ERR_UNSERVED until it has actually been served: a call that returns early (argument checks, staging
+  // blocks) must not leave OK beside zeroed outputs
+  for (int i = 0; i < count; i++) it[i].status = SDPLR_ERR_UNSERVED;
   {
-    ApiShared api_guard;
     std::vector<const S*> hs;
     for (int i = 0; i < count; i++) hs.push_back(it[i].s);
-    if (!batch_handles_distinct(hs)) return fail(nullptr, SDPLR_ERR_INVALID_ARG, "batch_dual_obj: a handle appears twice");
+    if (!batch_handles_distinct(hs)) return fail(nullptr, SDPLR_ERR_INVALID_ARG, "batch_dual_obj: a handle appears twice");   // (before any handle is dereferenced)
+    int dev = -1;
+    if (!batch_one_device(hs, &dev)) return fail(nullptr, SDPLR_ERR_INVALID_ARG, "batch_dual_obj: the handles live on different devices");
+    ApiShared api_guard(dev);
     const bool fused_ok = getenv("SDPLR_HIP_NO_FUSED_DUAL") == nullptr;
     std::map<int, std::vector<int>> groups;   // keyed by "the packed columns fit in LDS" (the kernel's template flag)
     for (int i = 0; i < count; i++) {
       S* s = it[i].s;
-      it[i].status = SDPLR_OK;
       if (s && s->finalized && it[i].v0 && fused_ok && s->n >= 2 && rs_lanczos_ell_applies(s)) {
         bool in_lds = false;
         (void)rs_lz_ell_lds(s, &in_lds);

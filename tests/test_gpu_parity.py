@@ -608,6 +608,7 @@ def test_recycled_device_blocks_do_not_leak_state(hip_abi):
 
 @pytest.mark.parametrize("family,toggles", [
     ("maxcut", ["SDPLR_HIP_NO_FAST"]), ("maxcut", ["SDPLR_HIP_NO_FAST2"]), ("maxcut", ["SDPLR_HIP_NO_GRAPH"]),
+    ("maxcut", ["SDPLR_HIP_NO_PDROP"]), ("cutnorm", ["SDPLR_HIP_NO_PDROP"]), ("maxcut", ["SDPLR_HIP_NO_PDROP", "SDPLR_HIP_NO_GRAPH"]),
     ("maxcut", ["SDPLR_HIP_NO_UPDFUSE"]), ("minimum_bisection", ["SDPLR_HIP_NO_UPDFUSE"]),
     ("mu_conductance_0.05", ["SDPLR_HIP_NO_TILE"]), ("mu_conductance_0.05", ["SDPLR_HIP_NO_UPDFUSE"]),
     ("ineq_0.05", ["SDPLR_HIP_NO_TILE", "SDPLR_HIP_NO_UPDFUSE"]),
@@ -659,6 +660,49 @@ def test_code_paths_agree(hip_abi, oracle_abi, family, toggles, monkeypatch):
     scale = np.array([max(abs(st0[0]), abs(base[0])), max(st0[1], base[1]), max(st0[2], base[2])])
     assert np.all(np.abs(np.array(base[:3]) - np.array(alt[:3])) <= (1e-6 if armijo else 1e-9) * scale) and rel(Rb, Ra) < tolR
     assert np.all(np.abs(np.array(base[:3]) - np.array(ora[:3])) <= (1e-6 if armijo else 1e-8) * scale) and rel(Rb, Ro) < 10 * tolR
+
+
+def test_step_kernel_without_P_carries_G_forward(hip_abi, oracle_abi, monkeypatch):
+    """The singleton fast path with A_g = C and no low-rank matrix runs the step kernel that neither reads nor writes
+    P = A_g·R: G_new = G_old + 2(αW + d_new∘R_new − d_old∘R_old) (k_fast_step2<…, PDROP>).  Checked here: (1) G after
+    every call of a chain of loops equals the gradient formed from scratch at that point (g! on the same handle) to
+    round-off and the oracle's to 1e-8 — across the refresh (SDPLR_HIP_P_REFRESH_ITERS=7: every third call of 3
+    iterations rebuilds G), (2) a host write between two loops (here: λ) sends the next loop through the P-based kernel,
+    which rebuilds G from the new multipliers exactly as the reference's g! would, (3) R and the history agree with the
+    P-based route (SDPLR_HIP_NO_PDROP) to 1e-9 after the chain."""
+    monkeypatch.setenv("SDPLR_HIP_P_REFRESH_ITERS", "7")
+    data = problems.maxcut_data(problems.gnp_graph(500, 0.03, 11))
+    normC, normb = data.normC(), float(np.linalg.norm(data.b))
+    r = 6
+
+    def chain(abi, touch):
+        s_, _ = make_solver(abi, data, r, seed=4)
+        st = s_.fg(normC, normb)
+        gs = []
+        for call in range(5):
+            out = s_.inner_loop(normC, normb, True, True, False, 0.0, -1e300, 3, 0.0, *st)
+            st = out[:3]
+            gs.append(s_.Gt.copy())
+            if touch and call == 2:
+                s_.λ = s_.λ + 0.25                         # G is no longer known to be the gradient at the device's state
+        R, S0, Y0 = s_.Rt.copy(), s_.get_factor(cabi.F_LBFGS_S).copy(), s_.get_factor(cabi.F_LBFGS_Y).copy()
+        s_.g()                                               # the gradient from scratch at the final point
+        Gfresh = s_.Gt.copy()
+        s_.close()
+        return gs, R, S0, Y0, Gfresh, st
+
+    for touch in (False, True):
+        gh, Rh, Sh, Yh, Gf, sth = chain(hip_abi, touch)
+        go, Ro, So, Yo, Gfo, sto = chain(oracle_abi, touch)
+        for a, b in zip(gh, go):
+            assert rel(a, b) < 1e-8
+        assert rel(gh[-1], Gf) < 1e-12                       # carried forward ≡ from scratch
+        assert rel(Rh, Ro) < 1e-8 and rel(Sh, So) < 1e-7 and rel(Yh, Yo) < 1e-7
+        monkeypatch.setenv("SDPLR_HIP_NO_PDROP", "1")
+        gp, Rp, Sp, Yp, _, stp = chain(hip_abi, touch)
+        monkeypatch.delenv("SDPLR_HIP_NO_PDROP")
+        assert rel(Rh, Rp) < 1e-9 and rel(gh[-1], gp[-1]) < 1e-9 and rel(Yh, Yp) < 1e-8
+        assert np.allclose(sth, stp, rtol=1e-9)
 
 
 @pytest.mark.parametrize("r,n,p,tile_k", [
