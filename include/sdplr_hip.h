@@ -235,7 +235,13 @@ int32_t sdplr_hip_inner_loop(sdplr_hip_solver* s, double normC, double normb,
  * var.σ[] = sigma  →  lbfgs_clear!  →  fg!  →  the inner while loop on fg!'s (ℒ, grad_norm) — exactly
  * sdplr_hip_update_lambda / set_scalar / lbfgs_clear / fg / inner_loop in that order, whose arguments these are.  On
  * small instances (the resident route) all five are ONE kernel launch; out parameters as sdplr_hip_inner_loop
- * (iterations 0, exit_reason 0 when fg!'s gradient norm is already ≤ cur_gtol).                                    */
+ * (iterations 0, exit_reason 0 when fg!'s gradient norm is already ≤ cur_gtol).
+ * update_lambda = SDPLR_MAJOR_RESUME: none of the prologue — the `while` CONTINUES on the state an earlier call left when
+ * it ran out of its iteration budget (exit_reason 2): lagrangian / grad_norm / primal_vio_norm are in/out (on entry what
+ * that call returned), sigma must be the σ of that call.  A driver that caps the iterations per call and resumes gets the
+ * iterates of the uncapped call bit for bit (the lockstep batches do that so that a round does not last as long as its
+ * slowest member).                                                                                                  */
+#define SDPLR_MAJOR_RESUME 2
 int32_t sdplr_hip_major_iteration(sdplr_hip_solver* s, double normC, double normb, int32_t gtol_relative,
                                   int32_t ptol_relative, int32_t use_armijo, int32_t update_lambda,
                                   double sigma, double cur_gtol, double fprec_eps, int64_t max_local_iters,

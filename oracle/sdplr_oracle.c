@@ -1046,6 +1046,9 @@ int32_t sdplr_oracle_major_iteration(S* s, double normC, double normb, int32_t g
                                      double* last_alpha, int64_t* iters, int32_t* exit_reason) {
   NEED_FINAL(s);
   if (!L || !gn || !pn || max_local_iters < 1) return fail(s, ERR_INVALID, "major_iteration: bad args");
+  if (update_lambda == 2) /* SDPLR_MAJOR_RESUME: the while loop continues where a capped call left it (L, gn, pn in/out) */
+    return sdplr_oracle_inner_loop(s, normC, normb, grel, prel, use_armijo, cur_gtol, fprec_eps, max_local_iters,
+                                   time_budget_s, L, gn, pn, last_alpha, iters, exit_reason);
   int32_t rc;
   if (update_lambda && (rc = sdplr_oracle_update_lambda(s))) return rc;
   if ((rc = sdplr_oracle_set_scalar(s, 0, sigma))) return rc;

@@ -38,15 +38,21 @@ for rep in range(2):
     laps["python"] += time.perf_counter() - t0
     rounds = []
     results = {}
+    cap = batch._Cap(int(os.environ.get("SDPLR_LOCKSTEP_CAP", "0")))
     while pending:
         ks = sorted(pending)
         t0 = time.perf_counter()
-        resp = batch.serve_batch(abi, [solvers[k] for k in ks], [pending[k] for k in ks])
+        reqs = [cap.outgoing(k, pending[k]) for k in ks]
+        resp = batch.serve_batch(abi, [solvers[k] for k in ks], reqs)
         t1 = time.perf_counter()
         kinds = {}
-        for k in ks:
-            kinds[pending[k][0]] = kinds.get(pending[k][0], 0) + 1
+        for k, q in zip(ks, reqs):
+            name = q[0] + ("+" if q[0] == "major_iteration" and q[6] == cabi.MAJOR_RESUME else "")
+            kinds[name] = kinds.get(name, 0) + 1
         for k, r in zip(ks, resp):
+            r = cap.incoming(k, r)
+            if r is None:
+                continue
             try:
                 pending[k] = steppers[k].send(r)
             except StopIteration as done:

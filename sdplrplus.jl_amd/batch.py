@@ -72,16 +72,89 @@ def solve_local(instances: Sequence, rank: int, world: int, r: int, *, abi=None,
     return np.asarray(rows, dtype=np.float64)
 
 
+_KIND_POOL = None
+
+
+def _kind_pool() -> ThreadPoolExecutor:
+    global _KIND_POOL
+    if _KIND_POOL is None:
+        _KIND_POOL = ThreadPoolExecutor(max_workers=3, thread_name_prefix="sdplr-batch-kind")
+    return _KIND_POOL
+
+
+EXIT_ITERS = 2   # exit_reason of the inner loop: the iteration budget (include/sdplr_hip.h)
+
+
+class _Cap:
+    """Inner iterations per lockstep launch (``SDPLR_LOCKSTEP_CAP``; default 0: none — on BASELINE config 5 the batch's wall
+    is its slowest instance's own path, 403 inner iterations on one CU, and shorter rounds only add their fixed costs:
+    32.7 ms of batch calls uncapped, 40.3 ms at 64).  A major iteration whose budget
+    is larger goes out capped; while it keeps coming back on the budget exit it is RESUMED (``MAJOR_RESUME``: no prologue,
+    the loop continues on the state the launch left — bit for bit the iterates of the uncapped call), and only the final
+    answer — with the iterations of all its launches — reaches the instance's stepper.  A round then lasts as long as
+    ``cap`` iterations, not as long as its slowest member's whole inner loop, and the instances that have left their
+    loop move on to their dual bound in the next round."""
+
+    def __init__(self, cap: int):
+        self.cap = int(cap)
+        self.open = {}        # instance → [original request, iterations so far, wall at first send, (ℒ, ‖grad‖, ‖pv‖)]
+
+    def outgoing(self, k, req):
+        if self.cap <= 0 or req[0] != REQ_MAJOR:
+            return req
+        st = self.open.get(k)
+        if st is None:
+            if req[10] <= self.cap:
+                return req
+            self.open[k] = [req, 0, time.time(), None]
+            return req[:10] + (self.cap,) + req[11:]
+        left = req[10] - st[1]
+        tleft = req[11] - (time.time() - st[2])
+        return req[:6] + (cabi.MAJOR_RESUME,) + req[7:10] + (min(self.cap, left), max(tleft, 1e-9)) + st[3]
+
+    def incoming(self, k, resp):
+        """→ the response to forward to the stepper, or None: the instance's request stays pending (resumed next round)."""
+        st = self.open.get(k)
+        if st is None:
+            return resp
+        if isinstance(resp, Exception):
+            del self.open[k]
+            return resp
+        L, gn, pn, alpha, it, why, obj = resp
+        sent = min(self.cap, st[0][10] - st[1])
+        st[1] += it
+        if why == EXIT_ITERS and it == sent and st[1] < st[0][10]:
+            st[3] = (L, gn, pn)
+            return None
+        del self.open[k]
+        return (L, gn, pn, alpha, st[1], why, obj)
+
+
 def serve_batch(abi, solvers, reqs) -> list:
     """The pending request of every instance, served side by side: the requests of one kind are ONE library call
     (``sdplr_hip_batch_*``: one kernel launch for all the small instances among them); the rest go one by one.
     → per instance what ``sdplr.serve`` returns, or the exception its call raised."""
     out = [None] * len(solvers)
+    jobs = []
     for kind, call in ((REQ_MAJOR, cabi.batch_major_iteration), (REQ_DUAL, cabi.batch_dual_obj), (REQ_FG, cabi.batch_fg)):
         ks = [k for k, q in enumerate(reqs) if q[0] == kind]
         if ks:
-            for k, res in zip(ks, call(abi, [solvers[k] for k in ks], [reqs[k][1:] for k in ks])):
-                out[k] = res
+            jobs.append((ks, call))
+
+    def run(job):
+        ks, call = job
+        try:
+            return call(abi, [solvers[k] for k in ks], [reqs[k][1:] for k in ks])
+        except Exception as e:               # (a call that failed as a whole: every instance of it gets the error)
+            return [e] * len(ks)
+
+    # the kinds of one round are independent library calls on disjoint handles (each grid on its first handle's stream):
+    # side by side, so that the dual bounds of the instances that have finished a major iteration run beside the inner
+    # loops of those that have not (ctypes releases the GIL inside the library)
+    results = list(_kind_pool().map(run, jobs)) if len(jobs) > 1 else [run(j) for j in jobs]
+    for (ks, _), res in zip(jobs, results):
+        for k, r_ in zip(ks, res):
+            out[k] = r_
     for k, q in enumerate(reqs):
         if out[k] is None:
             try:
@@ -91,7 +164,8 @@ def serve_batch(abi, solvers, reqs) -> list:
     return out
 
 
-def solve_lockstep(datas: Sequence, r: int, *, abi=None, setup_workers: int = 8, **kwargs) -> list:
+def solve_lockstep(datas: Sequence, r: int, *, abi=None, setup_workers: int = 8, iteration_cap: Optional[int] = None,
+                   **kwargs) -> list:
     """``sdplr`` on every SDPData of ``datas`` side by side on ONE device: the solves advance in lockstep — each round
     serves the pending device step of all live instances as one call (``serve_batch``) — instead of as independent
     threads whose launches share the GPU only as far as its hardware queues allow.  Same control flow (``sdplr_steps``),
@@ -149,10 +223,15 @@ def solve_lockstep(datas: Sequence, r: int, *, abi=None, setup_workers: int = 8,
     try:
         for k in range(len(datas)):
             advance(k, None)
+        import os
+        cap = _Cap(int(os.environ.get("SDPLR_LOCKSTEP_CAP", "0")) if iteration_cap is None else iteration_cap)
         while pending:
             ks = sorted(pending)
-            for k, response in zip(ks, serve_batch(abi, [solvers[k] for k in ks], [pending[k] for k in ks])):
-                advance(k, response)
+            reqs = [cap.outgoing(k, pending[k]) for k in ks]
+            for k, response in zip(ks, serve_batch(abi, [solvers[k] for k in ks], reqs)):
+                response = cap.incoming(k, response)
+                if response is not None:
+                    advance(k, response)
     finally:
         for v in solvers:
             v.close()

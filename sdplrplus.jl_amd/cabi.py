@@ -22,6 +22,7 @@ ERR_STATE = -4
 ERR_NO_DEVICE = -5
 ERR_ALLOC = -6
 ERR_UNSERVED = -7   # batch calls: the call returned before this item was served
+MAJOR_RESUME = 2    # update_lambda of major_iteration: continue a capped loop (include/sdplr_hip.h)
 
 F_RT, F_GT, F_DIRT, F_LBFGS_S, F_LBFGS_Y, F_SCRATCH = 0, 1, 2, 100, 200, 300
 (V_LAMBDA, V_LAMBDA_UB, V_B, V_Y, V_PV_RAW, V_PV_LB, V_PV, V_A_RD, V_A_DD, V_LBFGS_RHO, V_LBFGS_A,
@@ -460,10 +461,12 @@ class DeviceSolver:
                 int(why.value))
 
     def major_iteration(self, normC, normb, gtol_relative, ptol_relative, use_armijo, update_lambda, sigma,
-                        cur_gtol, fprec_eps, max_local_iters, time_budget_s):
+                        cur_gtol, fprec_eps, max_local_iters, time_budget_s, L_in=0.0, gn_in=0.0, pn_in=0.0):
         """One major iteration's device work as one call: [λ update] → σ → lbfgs_clear! → fg! → inner loop
-        (src/sdplr.jl:358-369, :384, :389, :190-278) → (ℒ, grad_norm, primal_vio_norm, last α, iterations, exit_reason)."""
-        L, g, p, a = C.c_double(0.0), C.c_double(0.0), C.c_double(0.0), C.c_double(0.0)
+        (src/sdplr.jl:358-369, :384, :389, :190-278) → (ℒ, grad_norm, primal_vio_norm, last α, iterations, exit_reason).
+        ``update_lambda = MAJOR_RESUME``: no prologue — the loop continues on the state a capped call left (its ℒ and norms
+        come in as L_in, gn_in, pn_in)."""
+        L, g, p, a = C.c_double(float(L_in)), C.c_double(float(gn_in)), C.c_double(float(pn_in)), C.c_double(0.0)
         it, why = C.c_int64(0), C.c_int32(0)
         self._ck(self.abi.major_iteration(self._h, normC, normb, int(gtol_relative), int(ptol_relative), int(use_armijo),
                                           int(update_lambda), float(sigma), float(cur_gtol), float(fprec_eps),
@@ -567,6 +570,8 @@ def batch_major_iteration(abi: CABI, solvers, args):
          it.fprec_eps, it.max_local_iters, it.time_budget_s) = (
             float(a[0]), float(a[1]), int(a[2]), int(a[3]), int(a[4]), int(a[5]), float(a[6]), float(a[7]), float(a[8]),
             int(a[9]), float(a[10]))
+        if len(a) > 11:    # MAJOR_RESUME: ℒ and the norms the capped call returned
+            it.lagrangian, it.grad_norm, it.primal_vio_norm = float(a[11]), float(a[12]), float(a[13])
     rc = abi.batch_major_iteration(len(solvers), arr)
     return _batch_results(abi, arr, solvers, lambda q: (q.lagrangian, q.grad_norm, q.primal_vio_norm, q.last_alpha,
                                                         int(q.iters_done), int(q.exit_reason), q.obj), rc)

@@ -51,6 +51,12 @@
 #endif
 #define SDPLR_RS_NW (SDPLR_RS_NT / 64)
 #define SDPLR_RS_RPT 2         /* rows whose constraint data a thread keeps in registers (n ≤ RPT·NT) */
+#ifndef SDPLR_RS_EARLY_MAX
+#define SDPLR_RS_EARLY_MAX 8   /* the SpMM asks for R_j before its gather loop when the row is at most this many doubles wide */
+#endif
+#ifndef SDPLR_RS_NCHMAX
+#define SDPLR_RS_NCHMAX 8      /* most VEC-wide chunks of a row a lane carries through one pass of the SpMM */
+#endif
 #ifndef SDPLR_RS_ELL_PF
 #define SDPLR_RS_ELL_PF 8      /* entries of a row in flight per lane in the SpMM (a register ring) */
 #endif
@@ -202,7 +208,7 @@ __device__ __forceinline__ void rs_ell_spmm_chunks(const RsEll& E, const double*
     const double gd = (jp >= 0) ? E.gdiag[j] : 0.0;
     // (R_j is asked for before the gather loop where the registers allow it — up to five chunks: with eight, the 32
     // registers it would hold through the loop spill — and after it otherwise)
-    constexpr bool EARLY = DOTS && NCH * VEC <= 10;
+    constexpr bool EARLY = DOTS && NCH * VEC <= SDPLR_RS_EARLY_MAX;
     vecd<VEC> xr[DOTS ? NCH : 1];
     if (EARLY) {
 #pragma unroll
@@ -245,17 +251,27 @@ template <int VEC, int MODE, bool DOTS>
 __device__ __forceinline__ void rs_ell_spmm(const RsEll& E, const double* Xl, int n, int r, double* out, const RsDots& dots,
                                             double& rw, double& dw) {
   const int NC = r / VEC;   // (VEC = 2 only for even r)
+  constexpr int CMAX = SDPLR_RS_NCHMAX;
 #pragma nounroll
-  for (int c0 = 0; c0 < NC; c0 += 8) {
-    switch (min(NC - c0, 8)) {
+  for (int c0 = 0; c0 < NC; c0 += CMAX) {
+    switch (min(NC - c0, CMAX)) {
       case 1: rs_ell_spmm_chunks<VEC, MODE, 1, DOTS>(E, Xl, n, r, c0, out, dots, rw, dw); break;
       case 2: rs_ell_spmm_chunks<VEC, MODE, 2, DOTS>(E, Xl, n, r, c0, out, dots, rw, dw); break;
       case 3: rs_ell_spmm_chunks<VEC, MODE, 3, DOTS>(E, Xl, n, r, c0, out, dots, rw, dw); break;
       case 4: rs_ell_spmm_chunks<VEC, MODE, 4, DOTS>(E, Xl, n, r, c0, out, dots, rw, dw); break;
+#if SDPLR_RS_NCHMAX > 4
       case 5: rs_ell_spmm_chunks<VEC, MODE, 5, DOTS>(E, Xl, n, r, c0, out, dots, rw, dw); break;
+#endif
+#if SDPLR_RS_NCHMAX > 5
       case 6: rs_ell_spmm_chunks<VEC, MODE, 6, DOTS>(E, Xl, n, r, c0, out, dots, rw, dw); break;
+#endif
+#if SDPLR_RS_NCHMAX > 6
       case 7: rs_ell_spmm_chunks<VEC, MODE, 7, DOTS>(E, Xl, n, r, c0, out, dots, rw, dw); break;
-      default: rs_ell_spmm_chunks<VEC, MODE, 8, DOTS>(E, Xl, n, r, c0, out, dots, rw, dw); break;
+#endif
+#if SDPLR_RS_NCHMAX > 7
+      case 8: rs_ell_spmm_chunks<VEC, MODE, 8, DOTS>(E, Xl, n, r, c0, out, dots, rw, dw); break;
+#endif
+      default: break;
     }
   }
 }
@@ -462,9 +478,12 @@ struct RsLoopArgs {
 };
 
 // constraint data of the rows a thread owns (row j = tid + q·NT): registers for q < RPT, global memory beyond
+// (λ_ub and the lower bound of the violation — ±∞ on equality constraints — are read where COMMIT needs them, once per
+// iteration from L2: eight registers per lane less across every phase of the loop, which is what kept the even-rank
+// shape at 256 VGPRs + scratch)
 struct RsRow {
   int k;
-  double v, lam, lub, lb, pvr;
+  double v, lam, pvr;
 };
 __device__ __forceinline__ RsRow rs_load_row(const RsLoopArgs& a, int j) {
   RsRow o;
@@ -473,13 +492,14 @@ __device__ __forceinline__ RsRow rs_load_row(const RsLoopArgs& a, int j) {
   const int kc = (o.k >= 0 && o.k < a.m) ? o.k : 0;
   const bool has = o.k >= 0 && o.k < a.m && a.m > 0;
   o.lam = has ? a.lam[kc] : 0.0;
-  o.lub = has ? a.lam_ub[kc] : 0.0;
-  o.lb = has ? a.lb[kc] : 0.0;
   o.pvr = (o.k >= 0) ? a.pv_raw[o.k] : 0.0;
   return o;
 }
 
-template <int VEC, int HM>
+// PDROP (A_g is the cost matrix: y_g ≡ 1; the caller vouches that G is the gradient at the device's state, or has fg! run
+// in the prologue): STEP carries G forward — G_new = G_old + 2(αW + d_new∘R_new − d_old∘R_old), as k_fast_step2<…, PDROP>
+// does — and P is neither read nor written: two of STEP's seventeen streams gone, and no P = A_g·R at the loop's entry.
+template <int VEC, int HM, bool PDROP>
 __device__ __forceinline__ void rs_loop_run(const RsLoopArgs& a) {
   extern __shared__ __attribute__((aligned(16))) double rs_lds[];   // (16-byte LDS reads: an 8-byte-aligned base behind the static LDS made every ds_read_b128 a misaligned access — 5× slower)
   __shared__ SeamLds gd;
@@ -553,9 +573,20 @@ __device__ __forceinline__ void rs_loop_run(const RsLoopArgs& a) {
   for (int q = 0; q < SDPLR_RS_RPT; q++) {
     const int j = tid + q * NT;
     if (j < n) rw_[q] = rs_load_row(a, j);
-    else { rw_[q].k = -1; rw_[q].v = rw_[q].lam = rw_[q].lub = rw_[q].lb = rw_[q].pvr = 0.0; }
+    else { rw_[q].k = -1; rw_[q].v = rw_[q].lam = rw_[q].pvr = 0.0; }
   }
-  if (a.refresh_P && !a.pre_fg) {   // P = A_g·R (entry of the loop: R was written outside, or the incremental P is due for a refresh)
+  if (PDROP && !a.pre_fg) {   // d_j at the multipliers the previous g! left (fg! in the prologue has just formed them)
+#pragma unroll
+    for (int q = 0; q < SDPLR_RS_RPT; q++) {
+      const int j = tid + q * NT;
+      if (j < n) djl[j] = (rw_[q].k >= 0) ? rw_[q].v * a.y[rw_[q].k] : 0.0;
+    }
+    for (int j = tid + SDPLR_RS_RPT * NT; j < n; j += NT) {
+      const int k = a.row_k[j];
+      djl[j] = (k >= 0) ? a.row_v[j] * a.y[k] : 0.0;
+    }
+  }
+  if (!PDROP && a.refresh_P && !a.pre_fg) {   // P = A_g·R (entry of the loop: R was written outside, or the incremental P is due for a refresh)
     for (long long e = tid; e < N; e += NT) Dl[e] = R[e];
     __syncthreads();
     rs_ell_spmm_any<VEC>(a.E, Dl, n, r, a.P);
@@ -770,6 +801,9 @@ __device__ __forceinline__ void rs_loop_run(const RsLoopArgs& a) {
       auto commit_row = [&](int j, RsRow& rw) {
         double dj = 0.0;
         if (rw.k >= 0) {
+          int kb = rw.k < m ? rw.k : 0;
+          asm volatile("" : "+v"(kb));   // (opaque: a loop-invariant address pair hoisted out of the persistent loop is a spill)
+          const double lub = (rw.k < m) ? a.lam_ub[kb] : 0.0, lbv = (rw.k < m) ? a.lb[kb] : 0.0;
           const double rd = rdl[j], dd = ddl[j];
           const double q1 = rw.v * (rd + rd), q2 = rw.v * dd;
           const double v = rw.pvr + al * (al * q2 + q1);     // src/linesearch.jl:118
@@ -777,8 +811,8 @@ __device__ __forceinline__ void rs_loop_run(const RsLoopArgs& a) {
           a.pv_raw[rw.k] = v;
           double yk;
           if (rw.k < m) {
-            yk = -fmin(rw.lub, rw.lam - sigma * v);           // src/coreop.jl:233
-            const double pc = fmax(v, rw.lb);                 // src/linesearch.jl:122-124
+            yk = -fmin(lub, rw.lam - sigma * v);              // src/coreop.jl:233
+            const double pc = fmax(v, lbv);                   // src/linesearch.jl:122-124
             a.pv[rw.k] = pc;
             nrm[1] += pc * pc;
           } else {
@@ -788,6 +822,7 @@ __device__ __forceinline__ void rs_loop_run(const RsLoopArgs& a) {
           a.y[rw.k] = yk;
           dj = rw.v * yk;
         }
+        if (PDROP) rdl[j] = djl[j];    // d_j at the old multipliers, for STEP (⟨R_j,D_j⟩ has been consumed above)
         djl[j] = dj;
       };
 #pragma unroll
@@ -822,7 +857,9 @@ __device__ __forceinline__ void rs_loop_run(const RsLoopArgs& a) {
 #pragma nounroll
         for (long long u = tid; u < U; u += NT) {
           const long long e = u * VEC;
-          const vecd<VEC> x0 = ldrow<VEC>(R + e), p0 = ldrow<VEC>(a.P + e), gold = ldrow<VEC>(Gm + e);
+          const vecd<VEC> x0 = ldrow<VEC>(R + e), gold = ldrow<VEC>(Gm + e);
+          vecd<VEC> p0;
+          if (!PDROP) p0 = ldrow<VEC>(a.P + e);
           const vecd<VEC> w = ldrow<VEC>(a.W + e);
           const vecd<VEC> d = ldrow<VEC>(Dl + e);
           vecd<VEC> sv[HM], yv[HM];
@@ -834,6 +871,7 @@ __device__ __forceinline__ void rs_loop_run(const RsLoopArgs& a) {
             }
           }
           const double dj = djl[j];
+          const double djo = PDROP ? rdl[j] : 0.0;
           ch += adv_r;
           j += adv_q;
           if (ch >= r) { ch -= r; j++; }
@@ -841,13 +879,18 @@ __device__ __forceinline__ void rs_loop_run(const RsLoopArgs& a) {
 #pragma unroll
           for (int q = 0; q < VEC; q++) {
             x.v[q] = x0.v[q] + al * d.v[q];                 // src/sdplr.jl:219
-            pp.v[q] = p0.v[q] + al * w.v[q];
-            g.v[q] = pp.v[q] * yg + x.v[q] * dj;
-            g.v[q] *= 2.0;                                  // src/coreop.jl:315
+            if (PDROP) {
+              const double t = al * w.v[q] + (x.v[q] * dj - x0.v[q] * djo);
+              g.v[q] = -gs * gold.v[q] + 2.0 * t;           // G_old + 2(αW + d_new∘R_new − d_old∘R_old)
+            } else {
+              pp.v[q] = p0.v[q] + al * w.v[q];
+              g.v[q] = pp.v[q] * yg + x.v[q] * dj;
+              g.v[q] *= 2.0;                                // src/coreop.jl:315
+            }
             nrm[0] += g.v[q] * g.v[q];
           }
           strow<VEC>(R + e, x);
-          strow<VEC>(a.P + e, pp);
+          if (!PDROP) strow<VEC>(a.P + e, pp);
           strow<VEC>(Gm + e, g);
           if (!upd) {   // relative-decrease exit: no update, y_next = −G_old as lbfgs_dir! leaves it (lbfgs.jl:121-123)
             vecd<VEC> go;
@@ -925,16 +968,16 @@ __device__ __forceinline__ void rs_loop_run(const RsLoopArgs& a) {
     a.out[5] = (double)c.iters; a.out[6] = (double)c.exit_reason; a.out[7] = (double)c.err;
   }
 }
-template <int VEC, int HM>
+template <int VEC, int HM, bool PDROP>
 __global__ void __launch_bounds__(SDPLR_RS_NT)
-k_rs_loop(RsLoopArgs a) { rs_loop_run<VEC, HM>(a); }
+k_rs_loop(RsLoopArgs a) { rs_loop_run<VEC, HM, PDROP>(a); }
 // one workgroup per instance: block b takes row b of the argument table (64 small instances: one launch on 64 CUs instead
 // of 64 launches that share the device only as far as the hardware queues allow)
-template <int VEC, int HM>
+template <int VEC, int HM, bool PDROP>
 __global__ void __launch_bounds__(SDPLR_RS_NT)
 k_rs_loop_batch(const RsLoopArgs* __restrict__ items) {
   const RsLoopArgs a = items[blockIdx.x];
-  rs_loop_run<VEC, HM>(a);
+  rs_loop_run<VEC, HM, PDROP>(a);
 }
 
 // ---- approx_mineigval_lanczos's recurrence (src/coreop.jl:473-500) in one launch -----------------------------------

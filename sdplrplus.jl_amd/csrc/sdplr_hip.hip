@@ -2680,12 +2680,15 @@ void rs_loop_set_in(RsLoopArgs& a, const RsLoopIn& in) {
   a.in_sigma = in.sigma; a.in_gtol = in.gtol; a.in_fprec = in.fprec; a.in_normC = in.normC; a.in_normb = in.normb;
   a.in_grel = in.grel; a.in_prel = in.prel; a.in_max_iters = in.max_iters;
 }
+// the resident loop without P (k_resident.h, PDROP): A_g is the cost matrix
+bool rs_can_drop_P(const S* s) { return s->ff.gid_g == (int)s->m && !s->no_pdrop; }
 int enq_resident_loop(S* s, double time_budget_s, bool refresh_P, bool pre_lambda = false, bool pre_clear_fg = false,
-                      const RsLoopIn* in = nullptr) {
+                      const RsLoopIn* in = nullptr, bool pdrop = false) {
   RsLoopArgs a = rs_loop_args(s, time_budget_s, refresh_P, pre_lambda, pre_clear_fg);
   if (in) rs_loop_set_in(a, *in);
   const size_t lds = rs_loop_lds(s);
-  RS_VEC_DISPATCH(s, ({ RS_SET_ATTR((k_rs_loop<VEC, 4>)); k_rs_loop<VEC, 4><<<1, SDPLR_RS_NT, lds, s->stream>>>(a); }))
+  if (pdrop) { RS_VEC_DISPATCH(s, ({ RS_SET_ATTR((k_rs_loop<VEC, 4, true>)); k_rs_loop<VEC, 4, true><<<1, SDPLR_RS_NT, lds, s->stream>>>(a); })) }
+  else { RS_VEC_DISPATCH(s, ({ RS_SET_ATTR((k_rs_loop<VEC, 4, false>)); k_rs_loop<VEC, 4, false><<<1, SDPLR_RS_NT, lds, s->stream>>>(a); })) }
   HIPCK(s, hipGetLastError());
   s->st_rs_loops++;
   return SDPLR_OK;
@@ -2694,13 +2697,21 @@ int enq_resident_loop(S* s, double time_budget_s, bool refresh_P, bool pre_lambd
 // launch + wait + the host-side bookkeeping of one resident loop (the control block has been pushed by the caller);
 // pre_lambda / pre_clear_fg: the head of a major iteration rides the same launch (sdplr_hip_major_iteration)
 int run_resident_loop(S* s, double time_budget_s, bool pre_lambda, bool pre_clear_fg, double* Lio, double* gnio, double* pnio,
-                      double* last_alpha, int64_t* iters, int32_t* exit_reason, const RsLoopIn* in = nullptr) {
+                      double* last_alpha, int64_t* iters, int32_t* exit_reason, const RsLoopIn* in = nullptr,
+                      bool G_was_consistent = false, bool resume = false) {
   static const int64_t refresh_iters = getenv("SDPLR_HIP_P_REFRESH_ITERS") ? atoll(getenv("SDPLR_HIP_P_REFRESH_ITERS")) : 256;
-  const bool refresh = pre_clear_fg || !s->P_valid || s->P_age >= refresh_iters;   // (fg! rebuilds P = A_g·R itself)
-  int rc = enq_resident_loop(s, time_budget_s, refresh, pre_lambda, pre_clear_fg, in);
+  // without P: G is carried forward from the fg! of the prologue, or from a G known to be the gradient at the device's
+  // state and not older than the refresh interval (otherwise this call runs the P-based loop, which rebuilds G at every step).
+  // resume (SDPLR_MAJOR_RESUME): the continuation of a capped loop takes the kernel the capped call took and refreshes
+  // nothing by age, so that cap + resume ≡ one uncapped call, bit for bit.
+  const bool pdrop = rs_can_drop_P(s) && (pre_clear_fg || (G_was_consistent && (resume ? s->pdrop_now : s->G_age < refresh_iters)));
+  const bool refresh = pre_clear_fg || !s->P_valid || (!resume && s->P_age >= refresh_iters);   // (fg! rebuilds P = A_g·R itself)
+  int rc = enq_resident_loop(s, time_budget_s, refresh, pre_lambda, pre_clear_fg, in, pdrop);
   if (rc) return rc;
-  s->P_valid = true;
+  s->pdrop_now = pdrop;
+  s->P_valid = !pdrop;
   if (refresh) s->P_age = 0;
+  if (pre_clear_fg || !pdrop) s->G_age = 0;
   s->S_stale = true;   // y is current, S is assembled by whoever reads it next (ensure_S)
   s->S_from_y = true;
   if (pre_clear_fg) { s->st_rs_fg++; s->gram_dirty = false; }
@@ -2718,6 +2729,8 @@ int run_resident_loop(S* s, double time_budget_s, bool pre_lambda, bool pre_clea
   }
   s->st_iters += c->iters;
   s->P_age += c->iters;
+  if (pdrop) s->G_age += c->iters;
+  s->G_consistent = true;
   *Lio = c->L; *gnio = c->gnorm; *pnio = c->pvnorm;
   if (last_alpha) *last_alpha = c->alpha;
   if (iters) *iters = c->iters;
@@ -3142,6 +3155,8 @@ int32_t sdplr_hip_fg(S* s, double normC, double normb, int32_t grel, int32_t pre
     s->S_stale = true;   // y is current; S is assembled by whoever reads it (ensure_S)
     s->S_from_y = true;
     s->sg_stale = true;
+    s->G_consistent = true;
+    s->G_age = 0;
     s->st_rs_fg++;
     if ((rc = pull(s))) return rc;
     if (L) *L = s->hc->L;
@@ -3284,10 +3299,21 @@ int32_t sdplr_hip_linesearch_armijo(S* s, double alpha_max, double* alpha, doubl
 }
 
 // ---- the inner loop ----------------------------------------------------------------------------------
+static int32_t inner_loop_impl(S* s, double normC, double normb, int32_t grel, int32_t prel, int32_t use_armijo,
+                               double cur_gtol, double fprec_eps, int64_t max_local_iters, double time_budget_s,
+                               double* Lio, double* gnio, double* pnio, double* last_alpha, int64_t* iters,
+                               int32_t* exit_reason, bool resume);
 int32_t sdplr_hip_inner_loop(S* s, double normC, double normb, int32_t grel, int32_t prel, int32_t use_armijo,
                              double cur_gtol, double fprec_eps, int64_t max_local_iters, double time_budget_s,
                              double* Lio, double* gnio, double* pnio, double* last_alpha, int64_t* iters,
                              int32_t* exit_reason) {
+  return inner_loop_impl(s, normC, normb, grel, prel, use_armijo, cur_gtol, fprec_eps, max_local_iters, time_budget_s, Lio, gnio,
+                         pnio, last_alpha, iters, exit_reason, false);
+}
+static int32_t inner_loop_impl(S* s, double normC, double normb, int32_t grel, int32_t prel, int32_t use_armijo,
+                               double cur_gtol, double fprec_eps, int64_t max_local_iters, double time_budget_s,
+                               double* Lio, double* gnio, double* pnio, double* last_alpha, int64_t* iters,
+                               int32_t* exit_reason, bool resume) {
   ApiLock api_lock(g_api_rw);
   bind_device(dev_of(s));
   const bool hc_was_valid = s && s->finalized && s->hc_valid;
@@ -3316,15 +3342,17 @@ int32_t sdplr_hip_inner_loop(S* s, double normC, double normb, int32_t grel, int
   if (rs_loop_applies(s, use_armijo)) {
     // resident route (k_resident.h): the whole while loop is ONE launch of one workgroup; every exit — the time
     // budget too — is taken on the device, the host reads the control block once
-    return run_resident_loop(s, time_budget_s, false, false, Lio, gnio, pnio, last_alpha, iters, exit_reason);
+    return run_resident_loop(s, time_budget_s, false, false, Lio, gnio, pnio, last_alpha, iters, exit_reason, nullptr, G_was_consistent, resume);
   }
   const bool fastp = s->fast;
   const bool fast2 = fastp && s->fast_singleton && !use_armijo;
   static const int64_t refresh_iters = getenv("SDPLR_HIP_P_REFRESH_ITERS") ? atoll(getenv("SDPLR_HIP_P_REFRESH_ITERS")) : 256;
   // the P-less step kernel carries G forward: only from a G known to be the gradient at the device's state, and only for
   // so many steps before G is formed from scratch again (every fg! does that anyway)
-  s->pdrop_now = fast2 && step_can_drop_P(s) && G_was_consistent;
-  if (s->pdrop_now && s->G_age >= refresh_iters) {
+  // (resume — SDPLR_MAJOR_RESUME — continues a capped loop: the kernel the capped call took, and nothing refreshed by age, so
+  // that cap + resume ≡ one uncapped call bit for bit)
+  s->pdrop_now = fast2 && step_can_drop_P(s) && G_was_consistent && (!resume || s->pdrop_now);
+  if (s->pdrop_now && !resume && s->G_age >= refresh_iters) {
     enq_g(s, 0, false);          // g! from scratch (src/coreop.jl:305-317): same y, S assembled, G = 2·R·S
     s->S_stale = false;
     s->G_age = 0;
@@ -3343,7 +3371,7 @@ int32_t sdplr_hip_inner_loop(S* s, double normC, double normb, int32_t grel, int
   if (s->pdrop_now) {
     s->P_valid = false;          // P is neither read nor kept up to date by this loop
   } else if (fastp) {
-    if (!s->P_valid || s->P_age >= refresh_iters) {
+    if (!s->P_valid || (!resume && s->P_age >= refresh_iters)) {
       enq_fast_refresh_P(s);
       s->P_valid = true;
       s->P_age = 0;
@@ -3508,6 +3536,9 @@ int32_t sdplr_hip_major_iteration(S* s, double normC, double normb, int32_t grel
                                   double* last_alpha, int64_t* iters, int32_t* exit_reason) {
   if (!s) return fail(nullptr, SDPLR_ERR_INVALID_ARG, "null handle");
   if (!L || !gn || !pn || max_local_iters < 1) return fail(s, SDPLR_ERR_INVALID_ARG, "major_iteration: bad args");
+  if (update_lambda == SDPLR_MAJOR_RESUME)   // the while loop continues where a capped call left it: ℒ and the norms are in/out
+    return inner_loop_impl(s, normC, normb, grel, prel, use_armijo, cur_gtol, fprec_eps, max_local_iters, time_budget_s, L, gn, pn,
+                           last_alpha, iters, exit_reason, true);
   bool resident = false;
   {
     ApiShared api_guard(dev_of(s));
@@ -3931,6 +3962,7 @@ int32_t sdplr_hip_batch_fg(int32_t count, sdplr_hip_fg_item* it) {
     std::map<ShapeKey, std::vector<int>> groups;
     for (int i = 0; i < count; i++) {
       S* s = it[i].s;
+      if (s) s->G_consistent = false;
       if (s && s->finalized && rs_fg_applies(s)) groups[{0, rs_vec(s)}].push_back(i);
       else single.push_back(i);
     }
@@ -3970,6 +4002,7 @@ int32_t sdplr_hip_batch_fg(int32_t count, sdplr_hip_fg_item* it) {
           q.status = rc;
           if (rc) { if (sk != s) sk->err = s->err; continue; }
           sk->P_valid = true; sk->P_age = 0; sk->S_stale = true; sk->S_from_y = true; sk->sg_stale = true;
+          sk->G_consistent = true; sk->G_age = 0;
           sk->st_rs_fg++; sk->st_rs_shared++;
           q.lagrangian = res[4 * k]; q.grad_norm = res[4 * k + 1]; q.primal_vio_norm = res[4 * k + 2]; q.obj = res[4 * k + 3];
         }
@@ -4000,17 +4033,30 @@ int32_t sdplr_hip_batch_major_iteration(int32_t count, sdplr_hip_major_item* it)
     if (!batch_one_device(hs, &dev)) return fail(nullptr, SDPLR_ERR_INVALID_ARG, "batch_major_iteration: the handles live on different devices");
     ApiShared api_guard(dev);
     std::map<ShapeKey, std::vector<int>> groups;
+    std::vector<char> was_cons(count, 0);
     for (int i = 0; i < count; i++) {
       S* s = it[i].s;
-      if (s && s->finalized && it[i].max_local_iters >= 1 && rs_loop_applies(s, it[i].use_armijo) && rs_fg_applies(s))
-        groups[{0, rs_vec(s)}].push_back(i);
-      else
+      const bool was_consistent = s && s->G_consistent;
+      was_cons[i] = was_consistent ? 1 : 0;
+      if (s) s->G_consistent = false;
+      const bool resume = it[i].update_lambda == SDPLR_MAJOR_RESUME;
+      // (fg! runs in the prologue: G is fresh, the P-less loop applies; a resumed loop takes the kernel it was capped in)
+      const bool pd = s && rs_can_drop_P(s) && (!resume || (was_consistent && s->pdrop_now));
+      if (s && s->finalized && it[i].max_local_iters >= 1 && rs_loop_applies(s, it[i].use_armijo) && rs_fg_applies(s)) {
+        groups[{pd ? 1 : 0, rs_vec(s)}].push_back(i);
+      } else {
+        if (s) s->G_consistent = was_consistent;   // (the single-instance entry point looks at it itself)
         single.push_back(i);
+      }
     }
     const size_t max_rows = ARENA_CHUNK / (batch_up(sizeof(RsLoopArgs)) + 128);
     for (auto& g : groups) {
       std::vector<int>& idx = g.second;
-      if (idx.size() < 2) { single.insert(single.end(), idx.begin(), idx.end()); continue; }
+      if (idx.size() < 2) {   // a lone shape: the single-instance entry point (which looks at G_consistent itself)
+        for (int i : idx) it[i].s->G_consistent = was_cons[i] != 0;
+        single.insert(single.end(), idx.begin(), idx.end());
+        continue;
+      }
       for (size_t lo = 0; lo < idx.size(); lo += max_rows) {
         const size_t nb = std::min(max_rows, idx.size() - lo);
         S* s = it[idx[lo]].s;
@@ -4026,8 +4072,10 @@ int32_t sdplr_hip_batch_major_iteration(int32_t count, sdplr_hip_major_item* it)
           const sdplr_hip_major_item& q = it[idx[lo + k]];
           S* sk = q.s;
           sk->hc_valid = false;
-          sk->sg_stale = sk->ynext_pending = false;   // (cleared history: see sdplr_hip_lbfgs_clear)
-          RsLoopArgs a = rs_loop_args(sk, q.time_budget_s, true, q.update_lambda != 0, true);
+          const bool resume = q.update_lambda == SDPLR_MAJOR_RESUME;
+          if (!resume) sk->sg_stale = sk->ynext_pending = false;   // (cleared history: see sdplr_hip_lbfgs_clear)
+          RsLoopArgs a = resume ? rs_loop_args(sk, q.time_budget_s, !sk->P_valid, false, false)
+                                : rs_loop_args(sk, q.time_budget_s, true, q.update_lambda != 0, true);
           RsLoopIn in{};
           in.sigma = q.sigma; in.gtol = q.cur_gtol; in.fprec = q.fprec_eps; in.normC = q.normC; in.normb = q.normb;
           in.grel = q.gtol_relative; in.prel = q.ptol_relative; in.max_iters = q.max_local_iters;
@@ -4038,7 +4086,8 @@ int32_t sdplr_hip_batch_major_iteration(int32_t count, sdplr_hip_major_item* it)
         }
         const RsLoopArgs* dtab = reinterpret_cast<const RsLoopArgs*>(bb.dev);
         int rc = batch_round_trip(s, bb, nb * sizeof(RsLoopArgs), res_off, nb * 8 * sizeof(double), [&](hipStream_t st) {
-          RS_VEC_DISPATCH(s, ({ RS_SET_ATTR((k_rs_loop_batch<VEC, 4>)); k_rs_loop_batch<VEC, 4><<<(int)nb, SDPLR_RS_NT, lds, st>>>(dtab); }))
+          if (g.first.first) { RS_VEC_DISPATCH(s, ({ RS_SET_ATTR((k_rs_loop_batch<VEC, 4, true>)); k_rs_loop_batch<VEC, 4, true><<<(int)nb, SDPLR_RS_NT, lds, st>>>(dtab); })) }
+          else { RS_VEC_DISPATCH(s, ({ RS_SET_ATTR((k_rs_loop_batch<VEC, 4, false>)); k_rs_loop_batch<VEC, 4, false><<<(int)nb, SDPLR_RS_NT, lds, st>>>(dtab); })) }
         });
         const double* res = reinterpret_cast<const double*>(bb.host + res_off);
         for (size_t k = 0; k < nb; k++) {
@@ -4050,8 +4099,12 @@ int32_t sdplr_hip_batch_major_iteration(int32_t count, sdplr_hip_major_item* it)
           const int why = (int)o[6], err = (int)o[7];
           const int64_t iters = (int64_t)o[5];
           // (the bookkeeping of run_resident_loop)
-          sk->P_valid = true; sk->P_age = iters; sk->S_stale = true; sk->S_from_y = true;
-          sk->st_rs_fg++; sk->st_rs_loops++; sk->st_rs_shared++; sk->gram_dirty = false;
+          const bool pd = g.first.first != 0, resumed = q.update_lambda == SDPLR_MAJOR_RESUME;
+          sk->pdrop_now = pd;
+          sk->P_valid = !pd; sk->P_age = (resumed ? sk->P_age : 0) + iters; sk->S_stale = true; sk->S_from_y = true;
+          sk->G_consistent = true; sk->G_age = pd ? (resumed ? sk->G_age : 0) + iters : 0;
+          if (!resumed) { sk->st_rs_fg++; sk->gram_dirty = false; }
+          sk->st_rs_loops++; sk->st_rs_shared++;
           sk->sg_stale = (why == EXIT_RELDELTA);
           sk->ynext_pending = (why == EXIT_RELDELTA) && sk->h > 0;
           if (err == SDPLR_ERR_NOT_DESCENT) {
@@ -4096,6 +4149,7 @@ int32_t sdplr_hip_batch_dual_obj(int32_t count, sdplr_hip_dual_item* it) {
     std::map<int, std::vector<int>> groups;   // keyed by "the packed columns fit in LDS" (the kernel's template flag)
     for (int i = 0; i < count; i++) {
       S* s = it[i].s;
+      if (s) s->G_consistent = false;   // (conservative, as the single-instance entry point)
       if (s && s->finalized && it[i].v0 && fused_ok && s->n >= 2 && rs_lanczos_ell_applies(s)) {
         bool in_lds = false;
         (void)rs_lz_ell_lds(s, &in_lds);

@@ -129,6 +129,44 @@ def test_solve_lockstep_equals_sdplr_one_by_one(hip_abi):
     assert one[0]["iter"] > 50 and all(x["majoriter"] < 40 for x in one)
 
 
+@pytest.mark.parametrize("cap", [5, 64])
+def test_capped_rounds_resume_bit_for_bit(hip_abi, cap):
+    """The lockstep driver caps the inner iterations per launch and resumes the loops that hit the cap (MAJOR_RESUME: the
+    resident kernel without its prologue, on the control block, the history and — without P — the G it left): the solves
+    equal the uncapped driver's and sdplr() one by one bit for bit, Gset instances (their longest inner loops run for
+    hundreds of iterations) and small random ones (even and odd ranks are different kernel shapes) alike."""
+    datas = [gset("G1"), gset("G2")] + [make_data("maxcut", s, n, 0.3)[0] for s, n in ((1, 40), (2, 64), (3, 25))]
+    for r in (10, 5):
+        uncapped = batch.solve_lockstep(datas, r, abi=hip_abi, setup_workers=2, iteration_cap=0, **KW)
+        capped = batch.solve_lockstep(datas, r, abi=hip_abi, setup_workers=2, iteration_cap=cap, **KW)
+        for a, b in zip(uncapped, capped):
+            same(a, b)
+        same(sj.sdplr(data=datas[0], r=r, abi=hip_abi, **KW), capped[0])
+
+
+def test_resume_on_the_single_entry_point(hip_abi):
+    """major_iteration(update_lambda = MAJOR_RESUME) ≡ the continuation of the loop: 12 iterations in one call equal
+    5 + 5 + 2 through two resumes (ℒ, norms, R, G, the history), on the resident route with and without P."""
+    data = gset("G3")
+    normC, normb = data.normC(), float(np.linalg.norm(data.b))
+
+    def run(chunks):
+        s_ = make_solver(hip_abi, data, 10, seed=3)[0]
+        out = s_.major_iteration(normC, normb, 1, 1, 0, 0, 2.0, 0.0, -1e300, chunks[0], 0.0)
+        total = out[4]
+        for c in chunks[1:]:
+            out = s_.major_iteration(normC, normb, 1, 1, 0, cabi.MAJOR_RESUME, 2.0, 0.0, -1e300, c, 0.0, *out[:3])
+            total += out[4]
+        state = (out[:4], total, s_.Rt.copy(), s_.Gt.copy(), s_.get_factor(cabi.F_LBFGS_Y + 1).copy())
+        s_.close()
+        return state
+
+    a, b = run([12]), run([5, 5, 2])
+    assert a[0] == b[0] and a[1] == b[1] == 12
+    for x, y in zip(a[2:], b[2:]):
+        assert np.array_equal(x, y)
+
+
 def test_lockstep_through_rank_doublings(hip_abi):
     """Rank doublings inside a lockstep batch (reset_rank, a fresh point, then single-instance fg! / inner loop for that
     instance while the others keep sharing launches): bit-identical to the solves one by one."""

@@ -40,6 +40,42 @@ def test_lockstep_equals_one_by_one_on_the_oracle(oracle_abi):
         same(a, b)
 
 
+@pytest.mark.parametrize("cap", [1, 3, 7])
+def test_capped_launches_resume_to_the_same_solve(oracle_abi, cap):
+    """A lockstep round caps the inner iterations per launch (SDPLR_LOCKSTEP_CAP) and RESUMES the loops that ran into the
+    cap (update_lambda = MAJOR_RESUME: no λ update, no lbfgs_clear!, no fg!) while the instances that have left theirs
+    move on: the solves must be those of the uncapped driver and of sdplr() one by one, result for result."""
+    datas = instances()
+    one = [sj.sdplr(data=d, r=4, abi=oracle_abi, **KW) for d in datas]
+    assert max(max(row[1] for row in x["schedule"]) for x in one) > 7      # (some inner loop is longer than every cap tried)
+    uncapped = batch.solve_lockstep(datas, 4, abi=oracle_abi, setup_workers=1, iteration_cap=0, **KW)
+    capped = batch.solve_lockstep(datas, 4, abi=oracle_abi, setup_workers=1, iteration_cap=cap, **KW)
+    for a, b, c in zip(one, uncapped, capped):
+        same(a, b)
+        same(a, c)
+
+
+def test_cap_bookkeeping():
+    """_Cap alone: a budget of 10 at cap 4 goes out as 4 (major), 4 (resume), 2 (resume); the stepper sees one answer with
+    all ten iterations; an early exit inside a launch ends the sequence there."""
+    cap = batch._Cap(4)
+    req = ("major_iteration", 1.0, 2.0, True, True, False, 1, 2.0, 1e-3, 1e-9, 10, 60.0)
+    out = cap.outgoing(0, req)
+    assert out[10] == 4 and out[6] == 1
+    assert cap.incoming(0, (5.0, 0.5, 0.1, 0.3, 4, batch.EXIT_ITERS, -1.0)) is None
+    out = cap.outgoing(0, req)
+    assert out[6] == cabi.MAJOR_RESUME and out[10] == 4 and out[12:] == (5.0, 0.5, 0.1)
+    assert cap.incoming(0, (4.0, 0.4, 0.1, 0.3, 4, batch.EXIT_ITERS, -1.5)) is None
+    out = cap.outgoing(0, req)
+    assert out[10] == 2
+    assert cap.incoming(0, (3.0, 0.3, 0.1, 0.2, 2, batch.EXIT_ITERS, -2.0)) == (3.0, 0.3, 0.1, 0.2, 10, batch.EXIT_ITERS, -2.0)
+    assert not cap.open
+    out = cap.outgoing(1, req)
+    assert cap.incoming(1, (3.0, 0.3, 0.1, 0.2, 3, 0, -2.0)) == (3.0, 0.3, 0.1, 0.2, 3, 0, -2.0) and not cap.open
+    small = req[:10] + (3, 60.0)
+    assert cap.outgoing(2, small) == small and cap.incoming(2, (1.0, 0.1, 0.1, 0.1, 3, batch.EXIT_ITERS, 0.0))[4] == 3
+
+
 def test_lockstep_through_rank_doublings(oracle_abi):
     """Instances that double their rank on the way (rank_update!: reset_rank + a fresh point, then fg! and an inner loop that
     are NOT batch calls) stay in step with the others."""
