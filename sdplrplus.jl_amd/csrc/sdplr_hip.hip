@@ -757,6 +757,14 @@ void choose_shape(S* s) {
 // rows, so every CU carries the same number of equally long lists and all sweeps stay in phase.  Every list is
 // padded to a multiple of the sub-wave width with (dump row K, column = the tile's first row, value 0) entries,
 // and the arrays end with 2·64 more entries so that the kernel's look-ahead stays in bounds.
+// Sub-wave width of the column-sweep tile kernel.  Rows wider than one DPP row (r > 32 at two doubles per lane) are
+// swept in several passes of the 16-lane shape — the kernel's loop over row chunks — instead of with 32- or 64-lane
+// groups: those hand entries round by ds_bpermute, run at 2 waves per SIMD, and put half / a quarter as many rows in a
+// block (n = 1e5: 172 µs per launch at r = 64 and 355 µs at r = 128 against 54 µs at r = 32, for 2× / 4× the bytes).
+int tile_shape_lpr(const S* s) {
+  static const bool off = getenv("SDPLR_HIP_TILE_WIDE_GROUPS") != nullptr;
+  return (!off && s->VEC == 2 && s->LPR > 16) ? 16 : s->LPR;
+}
 int build_tiles(S* s) {
   const int64_t n = s->n;
   struct ArenaOff {   // (the tile arrays are released one by one when the rank changes: never arena items)
@@ -776,7 +784,7 @@ int build_tiles(S* s) {
   const std::vector<int>&g_ptr = s->h_gptr, &g_col = s->h_gcol;
   const std::vector<double>& g_val = s->h_gval;
   choose_shape(s);
-  const int G = SDPLR_NT / s->LPR, L = s->LPR;
+  const int L = tile_shape_lpr(s), G = SDPLR_NT / L;
   // Tile height and grid: the tallest tiles of which TWO blocks fit a CU's 160 KB of LDS (16 rows at r = 32), cut for
   // 512 blocks — one resident round of 2 blocks per CU.  Measured on the north-star instance (µs per launch):
   // 1024 blocks × ≤ 8 rows 77, 768 × ≤ 10 64, 512 × ≤ 16 58, 256 × ≤ 32 69; a grid that is not a whole number of
@@ -860,6 +868,7 @@ int build_tiles(S* s) {
   s->tile_blocks = tblocks;
   s->tile_lpr = L;
   s->use_tile = true;
+  s->nb_tile = blocks_for(nt, G, tblocks);   // (also set by alloc_factors; tiles built later — tiles_deferred — come through here)
   return SDPLR_OK;
 }
 
@@ -1159,7 +1168,7 @@ int alloc_factors(S* s) {
   s->nb_edge = blocks_for(s->nnzT, SDPLR_EDGE_POS * G, SDPLR_MAXNB);   // k_sddmm_edge: its per-block partials are folded by one block
   s->nb_spmm = blocks_for(s->n, G, 768);  // + up to 256 hub-row blocks share the partial slot
   if (const char* e = getenv("SDPLR_HIP_NB_SPMM")) s->nb_spmm = std::max(1, std::min(atoi(e), 768));
-  s->nb_tile = blocks_for(s->tile.n_tiles, G, s->tile_blocks);   // one resident round; taller instances stride
+  s->nb_tile = blocks_for(s->tile.n_tiles, SDPLR_NT / std::max(1, s->tile_lpr > 0 ? s->tile_lpr : s->LPR), s->tile_blocks);   // one resident round; taller instances stride
   s->nb_lr = (s->N >= (1LL << 22)) ? 1024 : 256;   // low-rank projection grid (lr_part is sized for 1024)
   { const int tr = std::min<int>(s->LPR, SDPLR_STEP_TR); s->nb_step = blocks_for((s->n + tr - 1) / tr, G, step_fuses_update(s) ? 512 : 1024); }  // one group per tile of LPR rows; its ‖G‖², ‖pv‖² (and Gram)
                                                                     // partials are folded by the one-block seam kernel: keep them few
@@ -2126,6 +2135,12 @@ namespace {
   LV_CASE(1, 1, CALL) LV_CASE(2, 1, CALL) LV_CASE(4, 1, CALL) LV_CASE(8, 1, CALL) LV_CASE(16, 1, CALL) \
   LV_CASE(32, 1, CALL) LV_CASE(64, 1, CALL) LV_CASE(1, 2, CALL) LV_CASE(2, 2, CALL) LV_CASE(4, 2, CALL) \
   LV_CASE(8, 2, CALL) LV_CASE(16, 2, CALL) LV_CASE(32, 2, CALL) LV_CASE(64, 2, CALL) {}
+// (the tile kernel's own sub-wave shape: tile_shape_lpr)
+#define TLV_CASE(L, V, CALL) if (s->tile_lpr == L && s->VEC == V) { constexpr int LPR = L, VEC = V; CALL; } else
+#define TLV_DISPATCH(CALL)                                                                                \
+  TLV_CASE(1, 1, CALL) TLV_CASE(2, 1, CALL) TLV_CASE(4, 1, CALL) TLV_CASE(8, 1, CALL) TLV_CASE(16, 1, CALL) \
+  TLV_CASE(32, 1, CALL) TLV_CASE(64, 1, CALL) TLV_CASE(1, 2, CALL) TLV_CASE(2, 2, CALL) TLV_CASE(4, 2, CALL) \
+  TLV_CASE(8, 2, CALL) TLV_CASE(16, 2, CALL) TLV_CASE(32, 2, CALL) TLV_CASE(64, 2, CALL) {}
 #define HM_DISPATCH(CALL)                                       \
   if (s->HM == 4) { constexpr int HM = 4; CALL; }               \
   else if (s->HM == 8) { constexpr int HM = 8; CALL; }          \
@@ -2140,14 +2155,14 @@ int tile_lds_attr(S* s) {
     if (rc) return rc;
   }
   if (!s->use_tile || s->tile_attr_done) return SDPLR_OK;
-  const int bytes = (int)(((size_t)SDPLR_NT * s->VEC * (s->tile.K + 1) + (size_t)(SDPLR_NT / s->LPR) * (2 * s->tile.K + 8) + (size_t)(SDPLR_NT / 64) * 2 * s->LPR * s->VEC) * sizeof(double));
+  const int bytes = (int)(((size_t)SDPLR_NT * s->VEC * (s->tile.K + 1) + (size_t)(SDPLR_NT / s->tile_lpr) * (2 * s->tile.K + 8) + (size_t)(SDPLR_NT / 64) * 2 * s->tile_lpr * s->VEC) * sizeof(double));
   // The attribute is per function and PROCESS-wide: each instantiation keeps the largest value any handle has asked for
   // (a smaller request from another handle, or after a rank change, must not lower the cap under the first one's feet).
   static std::mutex mu;
   std::lock_guard<std::mutex> g(mu);
   hipError_t e = hipSuccess;
 #define TILE_ATTR(LRN)                                                                                                           \
-  LV_DISPATCH(({                                                                                                                  \
+  TLV_DISPATCH(({                                                                                                                  \
     static int cur_max = 0;                                                                                                       \
     if (bytes > cur_max) {                                                                                                        \
       e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_spmm_tile<LPR, VEC, LRN>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes); \
@@ -2462,11 +2477,11 @@ void enq_iteration_fast(S* s, int armijo) {
     (void)hipMemsetAsync(s->A_DD, 0, (s->m + 1) * sizeof(double), s->stream);
   }
   // W = A_g·D and the row dots: the column-sweep tile kernel when it applies (no hub rows), else two kernels
-  const bool tiled = s->use_tile && s->tile_lpr == s->LPR && s->n * s->r * 8 < (1LL << 32) && s->spg.n_long_rows == 0;
+  const bool tiled = s->use_tile && s->tile_lpr == tile_shape_lpr(s) && s->n * s->r * 8 < (1LL << 32) && s->spg.n_long_rows == 0;
   if (tiled) {
     ProfScope ps(s, "spmm_W");
-    const size_t lds = ((size_t)SDPLR_NT * s->VEC * (s->tile.K + 1) + (size_t)(SDPLR_NT / s->LPR) * (2 * s->tile.K + 8)) * sizeof(double);
-    LV_DISPATCH((k_spmm_tile<LPR, VEC, 0><<<s->nb_tile, SDPLR_NT, lds, s->stream>>>(s->tile, (int)s->n, (int)s->m, s->ff, R, D, P, W, (int)s->r, s->lambda, s->pv_raw, s->sp_fast.UVt0, s->sp_fast.UVt1, s->partials, s->ctrl, 1, s->lr, s->lr_part, 1)))
+    const size_t lds = ((size_t)SDPLR_NT * s->VEC * (s->tile.K + 1) + (size_t)(SDPLR_NT / s->tile_lpr) * (2 * s->tile.K + 8)) * sizeof(double);
+    TLV_DISPATCH((k_spmm_tile<LPR, VEC, 0><<<s->nb_tile, SDPLR_NT, lds, s->stream>>>(s->tile, (int)s->n, (int)s->m, s->ff, R, D, P, W, (int)s->r, s->lambda, s->pv_raw, s->sp_fast.UVt0, s->sp_fast.UVt1, s->partials, s->ctrl, 1, s->lr, s->lr_part, 1)))
   } else {
   {
     ProfScope ps(s, "rowdots");
@@ -2556,17 +2571,17 @@ void enq_iteration_fast2(S* s) {
 #endif
   {
     ProfScope ps(s, "spmm_W");   // W = A_g·D + row dots + line-search sums of the row-attached constraints
-    if (s->use_tile && s->tile_lpr == s->LPR && s->n * s->r * 8 < (1LL << 32)) {
-      lr_fused = s->lr.ST == 1 && s->r <= (int64_t)s->LPR * s->VEC && !s->no_lrfuse;
-      const size_t lds = ((size_t)SDPLR_NT * s->VEC * (s->tile.K + 1) + (size_t)(SDPLR_NT / s->LPR) * (2 * s->tile.K + 8) + (lr_fused ? (size_t)(SDPLR_NT / 64) * 2 * s->LPR * s->VEC : 0)) * sizeof(double);
-      if (lr_fused) { LV_DISPATCH((k_spmm_tile<LPR, VEC, 1><<<s->nb_tile, SDPLR_NT, lds, s->stream>>>(s->tile, (int)s->n, (int)s->m, s->ff, R, D, P, W, (int)s->r, s->lambda, s->pv_raw, s->A_RD, s->A_DD, s->partials, s->ctrl, 1, s->lr, s->lr_part, 0))) }
-      else if (s->tile_panels && s->VEC == 2 && s->LPR == 16) {
+    if (s->use_tile && s->tile_lpr == tile_shape_lpr(s) && s->n * s->r * 8 < (1LL << 32)) {
+      lr_fused = s->lr.ST == 1 && s->r <= (int64_t)s->tile_lpr * s->VEC && !s->no_lrfuse;
+      const size_t lds = ((size_t)SDPLR_NT * s->VEC * (s->tile.K + 1) + (size_t)(SDPLR_NT / s->tile_lpr) * (2 * s->tile.K + 8) + (lr_fused ? (size_t)(SDPLR_NT / 64) * 2 * s->tile_lpr * s->VEC : 0)) * sizeof(double);
+      if (lr_fused) { TLV_DISPATCH((k_spmm_tile<LPR, VEC, 1><<<s->nb_tile, SDPLR_NT, lds, s->stream>>>(s->tile, (int)s->n, (int)s->m, s->ff, R, D, P, W, (int)s->r, s->lambda, s->pv_raw, s->A_RD, s->A_DD, s->partials, s->ctrl, 1, s->lr, s->lr_part, 0))) }
+      else if (s->tile_panels && s->VEC == 2 && s->tile_lpr == 16 && s->LPR == 16) {
         // rank panels: the same kernel with 8 bytes per lane walks the lists once per 16-column half of the rank, so a
         // gathered row is 128 B and the XCD's L2 holds twice as many of them (tile kernel)
         const size_t lds1 = ((size_t)SDPLR_NT * 1 * (s->tile.K + 1) + (size_t)(SDPLR_NT / s->LPR) * (2 * s->tile.K + 8)) * sizeof(double);
         k_spmm_tile<16, 1, 0><<<s->nb_tile, SDPLR_NT, lds1, s->stream>>>(s->tile, (int)s->n, (int)s->m, s->ff, R, D, P, W, (int)s->r, s->lambda, s->pv_raw, s->A_RD, s->A_DD, s->partials, s->ctrl, 1, s->lr, s->lr_part, 0);
       }
-      else { LV_DISPATCH((k_spmm_tile<LPR, VEC, 0><<<s->nb_tile, SDPLR_NT, lds, s->stream>>>(s->tile, (int)s->n, (int)s->m, s->ff, R, D, P, W, (int)s->r, s->lambda, s->pv_raw, s->A_RD, s->A_DD, s->partials, s->ctrl, 1, s->lr, s->lr_part, 0))) }
+      else { TLV_DISPATCH((k_spmm_tile<LPR, VEC, 0><<<s->nb_tile, SDPLR_NT, lds, s->stream>>>(s->tile, (int)s->n, (int)s->m, s->ff, R, D, P, W, (int)s->r, s->lambda, s->pv_raw, s->A_RD, s->A_DD, s->partials, s->ctrl, 1, s->lr, s->lr_part, 0))) }
     } else {
       LV_DISPATCH((k_spmm_fast<LPR, VEC><<<s->nb_spmm, SDPLR_NT, 0, s->stream>>>(s->spg, (int)s->m, s->ff, R, D, P, W, (int)s->r, s->lambda, s->pv_raw, s->A_RD, s->A_DD, s->partials, s->ctrl, 1)))
     }
@@ -2581,7 +2596,7 @@ void enq_iteration_fast2(S* s) {
   }
   {
     ProfScope ps(s, "ls_solve_fast");
-    k_ls_solve_fast<<<1, SDPLR_LSF_NT, 0, s->stream>>>(s->ctrl, (int)s->m, s->ff.gid_g, s->n_extra, s->extra_slots, (s->use_tile && s->tile_lpr == s->LPR && s->n * s->r * 8 < (1LL << 32)) ? s->nb_tile : s->nb_spmm, s->A_RD, s->A_DD, s->lambda, s->lambda_ub, s->pv_raw, s->pv_lb, s->pv, s->y, s->lr.ST, (int)s->r, s->lr.col_gid, s->lr.Dcat, s->lr_W, s->lr_WS, s->partials, 1, lr_fused ? 1 : 0, s->lr.n_lr, s->lr.mat_ptr, s->lr.mat_gid, nullptr, s->extra_head);
+    k_ls_solve_fast<<<1, SDPLR_LSF_NT, 0, s->stream>>>(s->ctrl, (int)s->m, s->ff.gid_g, s->n_extra, s->extra_slots, (s->use_tile && s->tile_lpr == tile_shape_lpr(s) && s->n * s->r * 8 < (1LL << 32)) ? s->nb_tile : s->nb_spmm, s->A_RD, s->A_DD, s->lambda, s->lambda_ub, s->pv_raw, s->pv_lb, s->pv, s->y, s->lr.ST, (int)s->r, s->lr.col_gid, s->lr.Dcat, s->lr_W, s->lr_WS, s->partials, 1, lr_fused ? 1 : 0, s->lr.n_lr, s->lr.mat_ptr, s->lr.mat_gid, nullptr, s->extra_head);
   }
   // (a variant fusing this step kernel with lbfgs_update! was measured at 111 µs against 38 + 59 µs for the
   // two kernels — 166 VGPRs and scratch — and dropped)
