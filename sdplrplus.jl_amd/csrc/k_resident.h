@@ -187,6 +187,25 @@ __device__ __forceinline__ void rs_ell_pass(const unsigned* __restrict__ ep, con
 // DOTS (the loop's W = A_g·D): the lane that owns row j also forms that row's four line-search dots while W_j is in its
 // registers — ⟨R_j,D_j⟩ and ‖D_j‖² to the LDS vectors rdl / ddl, ⟨R_j,W_j⟩ and ⟨D_j,W_j⟩ into the lane's running sums rw / dw
 // (R_j is requested before the gather loop and arrives under it; D_j is in LDS) — so that no pass re-reads W and R for them.
+// one rank-one matrix D·b·bᵀ among the constraints (MinBisection's 1ᵀX1 = 0, test/problem.jl:78-94): the only low-rank
+// structure the resident route takes.  Its products are r-vectors: w0 = Rᵀb, w1 = Dᵀb (src/coreop.jl:115-151), its share of
+// the gradient 2·b_j·(y_c·D·w0) (src/structs.jl:117-145).
+struct RsLr {
+  const double* B;   // [n] the column b; null: no low-rank matrix
+  double D;
+  int gid;           // its slot in the (m+1)-vectors (a constraint: gid < m)
+};
+// out[c] = Σ_j b_j·X[j][c] for the r columns of a factor-shaped LDS array: one column per wave and trip, the lanes stride the
+// rows (fixed order: lane partials, then the DPP wave sum) — a barrier must separate it from the writes of X and the reads of out
+__device__ __forceinline__ void rs_colsum(const double* Xl, const double* __restrict__ b, int n, int r, double* out) {
+  const int wave = threadIdx.x >> 6, wl = threadIdx.x & 63;
+  for (int c = wave; c < r; c += SDPLR_RS_NW) {
+    double t = 0.0;
+    for (int j = wl; j < n; j += 64) t += b[j] * Xl[(long long)j * r + c];
+    t = wave_sum(t);
+    if (wl == 0) out[c] = t;
+  }
+}
 struct RsDots {
   const double* R;
   double *rdl, *ddl;
@@ -305,6 +324,7 @@ struct RsFgArgs {
   double *y, *pv_raw, *pv;
   const double *lam, *lam_ub, *lb, *b;
   DevCtrl* c;
+  RsLr lr;
   // batched launches (sdplr_hip_batch_fg): the norm parameters ride the argument row instead of a pushed control block,
   // and the scalars the host reads back go to a row of a result table instead of a pulled one
   int in_set, in_grel, in_prel;
@@ -317,9 +337,10 @@ struct RsFgShared {
   double yg, obj_row;
   int has_obj_row;
 };
+// lrl: LDS, 2r doubles — w0 = Rᵀb and ws = y_c·D·w0 of the rank-one matrix (left there for the loop that follows)
 template <int VEC>
 __device__ __forceinline__ void rs_fg_body(const RsFgArgs& a, DevCtrl& c, double* Rl, double* rrl, double* djl, double* sred,
-                                           RsFgShared& sh) {
+                                           RsFgShared& sh, double* lrl) {
   constexpr int NT = SDPLR_RS_NT;
   const int tid = threadIdx.x;
   const int n = a.n, m = a.m, r = a.r;
@@ -337,8 +358,24 @@ __device__ __forceinline__ void rs_fg_body(const RsFgArgs& a, DevCtrl& c, double
     rs_ell_spmm_dots<VEC>(a.E, Rl, n, r, a.P, dots, acc[0], same);
   }
   rs_sum_to0<1>(reinterpret_cast<double(&)[1]>(acc[0]), sred);
+  const bool has_lr = a.lr.B != nullptr;
+  if (has_lr) rs_colsum(Rl, a.lr.B, n, r, lrl);   // w0 = Rᵀb
   __syncthreads();
   double fs = 0.0, pn = 0.0;
+  if (tid == 0 && has_lr) {   // the rank-one matrix's slot: 𝒜(RRᵀ)_c = D·‖Rᵀb‖²  (src/coreop.jl:115-120,132-139)
+    const int kc = a.lr.gid;
+    double q = 0.0;
+    for (int ch = 0; ch < r; ch++) q += lrl[ch] * lrl[ch];
+    double v = a.lr.D * q - a.b[kc];
+    const double pc = fmax(v, a.lb[kc]);
+    a.pv[kc] = pc;
+    pn += pc * pc;
+    const double l = a.lam[kc], yt = fmin(a.lam_ub[kc], l - sigma * v);
+    fs += (yt * yt - l * l) / (2 * sigma);
+    a.pv_raw[kc] = v;
+    a.y[kc] = -yt;
+    for (int ch = 0; ch < r; ch++) lrl[r + ch] = -yt * a.lr.D * lrl[ch];   // ws = y_c·D·w0
+  }
   if (tid == 0) {   // A_g's slot
     const int kg = a.gid_g;
     double v = acc[0];
@@ -395,6 +432,8 @@ __device__ __forceinline__ void rs_fg_body(const RsFgArgs& a, DevCtrl& c, double
       const long long e = u * VEC;
       const vecd<VEC> x = ldrow<VEC>(Rl + e), p = ldrow<VEC>(a.P + e);
       const double dj = djl[j];
+      const double bj = has_lr ? a.lr.B[j] : 0.0;
+      const int ch0 = ch;
       ch += adv_r;
       j += adv_q;
       if (ch >= r) { ch -= r; j++; }
@@ -402,6 +441,7 @@ __device__ __forceinline__ void rs_fg_body(const RsFgArgs& a, DevCtrl& c, double
 #pragma unroll
       for (int k = 0; k < VEC; k++) {
         g.v[k] = p.v[k] * yg + x.v[k] * dj;
+        if (has_lr) g.v[k] += lrl[r + ch0 + k] * bj;          // + Σ_c WS[c]·B[c]  (src/coreop.jl:271-278)
         g.v[k] *= 2.0;                                        // src/coreop.jl:315
         gn += g.v[k] * g.v[k];
       }
@@ -435,7 +475,7 @@ __device__ __forceinline__ void rs_fg_run(const RsFgArgs& a) {
     }
     __syncthreads();
   }
-  rs_fg_body<VEC>(a, *a.c, rs_lds, rs_lds + Npad, rs_lds + Npad + a.n, sred, sh);
+  rs_fg_body<VEC>(a, *a.c, rs_lds, rs_lds + Npad, rs_lds + Npad + a.n, sred, sh, rs_lds + Npad + 2 * a.n);
   if (a.out != nullptr && threadIdx.x == 0) {
     a.out[0] = a.c->L; a.out[1] = a.c->gnorm; a.out[2] = a.c->pvnorm; a.out[3] = a.c->obj;
   }
@@ -462,6 +502,7 @@ struct RsLoopArgs {
   double *y, *pv_raw, *pv, *A_RD, *A_DD;
   const double *lam, *lam_ub, *lb;
   DevCtrl* c;
+  RsLr lr;
   int refresh_P;                        // P = A_g·R from scratch before the first iteration
   // the head of a major iteration in the same launch (sdplr_hip_major_iteration): λ update (src/sdplr.jl:358-362),
   // lbfgs_clear! (:384, src/lbfgs.jl:52-59), fg! (:389) — then the while loop (:190-278) on what fg! returned
@@ -519,6 +560,11 @@ __device__ __forceinline__ void rs_loop_run(const RsLoopArgs& a) {
   double* rdl = Dl + Npad;             // [n] ⟨R_j, D_j⟩
   double* ddl = rdl + n;               // [n] ‖D_j‖²
   double* djl = ddl + n;               // [n] d_j = v_j·y[k_j]
+  double* const w0l = djl + n;         // [r] Rᵀb of the rank-one matrix, [r] y_c·D·w0 (same order as rs_fg_body leaves them) …
+  double* const wsl = w0l + r;
+  double* const w1l = wsl + r;         // … [r] Dᵀb, [r] the previous y_c·D·w0 (PDROP)
+  double* const wsol = w1l + r;
+  const bool has_lr = a.lr.B != nullptr;
   double* const R = aslot(a.A, AS_R);
   double* const Gm = aslot(a.A, AS_G);
   // the control block → LDS (one coalesced load)
@@ -564,8 +610,17 @@ __device__ __forceinline__ void rs_loop_run(const RsLoopArgs& a) {
       f.n = n; f.m = m; f.r = r; f.gid_g = a.gid_g; f.row_k = a.row_k; f.row_v = a.row_v; f.E = a.E;
       f.R = R; f.G = Gm; f.P = a.P; f.y = a.y; f.pv_raw = a.pv_raw; f.pv = a.pv;
       f.lam = a.lam; f.lam_ub = a.lam_ub; f.lb = a.lb; f.b = a.b; f.c = a.c;
-      rs_fg_body<VEC>(f, gd.c, Dl, rdl, djl, sred, fsh);
+      f.lr = a.lr;
+      rs_fg_body<VEC>(f, gd.c, Dl, rdl, djl, sred, fsh, w0l);
     }
+  }
+  if (has_lr && !a.pre_fg) {   // w0 = Rᵀb and ws = y_c·D·w0 at the point and multipliers the previous g! left
+    for (long long e = tid; e < N; e += NT) Dl[e] = R[e];
+    __syncthreads();
+    rs_colsum(Dl, a.lr.B, n, r, w0l);
+    __syncthreads();
+    if (tid < r) wsl[tid] = a.y[a.lr.gid] * a.lr.D * w0l[tid];
+    __syncthreads();
   }
   // constraint data of this thread's rows: constant over the call except primal_vio_raw, which the thread owns
   RsRow rw_[SDPLR_RS_RPT];
@@ -676,6 +731,7 @@ __device__ __forceinline__ void rs_loop_run(const RsLoopArgs& a) {
       if ((N & 1) && tid == 0) dir_unit(std::integral_constant<int, 1>{}, N - 1);
     }
     __syncthreads();
+    if (has_lr) rs_colsum(Dl, a.lr.B, n, r, w1l);   // w1 = Dᵀb (read by SOLVE, two barriers on)
     RS_STAMP(1);
     // ================= SPMM =================
     // W = A_g·D, one row per lane — and, by the lane that owns the row, ⟨R_j,D_j⟩, ‖D_j‖² (→ rdl, ddl) and this lane's part
@@ -698,11 +754,13 @@ __device__ __forceinline__ void rs_loop_run(const RsLoopArgs& a) {
       const double sigma = gd.c.sigma;
       auto ls_row = [&](int j, const RsRow& rw) {
         if (rw.k < 0) return;
+        int kk = rw.k;
+        asm volatile("" : "+v"(kk));   // (opaque: see commit_row)
         const double rd = rdl[j], dd = ddl[j];
         const double q1 = rw.v * (rd + rd), q2 = rw.v * dd;
-        a.A_RD[rw.k] = q1;
-        a.A_DD[rw.k] = q2;
-        if (rw.k < m) {
+        a.A_RD[kk] = q1;
+        a.A_DD[kk] = q2;
+        if (kk < m) {
           const double l = rw.lam, nq0 = rw.pvr;
           acc[0] += l * nq0;
           acc[1] += nq0 * nq0;
@@ -746,6 +804,30 @@ __device__ __forceinline__ void rs_loop_run(const RsLoopArgs& a) {
         acc[6] += g_rd * g_dd;
         acc[7] += g_dd * g_dd;
       }
+      // the rank-one matrix's slot: ⟨A_c, RDᵀ+DRᵀ⟩ = 2·D·⟨w0, w1⟩, ⟨A_c, DDᵀ⟩ = D·‖w1‖²  (src/coreop.jl:122-130,141-151)
+      double lr_q1 = 0.0, lr_q2 = 0.0, lr_pv = 0.0, lr_l = 0.0;
+      if (has_lr) {
+        const int kc = a.lr.gid;
+        double s01 = 0.0, s11 = 0.0;
+        for (int ch = 0; ch < r; ch++) {
+          s01 += w0l[ch] * w1l[ch];
+          s11 += w1l[ch] * w1l[ch];
+        }
+        lr_q1 = 2.0 * (a.lr.D * s01);
+        lr_q2 = a.lr.D * s11;
+        a.A_RD[kc] = lr_q1;
+        a.A_DD[kc] = lr_q2;
+        lr_pv = a.pv_raw[kc];
+        lr_l = a.lam[kc];
+        acc[0] += lr_l * lr_pv;
+        acc[1] += lr_pv * lr_pv;
+        acc[2] += lr_l * lr_q1;
+        acc[3] += lr_pv * lr_q1;
+        acc[4] += (lr_l - sigma * lr_pv) * lr_q2;
+        acc[5] += lr_q1 * lr_q1;
+        acc[6] += lr_q1 * lr_q2;
+        acc[7] += lr_q2 * lr_q2;
+      }
       const double p0 = c.obj, p1 = (kg == m) ? g_rd : sh_p1, p2 = (kg == m) ? g_dd : sh_p2;
       double bq[5];
       bq[0] = p0 - acc[0] + sigma * acc[1] / 2;
@@ -782,6 +864,22 @@ __device__ __forceinline__ void rs_loop_run(const RsLoopArgs& a) {
         }
         a.y[kg] = yk;
         sh_yg = yk;
+        if (has_lr) {   // commit of the rank-one matrix's slot; W0 ← W0 + α·W1 = R_newᵀb; WS = y_c·D·W0  (k_ls_solve_fast's tail)
+          const int kc = a.lr.gid;
+          const double vc = lr_pv + al * (al * lr_q2 + lr_q1);
+          a.pv_raw[kc] = vc;
+          const double pcc = fmax(vc, a.lb[kc]);
+          a.pv[kc] = pcc;
+          pv2 += pcc * pcc;
+          const double yc = -fmin(a.lam_ub[kc], lr_l - sigma * vc);
+          a.y[kc] = yc;
+          for (int ch = 0; ch < r; ch++) {
+            const double w = w0l[ch] + al * w1l[ch];
+            w0l[ch] = w;
+            wsol[ch] = wsl[ch];
+            wsl[ch] = yc * a.lr.D * w;
+          }
+        }
         c.pv2_extra = pv2;
       }
     }
@@ -801,25 +899,28 @@ __device__ __forceinline__ void rs_loop_run(const RsLoopArgs& a) {
       auto commit_row = [&](int j, RsRow& rw) {
         double dj = 0.0;
         if (rw.k >= 0) {
-          int kb = rw.k < m ? rw.k : 0;
-          asm volatile("" : "+v"(kb));   // (opaque: a loop-invariant address pair hoisted out of the persistent loop is a spill)
-          const double lub = (rw.k < m) ? a.lam_ub[kb] : 0.0, lbv = (rw.k < m) ? a.lb[kb] : 0.0;
+          // (opaque: the addresses derived from a row's constraint index are loop-invariant per thread, and every address
+          // pair the compiler hoists out of the persistent loop stays live across all its phases — a spill)
+          int kk = rw.k;
+          asm volatile("" : "+v"(kk));
+          const int kb = kk < m ? kk : 0;
+          const double lub = (kk < m) ? a.lam_ub[kb] : 0.0, lbv = (kk < m) ? a.lb[kb] : 0.0;
           const double rd = rdl[j], dd = ddl[j];
           const double q1 = rw.v * (rd + rd), q2 = rw.v * dd;
           const double v = rw.pvr + al * (al * q2 + q1);     // src/linesearch.jl:118
           rw.pvr = v;
-          a.pv_raw[rw.k] = v;
+          a.pv_raw[kk] = v;
           double yk;
-          if (rw.k < m) {
+          if (kk < m) {
             yk = -fmin(lub, rw.lam - sigma * v);              // src/coreop.jl:233
             const double pc = fmax(v, lbv);                   // src/linesearch.jl:122-124
-            a.pv[rw.k] = pc;
+            a.pv[kk] = pc;
             nrm[1] += pc * pc;
           } else {
             yk = 1.0;                                         // the cost slot, src/coreop.jl:235
             gd.c.obj = v;
           }
-          a.y[rw.k] = yk;
+          a.y[kk] = yk;
           dj = rw.v * yk;
         }
         if (PDROP) rdl[j] = djl[j];    // d_j at the old multipliers, for STEP (⟨R_j,D_j⟩ has been consumed above)
@@ -872,6 +973,8 @@ __device__ __forceinline__ void rs_loop_run(const RsLoopArgs& a) {
           }
           const double dj = djl[j];
           const double djo = PDROP ? rdl[j] : 0.0;
+          const double bj = has_lr ? a.lr.B[j] : 0.0;
+          const int ch0 = ch;
           ch += adv_r;
           j += adv_q;
           if (ch >= r) { ch -= r; j++; }
@@ -880,11 +983,13 @@ __device__ __forceinline__ void rs_loop_run(const RsLoopArgs& a) {
           for (int q = 0; q < VEC; q++) {
             x.v[q] = x0.v[q] + al * d.v[q];                 // src/sdplr.jl:219
             if (PDROP) {
-              const double t = al * w.v[q] + (x.v[q] * dj - x0.v[q] * djo);
-              g.v[q] = -gs * gold.v[q] + 2.0 * t;           // G_old + 2(αW + d_new∘R_new − d_old∘R_old)
+              double t = al * w.v[q] + (x.v[q] * dj - x0.v[q] * djo);
+              if (has_lr) t += bj * (wsl[ch0 + q] - wsol[ch0 + q]);   // + b_j·(WS_new − WS_old)
+              g.v[q] = -gs * gold.v[q] + 2.0 * t;           // G_old + 2(αW + d_new∘R_new − d_old∘R_old [+ low-rank])
             } else {
               pp.v[q] = p0.v[q] + al * w.v[q];
               g.v[q] = pp.v[q] * yg + x.v[q] * dj;
+              if (has_lr) g.v[q] += wsl[ch0 + q] * bj;      // + Σ_c WS[c]·B[c]  (src/coreop.jl:271-278)
               g.v[q] *= 2.0;                                // src/coreop.jl:315
             }
             nrm[0] += g.v[q] * g.v[q];
@@ -1103,6 +1208,7 @@ struct RsLzEllArgs {
   const double* v0;
   double *alpha_out, *beta_out;
   DevCtrl* c;
+  RsLr lr;
   // dual_obj (src/coreop.jl:376-415) around the recurrence, in the same launch: copy2y_λ_sub_pvio! (:384) before it,
   // ⟨y[1:m], b⟩ (:412) and the smallest eigenvalue of the tridiagonal (:502-513) after it
   int dual, m;
@@ -1158,6 +1264,9 @@ __device__ __forceinline__ void rs_lanczos_ell_run(const RsLzEllArgs& a) {
   const double yg = a.yvec[a.gid_g];
   const bool uniform = a.E.val == nullptr;
   const double s_off = yg * a.E.one;         // the value every off-diagonal entry of S has (unit weights)
+  // the rank-one matrix's share of S·v: y_c·D·b·⟨b, v⟩  (src/coreop.jl:291-298, src/structs.jl:135-145)
+  const bool has_lr = a.lr.B != nullptr;
+  const double lr_coef = has_lr ? a.yvec[a.lr.gid] * a.lr.D : 0.0;
   {   // v = v0/‖v0‖ (:473-474); the diagonal of S
     double s = 0.0;
     for (int i = tid; i < n; i += NT) {
@@ -1200,6 +1309,12 @@ __device__ __forceinline__ void rs_lanczos_ell_run(const RsLzEllArgs& a) {
   for (int it = 0; it < a.q; it++) {
     // Av = S·v  (:483), one row per lane
     double dot = 0.0;
+    double lr_bv = 0.0;
+    if (has_lr) {
+      double t = 0.0;
+      for (int i = tid; i < n; i += NT) t += a.lr.B[i] * v[i];
+      lr_bv = lr_coef * bsum(t);
+    }
 #pragma nounroll
     for (int sl = wave; sl < a.E.n_slices; sl += SDPLR_RS_NW) {
       const int idx = sl * 64 + wl;
@@ -1252,7 +1367,8 @@ __device__ __forceinline__ void rs_lanczos_ell_run(const RsLzEllArgs& a) {
       }
       if (jp >= 0) {
         const double vj = v[jp];
-        const double t = acc + sdiag[jp] * vj;
+        double t = acc + sdiag[jp] * vj;
+        if (has_lr) t += a.lr.B[jp] * lr_bv;
         av[jp] = t;
         dot += vj * t;
       }

@@ -702,8 +702,14 @@ int sync_check(S* s) {
 
 // dynamic LDS the resident loop needs (k_resident.h) and its budget; tiles_can_wait: "small enough for that route"
 constexpr size_t RS_LDS_MAX = 150 * 1024;   // dynamic LDS of a resident kernel (≈ 9.6 KB more are static: control block, reduction scratch)
-size_t rs_loop_lds(const S* s) {   // D (with the SpMM's zero row) | ⟨R_j,D_j⟩ | ‖D_j‖² | d_j
-  return ((size_t)rs_npad(s->n, s->r) + 3 * (size_t)s->n) * sizeof(double);
+size_t rs_loop_lds(const S* s) {   // D (with the SpMM's zero row) | ⟨R_j,D_j⟩ | ‖D_j‖² | d_j | four r-vectors of the rank-one matrix
+  return ((size_t)rs_npad(s->n, s->r) + 3 * (size_t)s->n + 4 * (size_t)s->r) * sizeof(double);
+}
+RsLr rs_lr(const S* s) {   // the one rank-one matrix of an instance of the resident route (finalize: lr_one), or none
+  RsLr l{};
+  l.B = nullptr; l.D = 0.0; l.gid = -1;
+  if (s->h_lr.size() == 1 && s->h_lr[0].s == 1) { l.B = s->lr.Bcat; l.D = s->h_lr[0].D[0]; l.gid = (int)s->h_lr[0].gid; }
+  return l;
 }
 bool tiles_can_wait(const S* s) {
   return !s->force_graph && getenv("SDPLR_HIP_NO_RESIDENT") == nullptr && rs_loop_lds(s) <= RS_LDS_MAX;
@@ -1786,7 +1792,11 @@ int32_t sdplr_hip_finalize(S* s) {
       s->n_extra = (int)extra.size();
       s->fast_singleton = single && s->spg.n_long_rows == 0 && getenv("SDPLR_HIP_NO_FAST2") == nullptr;
       // resident route for small instances (k_resident.h): row-local constraint data, one constraint per row at most
-      bool one_per_row = s->fast_singleton && s->h_lr.empty();
+      // … and at most one rank-one matrix among the constraints (MinBisection), A_g being the cost matrix
+      const bool lr_none = s->h_lr.empty();
+      const bool lr_one = s->h_lr.size() == 1 && s->h_lr[0].s == 1 && s->h_lr[0].gid < s->m && s->h_gids[kg] == (int)s->m &&
+                          getenv("SDPLR_HIP_NO_RESIDENT_LR") == nullptr;
+      bool one_per_row = s->fast_singleton && (lr_none || lr_one);
       for (int64_t i = 0; i < n && one_per_row; i++) one_per_row = d_ptr[i + 1] - d_ptr[i] <= 1;
       if (one_per_row) {
         std::vector<int> row_k(n, -1);
@@ -2668,6 +2678,7 @@ inline int rs_vec(const S* s) { return s->r % 2 == 0 ? 2 : 1; }
 
 RsLoopArgs rs_loop_args(S* s, double time_budget_s, bool refresh_P, bool pre_lambda, bool pre_clear_fg) {
   RsLoopArgs a{};
+  a.lr = rs_lr(s);
   a.pre_lambda = pre_lambda ? 1 : 0;
   a.pre_clear = a.pre_fg = pre_clear_fg ? 1 : 0;
   a.b = s->b;
@@ -2887,6 +2898,7 @@ void enq_lz_step(S* s, double* uprev, double* u, double* t) {
 RsLzEllArgs rs_lz_ell_args(S* s, int64_t q, bool dual) {
   const int64_t n = s->n;
   RsLzEllArgs a{};
+  a.lr = rs_lr(s);
   a.n = (int)n; a.q = (int)q;
   a.E = s->rs_ell; a.gid_g = s->ff.gid_g; a.row_k = s->rs_row_k; a.row_v = s->rs_row_v;
   a.yvec = s->y; a.v0 = s->lz_v0;
@@ -3137,6 +3149,7 @@ int32_t sdplr_hip_g(S* s) {
 namespace {
 RsFgArgs rs_fg_args(S* s) {
   RsFgArgs a{};
+  a.lr = rs_lr(s);
   a.n = (int)s->n; a.m = (int)s->m; a.r = (int)s->r;
   a.gid_g = s->ff.gid_g; a.row_k = s->rs_row_k; a.row_v = s->rs_row_v; a.E = s->rs_ell;
   a.R = aslot(s->arena, AS_R); a.G = aslot(s->arena, AS_G); a.P = aslot(s->arena, 3 + 2 * (int)s->h);

@@ -83,10 +83,10 @@ def test_batch_calls_equal_the_single_calls_bit_for_bit(hip_abi):
 
 def test_batch_of_mixed_routes_and_shapes(hip_abi, oracle_abi, monkeypatch):
     """One call with: resident instances of both kernel shapes (even ranks 6 and 20: 16-byte pieces of a row; odd ranks 5, 7
-    and 3: 8-byte ones — one launch per shape) and an instance with a low-rank constraint (multi-launch route) — the call
-    is total, every item equals its single-instance twin."""
+    and 3: 8-byte ones — one launch per shape), among them one with a rank-one constraint (MinBisection, rank 6), and an
+    instance of the edge path (Lovász-θ: multi-launch route) — the call is total, every item equals its single-instance twin."""
     specs = [("maxcut", 1, 40, 6), ("maxcut", 2, 50, 20), ("maxcut", 3, 30, 5), ("maxcut", 4, 36, 7),
-             ("minimum_bisection", 5, 24, 6), ("maxcut", 6, 28, 3)]
+             ("lovasz_theta", 5, 24, 6), ("maxcut", 6, 28, 3), ("minimum_bisection", 7, 26, 6)]
     datas = [make_data(f, s, n, 0.3)[0] for f, s, n, _ in specs]
     A = [make_solver(hip_abi, d, sp[3], seed=3)[0] for d, sp in zip(datas, specs)]
     B = [make_solver(hip_abi, d, sp[3], seed=3)[0] for d, sp in zip(datas, specs)]
@@ -101,7 +101,7 @@ def test_batch_of_mixed_routes_and_shapes(hip_abi, oracle_abi, monkeypatch):
     for x, s in zip(da, B):
         assert np.array_equal(x[2], s.y)
     shared = [s.stats()["resident_shared_launches"] for s in A]
-    assert shared[:4] == [3, 3, 3, 3] and shared[4] == 0 and shared[5] == 3
+    assert shared[:4] == [3, 3, 3, 3] and shared[4] == 0 and shared[5] == 3 and shared[6] == 3
     # … and against the oracle, to the resident route's tolerances
     for k in (1, 2):
         o = make_solver(oracle_abi, datas[k], specs[k][3], seed=3)[0]

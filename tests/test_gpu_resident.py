@@ -50,7 +50,11 @@ def run(s, normC, normb, k, st, gtol=0.0, fprec=-1e300, budget=0.0):
 @pytest.mark.parametrize("family,n,r,h", [("maxcut", 12, 3, 4), ("maxcut", 40, 8, 1), ("maxcut", 40, 10, 2),
                                           ("cutnorm", 14, 5, 4), ("maxcut", 30, 2, 3),
                                           ("maxcut", 15, 3, 2),      # n·r odd: the 16-byte units of DIR leave one element over
-                                          ("maxcut", 67, 1, 4)])     # rank one, one row more than a slice
+                                          ("maxcut", 67, 1, 4),      # rank one, one row more than a slice
+                                          # a rank-one matrix among the constraints (1ᵀX1 = 0, test/problem.jl:78-94): its
+                                          # r-vectors Rᵀb, Dᵀb live in LDS, its slot is committed by the scalar stage
+                                          ("minimum_bisection", 30, 4, 4), ("minimum_bisection", 41, 3, 2),
+                                          ("minimum_bisection", 64, 10, 4)])
 def test_resident_loop_iteration_by_iteration(hip_abi, oracle_abi, family, n, r, h):
     """One iteration per call, eight calls: ℒ, ‖grad‖, ‖pv‖ to 1e-8 (north_star's tolerance), R, G, y, primal_vio_raw,
     dirt (restored from s_latest on the way out), the history bookkeeping; every call must have been ONE resident
@@ -72,7 +76,7 @@ def test_resident_loop_iteration_by_iteration(hip_abi, oracle_abi, family, n, r,
         assert rel(g.Rt, o.Rt) < 1e-8 and rel(g.Gt, o.Gt) < 1e-7
         assert rel(g.dirt, o.dirt) < 1e-7
         assert rel(g.y, o.y) < 1e-8 and rel(g.primal_vio_raw, o.primal_vio_raw) < 1e-8
-        assert g.obj == pytest.approx(o.obj, rel=1e-9)
+        assert g.obj == pytest.approx(o.obj, rel=1e-9, abs=1e-9)   # (abs: MinBisection's objective passes near zero on the way)
         assert g.get_scalar(cabi.S_LBFGS_LATEST) == o.get_scalar(cabi.S_LBFGS_LATEST)
         sg, so = rg[:3], ro[:3]
     st = g.stats()
@@ -250,7 +254,7 @@ def test_resident_lanczos_and_dual_obj(hip_abi, oracle_abi, family, monkeypatch)
     (dg, eg), (do, eo) = g.dual_obj(float(n), 0, v0), o.dual_obj(float(n), 0, v0)
     assert g.stats()["resident_lanczos"] == 1
     assert eg == pytest.approx(eo, abs=1e-8 * max(1, abs(eo))) and dg == pytest.approx(do, rel=1e-8)
-    if family == "maxcut":
+    if family in ("maxcut", "minimum_bisection"):
         # on the instances of the resident loop dual_obj is ONE launch (copy2y, the recurrence, the tridiagonal's smallest
         # eigenvalue by 64-point multisection, ⟨y, b⟩); piece by piece — host bisection — it must give the very same numbers
         monkeypatch.setenv("SDPLR_HIP_NO_FUSED_DUAL", "1")
@@ -274,6 +278,60 @@ def test_resident_lanczos_and_dual_obj(hip_abi, oracle_abi, family, monkeypatch)
             a1, b1, k1 = s_.lanczos(6, e3)
             assert k1 == 1 and a1[0] == 4.0 and b1[0] == 0.0
     g.close(); o.close()
+
+
+def test_resident_rank_one_constraint_agrees_with_the_multi_launch_route(hip_abi, oracle_abi, monkeypatch):
+    """MinBisection on a Gset graph (the reference's batch generator names it: exps/gen_batch_test.jl:3; n = 800, rank 10)
+    on the resident route — the rank-one constraint's projections in LDS — against the same library's multi-launch route
+    (SDPLR_HIP_NO_RESIDENT_LR=1 keeps instances with a low-rank matrix off the resident route) and the oracle: fg!, 10
+    iterations in three calls (a continuation without fg!: the P-less kernel carries G and the low-rank share forward),
+    the dual bound.  (Ten, not more: on this family round-off differences — here the order in which Rᵀb and Dᵀb are
+    summed — grow by ≈ 1.7× per iteration, 4e-10 on R after 10 iterations and 5e-7 after 25 against the oracle, where
+    the multi-launch route, which sums in the oracle's row order, stays 15× closer: scripts/probes/diag_mb.py.)"""
+    data = problems.minimum_bisection_data(gset("G2"))
+    normC, normb = data.normC(), float(np.linalg.norm(data.b))
+    v0 = np.random.Generator(np.random.PCG64(3)).standard_normal(data.n)
+    out = {}
+    for route in ("resident", "launches", "oracle"):
+        if route == "launches":
+            monkeypatch.setenv("SDPLR_HIP_NO_RESIDENT_LR", "1")
+        s_, _ = make_solver(oracle_abi if route == "oracle" else hip_abi, data, 10, seed=2)
+        st = s_.fg(normC, normb)
+        fg0 = st
+        for k in (4, 4, 2):
+            st = run(s_, normC, normb, k, st)[:3]
+        dual = s_.dual_obj(float(data.n), 0, v0)
+        stats = s_.stats() if route != "oracle" else None
+        out[route] = (fg0, st, s_.Rt.copy(), s_.Gt.copy(), s_.y.copy(), dual, stats)
+        s_.close()
+        monkeypatch.delenv("SDPLR_HIP_NO_RESIDENT_LR", raising=False)
+    assert out["resident"][6]["resident_loops"] == 3 and out["resident"][6]["resident_fg"] == 1
+    assert out["resident"][6]["resident_lanczos"] == 1 and out["launches"][6]["resident_loops"] == 0
+    for other in ("launches", "oracle"):
+        a, b = out["resident"], out[other]
+        assert np.allclose(a[0], b[0], rtol=1e-11) and np.allclose(a[1], b[1], rtol=1e-8, atol=1e-10)
+        assert rel(a[2], b[2]) < 1e-8 and rel(a[3], b[3]) < 1e-6 and rel(a[4], b[4]) < 1e-7
+        assert a[5][0] == pytest.approx(b[5][0], rel=1e-6) and a[5][1] == pytest.approx(b[5][1], abs=1e-6 * max(1.0, abs(b[5][1])))
+
+
+def test_resident_solve_of_a_minimum_bisection_instance(hip_abi, oracle_abi):
+    """sdplr() end to end on MinBisection of Gset G1 (rank 10, ptol = objtol = 0.01): every inner loop and dual bound one
+    launch, the result inside the tolerance window of the oracle's solve, a second run bit-identical, and the lockstep
+    driver (MaxCut and MinBisection instances side by side: two P-less / P-based groups per round) equal to one by one."""
+    from sdplrplus_jl_amd import batch
+    data = problems.minimum_bisection_data(gset("G1"))
+    kw = dict(ptol=0.01, objtol=0.01, seed=0, prior_trace_bound=800.0, printlevel=0, maxtime=120.0)
+    a = sj.sdplr(data=data, r=10, **kw)
+    b = sj.sdplr(data=data, r=10, **kw)
+    o = sj.sdplr(data=data, r=10, abi=oracle_abi, **kw)
+    assert a["obj"] == b["obj"] and a["max_dual_value"] == b["max_dual_value"] and a["iter"] == b["iter"]
+    assert abs(a["obj"] - o["obj"]) <= 2e-2 * abs(o["obj"])
+    assert abs(a["max_dual_value"] - o["max_dual_value"]) <= 3e-2 * abs(o["max_dual_value"])
+    datas = [data, problems.maxcut_data(gset("G3")), problems.minimum_bisection_data(gset("G4")), problems.maxcut_data(gset("G5"))]
+    many = batch.solve_lockstep(datas, 10, **kw)
+    assert many[0]["obj"] == a["obj"] and many[0]["iter"] == a["iter"] and np.array_equal(many[0]["Rt"], a["Rt"])
+    one = sj.sdplr(data=datas[2], r=10, **kw)
+    assert many[2]["obj"] == one["obj"] and many[2]["iter"] == one["iter"]
 
 
 def test_resident_solve_of_a_gset_instance(hip_abi, oracle_abi):
