@@ -126,6 +126,8 @@ def algorithmic_bytes(d, h):
         # … with lbfgs_update! fused in: R, D, P, W, G_old in; R, P, G, s_j, y_j out (the other history pairs the
         # Gram form re-reads are this design's choice, not compulsory)
         "fast_step_upd": 10 * N,
+        # … and without P (the gradient carried forward from G_old; stats: p_less_loops): R, D, W, G_old in; R, G, s_j, y_j out
+        "fast_step_upd_pless": 8 * N,
     }
     b_iter = ((2 * h + 1) * N + 2 * N      # lbfgs_dir!
               + 2 * N                      # dot(dirt, Gt)
@@ -327,7 +329,8 @@ def main():
     if prof_all.get("fast_step", (0, 0.0))[0] and not prof_all.get("lbfgs_update", (0, 0.0))[0]:
         # lbfgs_update! rides the step kernel (k_fast_step2<…,4>): charged the fused dataflow's compulsory bytes,
         # and the in-loop direction kernel no longer parks y_next
-        per_kernel_bytes["fast_step"] = per_kernel_bytes["fast_step_upd"]
+        pless = hasattr(var, "stats") and var.stats().get("p_less_loops", 0) > 0     # … and P = A_g·R is neither read nor written
+        per_kernel_bytes["fast_step"] = per_kernel_bytes["fast_step_upd_pless" if pless else "fast_step_upd"]
         per_kernel_bytes["lbfgs_dir"] = per_kernel_bytes["lbfgs_dir_noynext"]
     candidates = [k for k in per_kernel_bytes if k in prof_all]
     dominant = max(candidates, key=lambda k: prof_all[k][1]) if candidates else "fast_step"
@@ -449,7 +452,7 @@ def measure_config(sj, abi, data, r, seed, K=200, W=20, P=40, parity_iters=PARIT
     fused_step = prof.get("fast_step", (0, 0.0))[0] and not prof.get("lbfgs_update", (0, 0.0))[0]
     fused_spmm = prof.get("spmm", (0, 0.0))[0] and not prof.get("lbfgs_update", (0, 0.0))[0] and not prof.get("fast_step", (0, 0.0))[0]
     if fused_step:
-        per_kernel["fast_step"] = per_kernel["fast_step_upd"]
+        per_kernel["fast_step"] = per_kernel["fast_step_upd_pless" if var.stats().get("p_less_loops", 0) > 0 else "fast_step_upd"]
         per_kernel["lbfgs_dir"] = per_kernel["lbfgs_dir_noynext"]
     if fused_spmm:
         per_kernel["spmm"] = per_kernel["spmm_upd"]
@@ -551,6 +554,45 @@ def other_configs(sj, abi):
                               "inner_iterations_total": int(rows[:, 3].sum()), "max_abs_relative_gap": float(np.max(np.abs(gap))),
                               "route": "resident (one launch per major iteration and per dual bound)",
                               "all_converged": bool(np.all(np.abs(gap) <= 1e-2))}
+    # the resident kernel itself, one instance on one CU: device time per inner iteration against the bytes an iteration
+    # requests from the XCD's L2 (DIR 9 streams in, STEP 11 in + 4 out, the SpMM R in + W out + the ELL lines; the
+    # direction itself lives in LDS).  The bound is the CU's L2 REQUEST rate (MI355X_MICROARCH.md: 66–73 GB/s per CU at 8 bytes
+    # per lane, twice that at the 16 bytes these phases ask for), not HBM: the state of an instance (≈ 0.8 MB) never leaves L2.
+    one = sj.build_solver(abi, datas[0], 10, sj.BurerMonteiroConfig(seed=0, printlevel=0))
+    nC, nB = datas[0].normC(), float(np.linalg.norm(datas[0].b))
+    st = one.fg(nC, nB)
+    st = one.inner_loop(nC, nB, True, True, False, 0.0, -1e300, 50, 0.0, *st)[:3]
+    abi.device_synchronize()
+    t0 = time.perf_counter()
+    st = one.inner_loop(nC, nB, True, True, False, 0.0, -1e300, 400, 0.0, *st)[:3]
+    abi.device_synchronize()
+    us_it = 1e6 * (time.perf_counter() - t0) / 400
+    dd = one.dims()
+    Ns = 8.0 * dd["n"] * dd["r"]
+    ell_bytes = 4.0 * (dd["nnzS"] - dd["n"]) + 8.0 * 4 * dd["n"]
+    it_bytes = 9 * Ns + (2 * Ns + ell_bytes) + 15 * Ns
+    one.close()
+    out["config5_batch64"]["roofline"] = {
+        "bound": "l2-request-rate of ONE CU (resident route: a workgroup per instance; 64 of 256 CUs busy with the batch)",
+        "kernel": "k_rs_loop (one inner iteration = SEAM, DIR, SPMM, LSSUM, SOLVE, COMMIT, STEP inside one launch)",
+        "us_per_iteration": us_it, "bytes_per_iteration": it_bytes, "achieved": it_bytes / us_it / 1e3, "peak": 134.0,
+        "unit": "GB/s per CU", "frac": it_bytes / us_it / 1e3 / 134.0, "traffic": None}
+    # ---- the reference's batch generator names three more problems (exps/gen_batch_test.jl:3); MinBisection on G1–G9 takes
+    # the resident route too (a rank-one constraint), Lovász-θ and CutNorm (n = 1600) the multi-launch routes ----
+    for name, build in (("MinimumBisection", problems.minimum_bisection_data), ("LovaszTheta", problems.lovasz_theta_data)):
+        ds = [build(g) for g in graphs[:9]]
+        kw2 = dict(ptol=1e-2, objtol=1e-2, seed=0, prior_trace_bound=1.0 if name == "LovaszTheta" else 800.0, maxtime=60.0)
+        if name != "LovaszTheta":   # (Lovász-θ on these graphs takes ≈ 6e4 inner iterations per instance, ≈ 13 s for the nine: one pass)
+            batch.solve_local(ds, 0, 1, 10, concurrency=conc, lockstep=True, **kw2)
+        abi.device_synchronize()
+        t0 = time.perf_counter()
+        r_ = batch.solve_local(ds, 0, 1, 10, concurrency=conc, lockstep=True, **kw2)
+        w_ = time.perf_counter() - t0
+        gp = (r_[:, 1] - r_[:, 2]) / np.maximum(1e-300, np.minimum(np.abs(r_[:, 1]), np.abs(r_[:, 2])))
+        out["batch_G1_G9_" + name] = {"workload": f"{name} on Gset G1–G9 (exps/gen_batch_test.jl:1-3), rank 10, ptol=objtol=1e-2, lockstep driver, one GPU",
+                                      "instances": 9, "wall_s": w_, "inner_iterations_total": int(r_[:, 3].sum()),
+                                      "route": "resident" if name == "MinimumBisection" else "multi-launch (edge path)",
+                                      "max_abs_relative_gap": float(np.max(np.abs(gp)))}
     out["seconds_spent"] = time.perf_counter() - t_all
     return out
 

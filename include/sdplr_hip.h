@@ -337,7 +337,9 @@ int32_t sdplr_hip_factor_dot(sdplr_hip_solver* s, int32_t slot_a, int32_t slot_b
  * eagerly, out[7] inner iterations run, out[8] inner loops run as ONE resident launch (small instances: one
  * workgroup owns the instance for the whole loop), out[9] Lanczos runs as one resident launch, out[10] fg! calls as
  * one resident launch, out[11] of those launches (loops, Lanczos runs, fg!) the ones this instance shared with others
- * (sdplr_hip_batch_*).  Writes min(cap, 12) entries, *n_written says how many.                            */
+ * (sdplr_hip_batch_*), out[12] the inner loops (calls) that ran the step kernel WITHOUT P = A_g·R (the gradient carried
+ * forward from G_old: cost matrix = the general sparse matrix, no low-rank term on the multi-launch route).  Writes
+ * min(cap, 13) entries, *n_written says how many.                                                               */
 int32_t sdplr_hip_get_stats(const sdplr_hip_solver* s, int64_t* out, int32_t cap, int32_t* n_written);
 
 /* ---- per-kernel device timing (hipEvent pairs on the handle's stream) ------------------------ */

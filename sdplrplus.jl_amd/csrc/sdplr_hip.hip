@@ -210,7 +210,7 @@ struct sdplr_hip_solver {
   double* scratchV = nullptr;
   // counters (sdplr_hip_get_stats)
   int64_t st_captures = 0, st_capture_failed = 0, st_capture_skipped = 0, st_graph_batches = 0,
-          st_eager_batches = 0, st_lz_graph = 0, st_lz_eager = 0, st_iters = 0, st_rs_loops = 0, st_rs_lz = 0, st_rs_fg = 0, st_rs_shared = 0;
+          st_eager_batches = 0, st_lz_graph = 0, st_lz_eager = 0, st_iters = 0, st_rs_loops = 0, st_rs_lz = 0, st_rs_fg = 0, st_rs_shared = 0, st_pdrop = 0;
 
   // profiling
   bool prof_on = false;
@@ -2755,7 +2755,7 @@ int run_resident_loop(S* s, double time_budget_s, bool pre_lambda, bool pre_clea
   }
   s->st_iters += c->iters;
   s->P_age += c->iters;
-  if (pdrop) s->G_age += c->iters;
+  if (pdrop) { s->G_age += c->iters; s->st_pdrop++; }
   s->G_consistent = true;
   *Lio = c->L; *gnio = c->gnorm; *pnio = c->pvnorm;
   if (last_alpha) *last_alpha = c->alpha;
@@ -3116,10 +3116,10 @@ int32_t sdplr_hip_At_right_device(S* s, const double* x, double* yd, int64_t k) 
 
 int32_t sdplr_hip_get_stats(const S* s, int64_t* out, int32_t cap, int32_t* n_written) {
   if (!s || !out || cap < 0) return SDPLR_ERR_INVALID_ARG;
-  const int64_t v[12] = {s->st_captures, s->st_capture_failed, s->st_capture_skipped, s->st_graph_batches,
+  const int64_t v[13] = {s->st_captures, s->st_capture_failed, s->st_capture_skipped, s->st_graph_batches,
                          s->st_eager_batches, s->st_lz_graph, s->st_lz_eager, s->st_iters, s->st_rs_loops, s->st_rs_lz, s->st_rs_fg,
-                         s->st_rs_shared};
-  const int32_t k = std::min<int32_t>(cap, 12);
+                         s->st_rs_shared, s->st_pdrop};
+  const int32_t k = std::min<int32_t>(cap, 13);
   for (int32_t i = 0; i < k; i++) out[i] = v[i];
   if (n_written) *n_written = k;
   return SDPLR_OK;
@@ -3547,6 +3547,7 @@ static int32_t inner_loop_impl(S* s, double normC, double normb, int32_t grel, i
   s->st_iters += c->iters;
   s->P_age += c->iters;
   s->G_age = s->pdrop_now ? s->G_age + c->iters : 0;   // (the P-based kernels form G from P and y at every step)
+  if (s->pdrop_now) s->st_pdrop++;
   s->G_consistent = true;                              // g! has run at the loop's last point
   *Lio = c->L; *gnio = c->gnorm; *pnio = c->pvnorm;
   if (last_alpha) *last_alpha = c->alpha;
@@ -4129,6 +4130,7 @@ int32_t sdplr_hip_batch_major_iteration(int32_t count, sdplr_hip_major_item* it)
           // (the bookkeeping of run_resident_loop)
           const bool pd = g.first.first != 0, resumed = q.update_lambda == SDPLR_MAJOR_RESUME;
           sk->pdrop_now = pd;
+          if (pd) sk->st_pdrop++;
           sk->P_valid = !pd; sk->P_age = (resumed ? sk->P_age : 0) + iters; sk->S_stale = true; sk->S_from_y = true;
           sk->G_consistent = true; sk->G_age = pd ? (resumed ? sk->G_age : 0) + iters : 0;
           if (!resumed) { sk->st_rs_fg++; sk->gram_dirty = false; }
