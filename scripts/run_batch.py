@@ -80,7 +80,7 @@ def main():
     assert abi.set_device(local_rank) == 0
     entries = manifest(args.batch)
     builders = {"MaxCut": problems.maxcut_data, "MinimumBisection": problems.minimum_bisection_data,
-                "LovaszTheta": problems.lovasz_theta_data}
+                "LovaszTheta": problems.lovasz_theta_data, "CutNorm": problems.cutnorm_data}
     e0 = entries[0]
     assert all(e["problem"] == e0["problem"] and e["rank"] == e0["rank"] and e["ptol"] == e0["ptol"] for e in entries)
     graphs = [load_graph(e["graph"]) for e in entries]
@@ -97,7 +97,7 @@ def main():
     mine = set(batch.assign(len(graphs), world)[rank])
     datas = [builders[e0["problem"]](g) if k in mine else None for k, g in enumerate(graphs)]
     build_s = time.perf_counter() - tb0
-    tb = 1.0 if e0["problem"] == "LovaszTheta" else float(max(g.shape[0] for g in graphs))     # exps/test.jl:166-176
+    tb = 1.0 if e0["problem"] == "LovaszTheta" else float(max(g.shape[0] for g in graphs))     # exps/test.jl:166-176 (CutNorm too: n of the graph, not 2n)
     lockstep = os.environ.get("SDPLR_BATCH_MODE", "lockstep") == "lockstep"     # ("threads": independent driver threads)
     # Two passes over the batch: the first one also fills the library's pools (streams, pinned blocks, device blocks of the
     # sizes this batch uses — a lockstep batch has all its handles alive at once), the second one is the steady state of a

@@ -414,7 +414,11 @@ k_lbfgs_boundary(DevCtrl* __restrict__ c, int h, int jfixed, int fin_mode, int d
 // ---- direction: dir = ∓(G − Σ α_l y_l + Σ γ_l s_l); y_next = −G; partial ⟨dir, G⟩ -----------------
 // src/lbfgs.jl:84 (copy), :94-113 (as one combination), :116-118 (negate), :121-123 (y_next = −grad),
 // src/sdplr.jl:201 (descent).
-template <int HM>
+// NTH: the history is read with non-temporal loads — when the iteration's working set (the factor arena) is larger than the
+// 256 MiB Infinity Cache, so that the once-per-kernel history streams do not evict the direction the gather kernel is about
+// to re-read (north-star instance, 333 MB: +4 %); a working set that FITS the cache (Lovász-θ stand-in, 140 MB) is served
+// from it on every pass, and there the hint only loses that (−2.3 %): plain loads.
+template <int HM, bool NTH = true>
 __global__ void __launch_bounds__(SDPLR_NT)
 k_lbfgs_dir(const DevCtrl* __restrict__ c, FactorArena A, long long N, int h, int negate,
             int check_done, double* __restrict__ partials, int inline_fallback) {
@@ -467,13 +471,13 @@ k_lbfgs_dir(const DevCtrl* __restrict__ c, FactorArena A, long long N, int h, in
     double2 yv[HM], sv[HM];
 #pragma unroll
     for (int k = 0; k < HM; k++) {
-#ifdef SDPLR_DIR_HIST_PLAIN   /* experiment: let the history allocate in the Infinity Cache for the step kernel's re-read */
-      yv[k] = reinterpret_cast<const double2*>(yp[k])[i];
-      sv[k] = reinterpret_cast<const double2*>(sp_[k])[i];
-#else
-      yv[k] = ldnt2(yp[k], i);
-      sv[k] = ldnt2(sp_[k], i);
-#endif
+      if constexpr (NTH) {
+        yv[k] = ldnt2(yp[k], i);
+        sv[k] = ldnt2(sp_[k], i);
+      } else {
+        yv[k] = reinterpret_cast<const double2*>(yp[k])[i];
+        sv[k] = reinterpret_cast<const double2*>(sp_[k])[i];
+      }
     }
     double2 r = g;
 #pragma unroll

@@ -325,6 +325,7 @@ struct RsFgArgs {
   const double *lam, *lam_ub, *lb, *b;
   DevCtrl* c;
   RsLr lr;
+  double* rowvec;                       // null, or 3n doubles of global memory for the per-row vectors (see RsLoopArgs)
   // batched launches (sdplr_hip_batch_fg): the norm parameters ride the argument row instead of a pushed control block,
   // and the scalars the host reads back go to a row of a result table instead of a pulled one
   int in_set, in_grel, in_prel;
@@ -475,7 +476,8 @@ __device__ __forceinline__ void rs_fg_run(const RsFgArgs& a) {
     }
     __syncthreads();
   }
-  rs_fg_body<VEC>(a, *a.c, rs_lds, rs_lds + Npad, rs_lds + Npad + a.n, sred, sh, rs_lds + Npad + 2 * a.n);
+  if (a.rowvec != nullptr) rs_fg_body<VEC>(a, *a.c, rs_lds, a.rowvec, a.rowvec + a.n, sred, sh, rs_lds + Npad);
+  else rs_fg_body<VEC>(a, *a.c, rs_lds, rs_lds + Npad, rs_lds + Npad + a.n, sred, sh, rs_lds + Npad + 2 * a.n);
   if (a.out != nullptr && threadIdx.x == 0) {
     a.out[0] = a.c->L; a.out[1] = a.c->gnorm; a.out[2] = a.c->pvnorm; a.out[3] = a.c->obj;
   }
@@ -503,6 +505,11 @@ struct RsLoopArgs {
   const double *lam, *lam_ub, *lb;
   DevCtrl* c;
   RsLr lr;
+  // The per-row vectors (⟨R_j,D_j⟩, ‖D_j‖², d_j: 3n doubles) live in LDS next to the direction — or, when the direction
+  // alone fills the CU's LDS (CutNorm on a Gset graph: n = 1600, rank 10: 128 KB), in this global scratch: each is
+  // written once and read once per phase by other threads of the same workgroup, behind its barriers (through the L2,
+  // like W and the 𝒜 values).
+  double* rowvec;
   int refresh_P;                        // P = A_g·R from scratch before the first iteration
   // the head of a major iteration in the same launch (sdplr_hip_major_iteration): λ update (src/sdplr.jl:358-362),
   // lbfgs_clear! (:384, src/lbfgs.jl:52-59), fg! (:389) — then the while loop (:190-278) on what fg! returned
@@ -557,10 +564,11 @@ __device__ __forceinline__ void rs_loop_run(const RsLoopArgs& a) {
   const long long Npad = rs_npad(n, r);
   double* Dl = rs_lds;                 // [Npad] the direction (or R while P is being refreshed), then the zero row
   for (long long e = N + threadIdx.x; e < Npad; e += SDPLR_RS_NT) Dl[e] = 0.0;
-  double* rdl = Dl + Npad;             // [n] ⟨R_j, D_j⟩
+  const bool rows_global = a.rowvec != nullptr;
+  double* rdl = rows_global ? a.rowvec : Dl + Npad;   // [n] ⟨R_j, D_j⟩
   double* ddl = rdl + n;               // [n] ‖D_j‖²
   double* djl = ddl + n;               // [n] d_j = v_j·y[k_j]
-  double* const w0l = djl + n;         // [r] Rᵀb of the rank-one matrix, [r] y_c·D·w0 (same order as rs_fg_body leaves them) …
+  double* const w0l = rows_global ? Dl + Npad : Dl + Npad + 3 * (long long)n;   // [r] Rᵀb of the rank-one matrix, [r] y_c·D·w0 (same order as rs_fg_body leaves them) …
   double* const wsl = w0l + r;
   double* const w1l = wsl + r;         // … [r] Dᵀb, [r] the previous y_c·D·w0 (PDROP)
   double* const wsol = w1l + r;
@@ -611,6 +619,7 @@ __device__ __forceinline__ void rs_loop_run(const RsLoopArgs& a) {
       f.R = R; f.G = Gm; f.P = a.P; f.y = a.y; f.pv_raw = a.pv_raw; f.pv = a.pv;
       f.lam = a.lam; f.lam_ub = a.lam_ub; f.lb = a.lb; f.b = a.b; f.c = a.c;
       f.lr = a.lr;
+      f.rowvec = a.rowvec;
       rs_fg_body<VEC>(f, gd.c, Dl, rdl, djl, sred, fsh, w0l);
     }
   }

@@ -157,6 +157,7 @@ struct sdplr_hip_solver {
   bool fast_singleton = false;   // every diagonal-only matrix has exactly one entry (k_sparse.h, singleton form)
   // resident route (k_resident.h): singleton form, no low-rank matrices, at most one singleton constraint per row
   bool rs_ok = false;
+  double* rs_rowvec = nullptr;   // 3n doubles: the resident kernels' per-row vectors when they do not fit the LDS (rs_rows_global)
   const int* rs_row_k = nullptr;     // [n] the constraint attached to row j (−1: none)
   const double* rs_row_v = nullptr;  // [n] its value
   RsEll rs_ell{};                    // A_g as a sliced ELL, one row per lane
@@ -702,8 +703,15 @@ int sync_check(S* s) {
 
 // dynamic LDS the resident loop needs (k_resident.h) and its budget; tiles_can_wait: "small enough for that route"
 constexpr size_t RS_LDS_MAX = 150 * 1024;   // dynamic LDS of a resident kernel (≈ 9.6 KB more are static: control block, reduction scratch)
-size_t rs_loop_lds(const S* s) {   // D (with the SpMM's zero row) | ⟨R_j,D_j⟩ | ‖D_j‖² | d_j | four r-vectors of the rank-one matrix
-  return ((size_t)rs_npad(s->n, s->r) + 3 * (size_t)s->n + 4 * (size_t)s->r) * sizeof(double);
+// D (with the SpMM's zero row) | ⟨R_j,D_j⟩ | ‖D_j‖² | d_j | four r-vectors of the rank-one matrix.  When that is more than
+// a CU has but the direction alone fits, the three per-row vectors move to global memory (k_resident.h, RsLoopArgs::rowvec).
+bool rs_rows_global(const S* s) {
+  const size_t full = ((size_t)rs_npad(s->n, s->r) + 3 * (size_t)s->n + 4 * (size_t)s->r) * sizeof(double);
+  return full > RS_LDS_MAX && getenv("SDPLR_HIP_NO_RESIDENT_ROWVEC") == nullptr;
+}
+size_t rs_loop_lds(const S* s) {
+  const size_t rows = rs_rows_global(s) ? 0 : 3 * (size_t)s->n;
+  return ((size_t)rs_npad(s->n, s->r) + rows + 4 * (size_t)s->r) * sizeof(double);
 }
 RsLr rs_lr(const S* s) {   // the one rank-one matrix of an instance of the resident route (finalize: lr_one), or none
   RsLr l{};
@@ -1137,6 +1145,7 @@ int build_rs_ell(S* s, const std::vector<int>& g_ptr, const std::vector<int>& g_
   if ((rc = upload(s, &E.ent, ent))) return rc;
   if (!uniform && (rc = upload(s, &E.val, val))) return rc;
   if ((rc = upload(s, &E.gdiag, gdiag))) return rc;
+  if (!s->rs_rowvec && (rc = dzero(s, &s->rs_rowvec, (size_t)3 * n))) return rc;   // (12.8 KB at n = 1600; used only when rs_rows_global)
   s->rs_ok = true;
   return SDPLR_OK;
 }
@@ -2338,7 +2347,14 @@ void enq_lbfgs_dir(S* s, int negate, int in_loop, int apply_fallback, bool skip_
   enq_boundary(s, 0, in_loop ? 1 : 0, in_loop, 1, analytic ? (negate ? 1 : 2) : 0);
   {
     ProfScope ps(s, "lbfgs_dir");
-    HM_DISPATCH((k_lbfgs_dir<HM><<<s->nb_dense, SDPLR_NT, 0, s->stream>>>(s->ctrl, s->arena, s->N, (int)s->h, negate, in_loop, s->partials, (analytic && skip_ynext) ? 2 : analytic)))
+    // (history loads non-temporal only when the arena does not fit the 256 MiB Infinity Cache: k_dense.h, NTH)
+    static const long long nt_above = getenv("SDPLR_HIP_DIR_NT_ABOVE_MB") ? atoll(getenv("SDPLR_HIP_DIR_NT_ABOVE_MB")) << 20 : 200LL << 20;
+    const long long arena_bytes = (long long)(3 + 2 * s->h + (s->fast ? 2 : 0)) * s->arena.stride * (long long)sizeof(double);
+    if (arena_bytes > nt_above) {
+      HM_DISPATCH((k_lbfgs_dir<HM, true><<<s->nb_dense, SDPLR_NT, 0, s->stream>>>(s->ctrl, s->arena, s->N, (int)s->h, negate, in_loop, s->partials, (analytic && skip_ynext) ? 2 : analytic)))
+    } else {
+      HM_DISPATCH((k_lbfgs_dir<HM, false><<<s->nb_dense, SDPLR_NT, 0, s->stream>>>(s->ctrl, s->arena, s->N, (int)s->h, negate, in_loop, s->partials, (analytic && skip_ynext) ? 2 : analytic)))
+    }
   }
   if (analytic) return;
   ProfScope ps(s, "descent");
@@ -2679,6 +2695,7 @@ inline int rs_vec(const S* s) { return s->r % 2 == 0 ? 2 : 1; }
 RsLoopArgs rs_loop_args(S* s, double time_budget_s, bool refresh_P, bool pre_lambda, bool pre_clear_fg) {
   RsLoopArgs a{};
   a.lr = rs_lr(s);
+  a.rowvec = rs_rows_global(s) ? s->rs_rowvec : nullptr;
   a.pre_lambda = pre_lambda ? 1 : 0;
   a.pre_clear = a.pre_fg = pre_clear_fg ? 1 : 0;
   a.b = s->b;
@@ -3150,6 +3167,7 @@ namespace {
 RsFgArgs rs_fg_args(S* s) {
   RsFgArgs a{};
   a.lr = rs_lr(s);
+  a.rowvec = rs_rows_global(s) ? s->rs_rowvec : nullptr;
   a.n = (int)s->n; a.m = (int)s->m; a.r = (int)s->r;
   a.gid_g = s->ff.gid_g; a.row_k = s->rs_row_k; a.row_v = s->rs_row_v; a.E = s->rs_ell;
   a.R = aslot(s->arena, AS_R); a.G = aslot(s->arena, AS_G); a.P = aslot(s->arena, 3 + 2 * (int)s->h);

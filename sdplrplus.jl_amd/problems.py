@@ -311,6 +311,21 @@ def maxcut_data(A) -> SDPData:
     return SDPData.from_batch(L, np.ones(n), batch, [])
 
 
+def cutnorm_data(A) -> SDPData:
+    """``cutnorm`` (test/problem.jl:96-112) straight from batched arrays: C = −½·[0 A; Aᵀ 0] on 2n vertices, unit diagonal
+    constraints — MaxCut-shaped (the reference's batch runs it on the Gset graphs: exps/gen_batch_test.jl:3)."""
+    A = sp.csc_matrix(A, dtype=np.float64)
+    m_, n_ = A.shape
+    C = sp.csc_matrix(-(sp.bmat([[None, A], [A.T, None]], format="csc") / 2))
+    C.sort_indices()
+    N = m_ + n_
+    idx = np.arange(N, dtype=np.int64)
+    CI, CJ, CV = _csc_entries(C)
+    batch = _batch(N, [(np.ones(N, dtype=np.int64), idx, idx, np.ones(N)),
+                       (np.array([CI.size]), CI, CJ, CV)], np.arange(N + 1))
+    return SDPData.from_batch(C, np.ones(N), batch, [])
+
+
 def minimum_bisection_data(A) -> SDPData:
     A = _check_undirected(A)
     n = A.shape[0]

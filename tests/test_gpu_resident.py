@@ -314,6 +314,36 @@ def test_resident_rank_one_constraint_agrees_with_the_multi_launch_route(hip_abi
         assert a[5][0] == pytest.approx(b[5][0], rel=1e-6) and a[5][1] == pytest.approx(b[5][1], abs=1e-6 * max(1.0, abs(b[5][1])))
 
 
+def test_resident_cutnorm_on_a_gset_graph(hip_abi, oracle_abi):
+    """CutNorm on a Gset graph (exps/gen_batch_test.jl:3): 2·800 = 1600 vertices at rank 10 — the direction alone fills the
+    CU's LDS (128 KB), the per-row vectors ⟨R_j,D_j⟩, ‖D_j‖², d_j go through global memory (RsLoopArgs::rowvec).  fg!, 12
+    iterations in three calls, the dual bound, against the oracle; and the whole solve inside the oracle's tolerance window."""
+    data = problems.cutnorm_data(gset("G1"))
+    assert data.n == 1600
+    normC, normb = data.normC(), float(np.linalg.norm(data.b))
+    g, o = pair(hip_abi, oracle_abi, data, 10, 6)
+    sg, so = g.fg(normC, normb), o.fg(normC, normb)
+    assert np.allclose(sg, so, rtol=1e-11) and rel(g.Gt, o.Gt) < 1e-12
+    for k in (4, 4, 4):
+        rg, ro = run(g, normC, normb, k, sg), run(o, normC, normb, k, so)
+        assert rg[4] == ro[4] == k and np.allclose(rg[:3], ro[:3], rtol=1e-8, atol=1e-12)
+        sg, so = rg[:3], ro[:3]
+    assert rel(g.Rt, o.Rt) < 1e-8 and rel(g.Gt, o.Gt) < 1e-7 and rel(g.y, o.y) < 1e-8
+    st = g.stats()
+    assert st["resident_loops"] == 3 and st["resident_fg"] == 1 and st["eager_batches"] == 0 and st["graph_batches"] == 0
+    v0 = np.random.Generator(np.random.PCG64(1)).standard_normal(data.n)
+    (dg, eg), (do, eo) = g.dual_obj(800.0, 0, v0), o.dual_obj(800.0, 0, v0)
+    assert g.stats()["resident_lanczos"] == 1
+    assert eg == pytest.approx(eo, abs=1e-7 * max(1, abs(eo))) and dg == pytest.approx(do, rel=1e-7)
+    g.close(); o.close()
+    kw = dict(ptol=0.01, objtol=0.01, seed=0, prior_trace_bound=800.0, printlevel=0, maxtime=120.0)
+    a = sj.sdplr(data=data, r=10, **kw)
+    b = sj.sdplr(data=data, r=10, **kw)
+    assert a["obj"] == b["obj"] and a["iter"] == b["iter"]
+    gap = (a["obj"] - a["max_dual_value"]) / min(abs(a["obj"]), abs(a["max_dual_value"]))
+    assert -1e-2 <= gap <= 1e-2
+
+
 def test_resident_solve_of_a_minimum_bisection_instance(hip_abi, oracle_abi):
     """sdplr() end to end on MinBisection of Gset G1 (rank 10, ptol = objtol = 0.01): every inner loop and dual bound one
     launch, the result inside the tolerance window of the oracle's solve, a second run bit-identical, and the lockstep
