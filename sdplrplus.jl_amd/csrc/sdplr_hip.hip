@@ -145,6 +145,10 @@ struct sdplr_hip_solver {
   // and needs that; when in doubt the loop takes the P-based kernel, which rebuilds G from P and y.
   bool G_consistent = false;
   int64_t G_age = 0;         // incremental steps since G was last formed from scratch
+  // `dirt *= α` of the last lbfgs_update! (src/lbfgs.jl:142) is not stored inside the device-driven loop: dirt = s_latest.
+  // The copy is made when something outside the loop looks at dirt (ensure_dirt) — a loop followed by another loop, the
+  // common case, overwrites it unread.  ≥ 0: the history slot whose s IS dirt; −1: the D array is current.
+  int dirt_from = -1;
   bool no_updfuse = false;   // SDPLR_HIP_NO_UPDFUSE: lbfgs_update! as a kernel of its own on the singleton fast path
   int gram_nb = 1;           // number of Gram partials the latest enqueued producer writes (k_lbfgs_update / fused step)
   bool force_graph = false;  // SDPLR_HIP_FORCE_GRAPH: hipGraph batches on small instances too (the tests' default)
@@ -245,11 +249,16 @@ int fail(S* s, int code, const std::string& msg) {
     if (!(s)->finalized) return fail((s), SDPLR_ERR_STATE, "not finalized");     \
   } while (0)
 // entry points that enqueue kernels: the host shadow of the control block is stale until the next pull
-#define NEED_FINAL_RW(s)          \
-  do {                            \
-    NEED_FINAL(s);                \
-    (s)->hc_valid = false;        \
-    (s)->G_consistent = false;    \
+int ensure_dirt(S* s);
+#define NEED_FINAL_RW(s)                                   \
+  do {                                                     \
+    NEED_FINAL(s);                                         \
+    (s)->hc_valid = false;                                 \
+    (s)->G_consistent = false;                             \
+    if ((s)->dirt_from >= 0) {                             \
+      const int rc_d__ = ensure_dirt(s);                   \
+      if (rc_d__) return rc_d__;                           \
+    }                                                      \
   } while (0)
 
 int have_device() {
@@ -694,6 +703,13 @@ int push(S* s) {
   HIPCK(s, hipMemcpyAsync(s->ctrl, s->hc, sizeof(DevCtrl), hipMemcpyHostToDevice, s->stream));
   HIPCK(s, hipStreamSynchronize(s->stream));
   return SDPLR_OK;   // (hc_valid is left as it is: a caller that enqueues kernels after this clears it at its entry)
+}
+int ensure_dirt(S* s) {   // dirt ← s_latest (see S::dirt_from); enqueued on the handle's stream, ahead of whatever reads dirt next
+  if (s->dirt_from < 0) return SDPLR_OK;
+  const int j = s->dirt_from;
+  s->dirt_from = -1;
+  HIPCK(s, hipMemcpyAsync(aslot(s->arena, AS_D), aslot(s->arena, AS_S0 + j), s->N * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
+  return SDPLR_OK;
 }
 int sync_check(S* s) {
   HIPCK(s, hipGetLastError());
@@ -2013,6 +2029,7 @@ int32_t sdplr_hip_set_factor(S* s, int32_t slot, const double* h) {
   ApiShared api_guard(dev_of(s));
   NEED_FINAL(s);
   s->G_consistent = false;   // (the host writes state behind G's back)
+  { const int rc_d = ensure_dirt(s); if (rc_d) return rc_d; }
   double* p = factor_ptr(s, slot);
   if (!p || !h) return fail(s, SDPLR_ERR_INVALID_ARG, "set_factor: bad slot");
   {
@@ -2025,6 +2042,7 @@ int32_t sdplr_hip_set_factor(S* s, int32_t slot, const double* h) {
 int32_t sdplr_hip_get_factor(S* s, int32_t slot, double* h) {
   ApiShared api_guard(dev_of(s));
   NEED_FINAL(s);
+  { const int rc_d = ensure_dirt(s); if (rc_d) return rc_d; }
   double* p = factor_ptr(s, slot);
   if (!p || !h) return fail(s, SDPLR_ERR_INVALID_ARG, "get_factor: bad slot");
   HIPCK(s, hipMemcpyAsync(h, p, s->N * sizeof(double), hipMemcpyDeviceToHost, s->stream));
@@ -3364,6 +3382,10 @@ static int32_t inner_loop_impl(S* s, double normC, double normb, int32_t grel, i
   bind_device(dev_of(s));
   const bool hc_was_valid = s && s->finalized && s->hc_valid;
   const bool G_was_consistent = s && s->finalized && s->G_consistent;
+  // (the loop's first kernel after the seam overwrites dirt: a pending dirt ← s_latest is dropped, not made — unless the
+  // loop turns out not to run a single iteration, see below)
+  const int dirt_was_from = (s && s->finalized) ? s->dirt_from : -1;
+  if (s && s->finalized && max_local_iters >= 1 && Lio && gnio && pnio) s->dirt_from = -1;
   NEED_FINAL_RW(s);
   if (!Lio || !gnio || !pnio || max_local_iters < 1) return fail(s, SDPLR_ERR_INVALID_ARG, "inner_loop: bad args");
   const bool gram_work = s->h > 0 && (s->gram_dirty || s->ynext_pending || s->sg_stale);
@@ -3379,7 +3401,9 @@ static int32_t inner_loop_impl(S* s, double normC, double normb, int32_t grel, i
   c->cur_gtol = cur_gtol; c->fprec_eps = fprec_eps; c->normC = normC; c->normb = normb;
   c->grel = grel; c->prel = prel;
   c->L = *Lio; c->gnorm = *gnio; c->pvnorm = *pnio; c->alpha = 0.0; c->alpha_max = 1.0;
-  if ((rc = push(s))) return rc;
+  // (no wait: the kernels are ordered behind the copy on the stream, and the host does not touch its shadow again before
+  // the closing snapshot has been waited for)
+  HIPCK(s, hipMemcpyAsync(s->ctrl, s->hc, sizeof(DevCtrl), hipMemcpyHostToDevice, s->stream));
   // Iterations are enqueued in batches — a captured hipGraph of `graph_iters` passes of the while
   // body, or eager launches when per-kernel event timing is on.  The device decides every exit;
   // once `done` is set the remaining kernels of a batch fall through.  The control block is
@@ -3388,6 +3412,8 @@ static int32_t inner_loop_impl(S* s, double normC, double normb, int32_t grel, i
   if (rs_loop_applies(s, use_armijo)) {
     // resident route (k_resident.h): the whole while loop is ONE launch of one workgroup; every exit — the time
     // budget too — is taken on the device, the host reads the control block once
+    s->dirt_from = dirt_was_from;   // (the resident kernel leaves dirt itself: a pending copy from a multi-launch loop is made first)
+    if ((rc = ensure_dirt(s))) return rc;
     return run_resident_loop(s, time_budget_s, false, false, Lio, gnio, pnio, last_alpha, iters, exit_reason, nullptr, G_was_consistent, resume);
   }
   const bool fastp = s->fast;
@@ -3498,6 +3524,7 @@ static int32_t inner_loop_impl(S* s, double normC, double normb, int32_t grel, i
     return SDPLR_OK;
   };
   int why = -1;
+  int final_snap = -1;   // the snapshot that holds the closed plan's final control block, if the device got that far
   if (s->prof_on) {
     // per-kernel event timing: no speculation, and the trailing loop-test pass (whose kernels fall
     // through) is left untimed, so that the averages are over real launches only
@@ -3529,7 +3556,12 @@ static int32_t inner_loop_impl(S* s, double normC, double normb, int32_t grel, i
       const double tw = now();
       HIPCK(s, hipEventSynchronize(s->snap_ev[cur]));
       t_wait += now() - tw;
-      if (s->snap[cur]->done) break;
+      if (s->snap[cur]->done) {
+        // (usable as the final state only if nothing was enqueued behind it — no speculative batch — and it was taken
+        // behind the closing seam)
+        if (!more && plan_closed) final_snap = cur;
+        break;
+      }
       if (time_budget_s > 0) {
         const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         if (el > time_budget_s) { why = EXIT_TIME; break; }
@@ -3542,13 +3574,23 @@ static int32_t inner_loop_impl(S* s, double normC, double normb, int32_t grel, i
   // enqueue functions, so the producer's partial count is set here, not inherited
   const bool loop_fused = fastp ? step_fuses_update(s) : spmm_fuses_update(s);   // lbfgs_update! rode another kernel
   s->gram_nb = !loop_fused ? s->nb_upd : (fastp ? s->nb_step : spmm_upd_blocks(s));
-  enq_boundary(s, 0, 1, 0, 0);
   if (fastp || edgep) { s->S_stale = true; s->S_from_y = true; }   // y is current, S is assembled by whoever reads it next (ensure_S)
-  if ((rc = pull(s))) return rc;
+  if (final_snap >= 0) {
+    // the device closed the plan itself: the closing seam (Gram fold + loop tests) ran in front of this snapshot, nothing
+    // has been enqueued behind it — it IS the control block (one launch, one copy and one wait less per call)
+    memcpy(s->hc, s->snap[final_snap], sizeof(DevCtrl));
+    s->hc_valid = true;
+  } else {
+    enq_boundary(s, 0, 1, 0, 0);
+    if ((rc = pull(s))) return rc;
+  }
   if (c->done) why = c->exit_reason;   // the device's verdict wins over the host's time check
   if (loop_fused && c->iters > 0 && c->err == 0 && why != EXIT_RELDELTA) {
-    // the kernels lbfgs_update! rides on leave `dirt *= α` (src/lbfgs.jl:142) to this copy: dirt = s_latest
-    HIPCK(s, hipMemcpyAsync(aslot(s->arena, AS_D), aslot(s->arena, AS_S0 + (c->latest - 1)), s->N * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
+    // the kernels lbfgs_update! rides on leave `dirt *= α` (src/lbfgs.jl:142) to a copy dirt ← s_latest, made when
+    // something looks at dirt (ensure_dirt)
+    s->dirt_from = c->latest - 1;
+  } else if (c->iters == 0) {
+    s->dirt_from = dirt_was_from;   // not one iteration ran: dirt is what it was
   }
   if (dbg)
     fprintf(stderr, "[sdplr_hip] inner_loop: %d batches (%s), host enqueue %.3f ms, host wait %.3f ms, iters %lld\n",
@@ -4119,6 +4161,9 @@ int32_t sdplr_hip_batch_major_iteration(int32_t count, sdplr_hip_major_item* it)
           const sdplr_hip_major_item& q = it[idx[lo + k]];
           S* sk = q.s;
           sk->hc_valid = false;
+          if (sk->dirt_from >= 0) {   // (an instance that came over from the multi-launch route with dirt ← s_latest pending)
+            if (ensure_dirt(sk) == SDPLR_OK) (void)hipStreamSynchronize(sk->stream);
+          }
           const bool resume = q.update_lambda == SDPLR_MAJOR_RESUME;
           if (!resume) sk->sg_stale = sk->ynext_pending = false;   // (cleared history: see sdplr_hip_lbfgs_clear)
           RsLoopArgs a = resume ? rs_loop_args(sk, q.time_budget_s, !sk->P_valid, false, false)
