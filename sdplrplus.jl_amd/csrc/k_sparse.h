@@ -1207,6 +1207,11 @@ struct DevTile {
   const int* ptr;        // [n_tiles + 1]
   const int* ent;        // local row << SDPLR_TILE_COLBITS (24) | column
   const double* val;
+  // UNIFORM form (every off-diagonal entry of A_g has the same value — unit-weight graphs): the lists hold the
+  // off-diagonal entries only and no values (4 bytes per nonzero instead of 12; the loop loses its value load, its two
+  // broadcasts and its multiplies: the gathered rows are SUMMED, the sum is scaled once); the diagonal is a vector.
+  double one;
+  const double* gdiag;   // [n], or null: the general form above
 };
 
 // value held by lane `src` (0 ≤ src < LPR, constant after unrolling) of the caller's LPR-lane group
@@ -1232,7 +1237,7 @@ __device__ __forceinline__ double group_bcast(double v, int src) {
 // (launch bounds: the tile's LDS rows leave room for two blocks per CU — two waves per SIMD — whatever the second
 // argument says; for rows wider than a DPP row (LPR ≥ 32: the hand-offs are ds_bpermute results that stay live across the
 // unrolled chunk) the 128-VGPR cap of "4" cost 20–268 bytes of scratch per lane inside the gather loop)
-template <int LPR, int VEC, int LRN>
+template <int LPR, int VEC, int LRN, bool UNI = false>
 #ifdef SDPLR_PROBE_TILE_HIST
 __global__ void __launch_bounds__(SDPLR_NT, 2)
 #else
@@ -1300,7 +1305,11 @@ k_spmm_tile(DevTile tl, int n, int m, DevFast ff, const double* __restrict__ R, 
       const char* Db = reinterpret_cast<const char*>(D);
       const int dump = (K << SDPLR_TILE_COLBITS) | (int)j0;  // row K of the group's LDS rows is a dump
       int ce = tl.ent[beg + lane], ne = tl.ent[beg + LPR + lane];
-      double cv = tl.val[beg + lane], nv = tl.val[beg + LPR + lane];
+      double cv = 0.0, nv = 0.0;
+      if (!UNI) {
+        cv = tl.val[beg + lane];
+        nv = tl.val[beg + LPR + lane];
+      }
       vecd<VEC> x[WIN];
       double* fold[WIN];  // LDS row the slot's gather will be added to
 #pragma unroll
@@ -1319,7 +1328,8 @@ k_spmm_tile(DevTile tl, int n, int m, DevFast ff, const double* __restrict__ R, 
         // must wait for the load) a whole chunk of gathers has been issued behind it and nothing drains
         // (the arrays carry 2·64 entries of tail padding, so this never reads past their end)
         const int fe = tl.ent[base + 2 * LPR + lane];
-        const double fv = tl.val[base + 2 * LPR + lane];
+        double fv = 0.0;
+        if (!UNI) fv = tl.val[base + 2 * LPR + lane];
 #pragma unroll
         for (int k0 = 0; k0 < LPR; k0 += WIN) {
 #pragma unroll
@@ -1327,10 +1337,11 @@ k_spmm_tile(DevTile tl, int n, int m, DevFast ff, const double* __restrict__ R, 
             // fold one …  (an LDS atomic add without return, ds_add_f64: the LDS unit applies a wave's adds in
             // issue order and each lane owns its addresses, so the sum is formed in list order exactly as a
             // read-add-write would form it, but the wave never waits for it)
-            const double v = group_bcast<LPR>(cv, k0 + q);
+            double v = 1.0;
+            if (!UNI) v = group_bcast<LPR>(cv, k0 + q);
 #pragma unroll
             for (int k = 0; k < VEC; k++)
-              (void)__hip_atomic_fetch_add(fold[q] + k, x[q].v[k] * v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+              (void)__hip_atomic_fetch_add(fold[q] + k, UNI ? x[q].v[k] : x[q].v[k] * v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             // … refill one
             int e2;
             if (k0 + WIN < LPR) {
@@ -1367,6 +1378,11 @@ k_spmm_tile(DevTile tl, int n, int m, DevFast ff, const double* __restrict__ R, 
           xd[i] = ldrow<VEC>(D + j * r + chs);
 #pragma unroll
           for (int q = 0; q < VEC; q++) w[i].v[q] = rows[min(k + i, nrows - 1) * RW + q];
+          if (UNI) {   // scale the sum of the gathered rows once; the diagonal entry, left out of the lists, last
+            const double gd = tl.gdiag[j];
+#pragma unroll
+            for (int q = 0; q < VEC; q++) w[i].v[q] = w[i].v[q] * tl.one + xd[i].v[q] * gd;
+          }
         }
 #ifdef SDPLR_PROBE_TILE_HIST
 #pragma unroll

@@ -859,12 +859,40 @@ int build_tiles(S* s) {
   int K = 1;
   for (int64_t t = 0; t < nt; t++) K = std::max(K, t_row[t + 1] - t_row[t]);
   std::vector<double> t_val;
+  // uniform form (k_sparse.h, DevTile): all off-diagonal values equal — the lists then hold the off-diagonal entries only
+  bool uni = getenv("SDPLR_HIP_NO_TILE_UNIFORM") == nullptr;
+  double uni_one = 0.0;
+  std::vector<double> gdiag;
+  std::vector<int> offd_cnt;   // per row: off-diagonal entries
+  {
+    bool have = false;
+    for (int64_t j = 0; j < n && uni; j++)
+      for (int q = g_ptr[j]; q < g_ptr[j + 1]; q++) {
+        if (g_col[q] == (int)j) continue;
+        if (!have) { uni_one = g_val[q]; have = true; }
+        else if (!(g_val[q] == uni_one)) { uni = false; break; }
+      }
+    if (!have) uni = false;
+    if (uni) {
+      gdiag.assign(n, 0.0);
+      offd_cnt.assign(n, 0);
+      for (int64_t j = 0; j < n; j++)
+        for (int q = g_ptr[j]; q < g_ptr[j + 1]; q++) {
+          if (g_col[q] == (int)j) gdiag[j] += g_val[q];
+          else offd_cnt[j]++;
+        }
+    }
+  }
   for (int64_t t = 0; t < nt; t++) {   // list lengths, padded to the sub-wave width
-    const int len = g_ptr[t_row[t + 1]] - g_ptr[t_row[t]];
+    int len = g_ptr[t_row[t + 1]] - g_ptr[t_row[t]];
+    if (uni) {
+      len = 0;
+      for (int j = t_row[t]; j < t_row[t + 1]; j++) len += offd_cnt[j];
+    }
     t_ptr[t + 1] = t_ptr[t] + (len + L - 1) / L * L;
   }
   t_ent.assign((size_t)t_ptr[nt] + 128, 0);
-  t_val.assign((size_t)t_ptr[nt] + 128, 0.0);
+  t_val.assign(uni ? 1 : (size_t)t_ptr[nt] + 128, 0.0);
   parallel_for(nt, 64, [&](int64_t t0, int64_t t1) {   // the tiles are independent: sorted and packed on a few host threads
     std::vector<unsigned long long> tmp;  // column << 32 | position in the tile's slice of the CSR
     std::vector<int> rowof;
@@ -880,10 +908,12 @@ int build_tiles(S* s) {
       size_t at0 = (size_t)t_ptr[t];
       for (int q = 0; q < e - b; q++) {
         const int col = (int)(tmp[q] >> 32), at = (int)(tmp[q] & 0xFFFFFFFFull);
+        if (uni && col == (int)r0 + rowof[at]) continue;   // the diagonal entry rides the epilogue (gdiag)
         t_ent[at0] = (rowof[at] << SDPLR_TILE_COLBITS) | col;
-        t_val[at0++] = g_val[b + at];
+        if (!uni) t_val[at0] = g_val[b + at];
+        at0++;
       }
-      for (; at0 < (size_t)t_ptr[t + 1]; at0++) { t_ent[at0] = (K << SDPLR_TILE_COLBITS) | (int)r0; t_val[at0] = 0.0; }
+      for (; at0 < (size_t)t_ptr[t + 1]; at0++) { t_ent[at0] = (K << SDPLR_TILE_COLBITS) | (int)r0; if (!uni) t_val[at0] = 0.0; }
     }
   });
   int rc;
@@ -892,6 +922,9 @@ int build_tiles(S* s) {
   if ((rc = upload(s, &s->tile.ptr, t_ptr))) return rc;
   if ((rc = upload(s, &s->tile.ent, t_ent))) return rc;
   if ((rc = upload(s, &s->tile.val, t_val))) return rc;
+  s->tile.one = uni_one;
+  s->tile.gdiag = nullptr;
+  if (uni && (rc = upload(s, &s->tile.gdiag, gdiag))) return rc;
   s->tile_allocs.assign(s->allocs.begin() + first, s->allocs.end());
   s->tile.K = K;
   s->tile.n_tiles = (int)nt;
@@ -2198,16 +2231,18 @@ int tile_lds_attr(S* s) {
   static std::mutex mu;
   std::lock_guard<std::mutex> g(mu);
   hipError_t e = hipSuccess;
-#define TILE_ATTR(LRN)                                                                                                           \
+#define TILE_ATTR(LRN, UNI)                                                                                                      \
   TLV_DISPATCH(({                                                                                                                  \
     static int cur_max = 0;                                                                                                       \
     if (bytes > cur_max) {                                                                                                        \
-      e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_spmm_tile<LPR, VEC, LRN>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes); \
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_spmm_tile<LPR, VEC, LRN, UNI>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes); \
       if (e == hipSuccess) cur_max = bytes;                                                                                       \
     }                                                                                                                             \
   }))
-  TILE_ATTR(0)
-  if (e == hipSuccess) { TILE_ATTR(1) }
+  TILE_ATTR(0, false)
+  if (e == hipSuccess) { TILE_ATTR(1, false) }
+  if (e == hipSuccess) { TILE_ATTR(0, true) }
+  if (e == hipSuccess) { TILE_ATTR(1, true) }
 #undef TILE_ATTR
   if (e != hipSuccess) return fail(s, SDPLR_ERR_HIP, std::string("hipFuncSetAttribute(k_spmm_tile): ") + hipGetErrorString(e));
   s->tile_attr_done = true;
@@ -2525,7 +2560,8 @@ void enq_iteration_fast(S* s, int armijo) {
   if (tiled) {
     ProfScope ps(s, "spmm_W");
     const size_t lds = ((size_t)SDPLR_NT * s->VEC * (s->tile.K + 1) + (size_t)(SDPLR_NT / s->tile_lpr) * (2 * s->tile.K + 8)) * sizeof(double);
-    TLV_DISPATCH((k_spmm_tile<LPR, VEC, 0><<<s->nb_tile, SDPLR_NT, lds, s->stream>>>(s->tile, (int)s->n, (int)s->m, s->ff, R, D, P, W, (int)s->r, s->lambda, s->pv_raw, s->sp_fast.UVt0, s->sp_fast.UVt1, s->partials, s->ctrl, 1, s->lr, s->lr_part, 1)))
+    if (s->tile.gdiag) { TLV_DISPATCH((k_spmm_tile<LPR, VEC, 0, true><<<s->nb_tile, SDPLR_NT, lds, s->stream>>>(s->tile, (int)s->n, (int)s->m, s->ff, R, D, P, W, (int)s->r, s->lambda, s->pv_raw, s->sp_fast.UVt0, s->sp_fast.UVt1, s->partials, s->ctrl, 1, s->lr, s->lr_part, 1))) }
+    else { TLV_DISPATCH((k_spmm_tile<LPR, VEC, 0><<<s->nb_tile, SDPLR_NT, lds, s->stream>>>(s->tile, (int)s->n, (int)s->m, s->ff, R, D, P, W, (int)s->r, s->lambda, s->pv_raw, s->sp_fast.UVt0, s->sp_fast.UVt1, s->partials, s->ctrl, 1, s->lr, s->lr_part, 1))) }
   } else {
   {
     ProfScope ps(s, "rowdots");
@@ -2618,13 +2654,15 @@ void enq_iteration_fast2(S* s) {
     if (s->use_tile && s->tile_lpr == tile_shape_lpr(s) && s->n * s->r * 8 < (1LL << 32)) {
       lr_fused = s->lr.ST == 1 && s->r <= (int64_t)s->tile_lpr * s->VEC && !s->no_lrfuse;
       const size_t lds = ((size_t)SDPLR_NT * s->VEC * (s->tile.K + 1) + (size_t)(SDPLR_NT / s->tile_lpr) * (2 * s->tile.K + 8) + (lr_fused ? (size_t)(SDPLR_NT / 64) * 2 * s->tile_lpr * s->VEC : 0)) * sizeof(double);
-      if (lr_fused) { TLV_DISPATCH((k_spmm_tile<LPR, VEC, 1><<<s->nb_tile, SDPLR_NT, lds, s->stream>>>(s->tile, (int)s->n, (int)s->m, s->ff, R, D, P, W, (int)s->r, s->lambda, s->pv_raw, s->A_RD, s->A_DD, s->partials, s->ctrl, 1, s->lr, s->lr_part, 0))) }
-      else if (s->tile_panels && s->VEC == 2 && s->tile_lpr == 16 && s->LPR == 16) {
+      if (lr_fused && s->tile.gdiag) { TLV_DISPATCH((k_spmm_tile<LPR, VEC, 1, true><<<s->nb_tile, SDPLR_NT, lds, s->stream>>>(s->tile, (int)s->n, (int)s->m, s->ff, R, D, P, W, (int)s->r, s->lambda, s->pv_raw, s->A_RD, s->A_DD, s->partials, s->ctrl, 1, s->lr, s->lr_part, 0))) }
+      else if (lr_fused) { TLV_DISPATCH((k_spmm_tile<LPR, VEC, 1><<<s->nb_tile, SDPLR_NT, lds, s->stream>>>(s->tile, (int)s->n, (int)s->m, s->ff, R, D, P, W, (int)s->r, s->lambda, s->pv_raw, s->A_RD, s->A_DD, s->partials, s->ctrl, 1, s->lr, s->lr_part, 0))) }
+      else if (s->tile_panels && s->VEC == 2 && s->tile_lpr == 16 && s->LPR == 16 && !s->tile.gdiag) {
         // rank panels: the same kernel with 8 bytes per lane walks the lists once per 16-column half of the rank, so a
         // gathered row is 128 B and the XCD's L2 holds twice as many of them (tile kernel)
         const size_t lds1 = ((size_t)SDPLR_NT * 1 * (s->tile.K + 1) + (size_t)(SDPLR_NT / s->LPR) * (2 * s->tile.K + 8)) * sizeof(double);
         k_spmm_tile<16, 1, 0><<<s->nb_tile, SDPLR_NT, lds1, s->stream>>>(s->tile, (int)s->n, (int)s->m, s->ff, R, D, P, W, (int)s->r, s->lambda, s->pv_raw, s->A_RD, s->A_DD, s->partials, s->ctrl, 1, s->lr, s->lr_part, 0);
       }
+      else if (s->tile.gdiag) { TLV_DISPATCH((k_spmm_tile<LPR, VEC, 0, true><<<s->nb_tile, SDPLR_NT, lds, s->stream>>>(s->tile, (int)s->n, (int)s->m, s->ff, R, D, P, W, (int)s->r, s->lambda, s->pv_raw, s->A_RD, s->A_DD, s->partials, s->ctrl, 1, s->lr, s->lr_part, 0))) }
       else { TLV_DISPATCH((k_spmm_tile<LPR, VEC, 0><<<s->nb_tile, SDPLR_NT, lds, s->stream>>>(s->tile, (int)s->n, (int)s->m, s->ff, R, D, P, W, (int)s->r, s->lambda, s->pv_raw, s->A_RD, s->A_DD, s->partials, s->ctrl, 1, s->lr, s->lr_part, 0))) }
     } else {
       LV_DISPATCH((k_spmm_fast<LPR, VEC><<<s->nb_spmm, SDPLR_NT, 0, s->stream>>>(s->spg, (int)s->m, s->ff, R, D, P, W, (int)s->r, s->lambda, s->pv_raw, s->A_RD, s->A_DD, s->partials, s->ctrl, 1)))
