@@ -1,5 +1,6 @@
 """dev tool: a plain run of one BASELINE configuration for rocprofv3 (scripts/pmc_config.sh): fg!, 40 + 100 inner iterations
-on the route the library picks, one dual bound and one 232-step Lanczos run.  which ∈ lovasz | minbis | maxcut."""
+on the route the library picks, one dual bound and one 232-step Lanczos run.  which ∈ lovasz | minbis | maxcut | wide64 |
+wide128 (the MaxCut instance at rank 64 / 128: where rank doubling sends a solve)."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -13,7 +14,8 @@ elif which == "minbis":
     data = problems.minimum_bisection_data(problems.gnp_graph(100_000, 2e-4, 4))
 else:
     data = problems.maxcut_data(problems.gnp_graph(100_000, 2e-4, 20240610))
-var = sj.build_solver(abi, data, 32, sj.BurerMonteiroConfig(seed=1, printlevel=0))
+rank = {"wide64": 64, "wide128": 128}.get(which, 32)
+var = sj.build_solver(abi, data, rank, sj.BurerMonteiroConfig(seed=1, printlevel=0))
 normC, normb = data.normC(), float(np.linalg.norm(data.b))
 st = var.fg(normC, normb)
 run = lambda s, k: var.inner_loop(normC, normb, True, True, False, 0.0, -1e300, k, 0.0, *s)[:3]
