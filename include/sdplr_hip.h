@@ -96,7 +96,9 @@ int32_t sdplr_hip_trim_pools(void);
 
 /* ---- construction: replaces SolverVars + SolverAuxiliary construction ------------------------
  * src/sdplr.jl:114-123, src/structs.jl:225-263 (SolverVars), :296-361 (SolverAuxiliary),
- * src/lbfgs.jl:35-47 (lbfgs_init: h zeroed (s,y,ρ,a) slots, latest = h).
+ * src/lbfgs.jl:35-47 (lbfgs_init: h zeroed (s,y,ρ,a) slots, latest = h).  Any numlbfgsvecs ≤ 4096: up to 16 the two-loop
+ * recursion runs in Gram form (one pass over the history per direction; ≤ 4: fused with the step), beyond that as the
+ * reference writes it (one dot + one axpy kernel per history vector).
  * Order: create → [set_sparse] → [add_symlowrank]* → finalize → set_factor/set_vec … → operators. */
 int32_t sdplr_hip_create(int64_t n, int64_t m, int64_t r, int64_t numlbfgsvecs,
                          sdplr_hip_solver** out);

@@ -669,6 +669,126 @@ k_lbfgs_update(const DevCtrl* __restrict__ c, FactorArena A, long long N, int h,
   }
 }
 
+// ---- numlbfgsvecs > SDPLR_HMAX: the two-loop recursion as the reference writes it --------------------------------
+// The Gram form keeps two h×h blocks in the control block that the seam kernel stages in LDS: fine for the h ≤ 16 anyone
+// runs (the reference's default is 4), not for an arbitrary m (`lbfgs_init` allocates any, src/lbfgs.jl:35-47).  Longer
+// histories take the literal route: dir ← G (:84); newest → oldest: α_j = ρ_j⟨s_j, dir⟩, dir −= α_j·y_j (:94-102); oldest →
+// newest: β = ρ_j⟨y_j, dir⟩, dir += (α_j − β)·s_j (:104-113); dir ← −dir (:116-118), y_next ← −G (:121-123) — one dot kernel
+// and one axpy kernel per history vector (4h + 2 launches, 12h·N of traffic: the reference's own cost), every slot found on
+// the device from `latest`, so that the sequence is the same enqueue in every iteration (hipGraph replay).  ρ and a live in
+// two device arrays of their own.
+__device__ __forceinline__ int lit_slot(int latest, int h, int i) {   // slot (0-based) of the i-th newest pair
+  int j = (latest - 1 - i) % h;
+  return j < 0 ? j + h : j;
+}
+__global__ void __launch_bounds__(SDPLR_NT)
+k_lit_copy(const DevCtrl* __restrict__ c, FactorArena A, long long N, int check_done) {
+  if (check_done && c->done) return;
+  const double* G = aslot(A, AS_G);
+  double* dir = aslot(A, AS_D);
+  const long long stride = (long long)gridDim.x * SDPLR_NT;
+  for (long long i = (long long)blockIdx.x * SDPLR_NT + threadIdx.x; i < N; i += stride) dir[i] = G[i];
+}
+// partials of ⟨v, dir⟩, v = s (sy = 0) or y (sy = 1) of the i-th newest pair
+__global__ void __launch_bounds__(SDPLR_NT)
+k_lit_dot(const DevCtrl* __restrict__ c, FactorArena A, long long N, int h, int i, int sy, int slot,
+          double* __restrict__ partials, int check_done) {
+  __shared__ double sh[8];
+  const int dn = check_done ? c->done : 0;
+  const int j = lit_slot(c->latest, h, i);
+  if (dn) return;
+  const double* v = aslot(A, (sy ? as_y0(A) : AS_S0) + j);
+  const double* dir = aslot(A, AS_D);
+  double t = 0.0;
+  const long long stride = (long long)gridDim.x * SDPLR_NT;
+  for (long long e = (long long)blockIdx.x * SDPLR_NT + threadIdx.x; e < N; e += stride) t += v[e] * dir[e];
+  t = block_sum1(t, sh);
+  if (threadIdx.x == 0) slot_partials(partials, slot)[blockIdx.x] = t;
+}
+// mode 0 (first loop): α = ρ_j·Σ, a[j] = α, dir −= α·y_j;  mode 1 (second loop): β = ρ_j·Σ, dir += (a[j] − β)·s_j
+__global__ void __launch_bounds__(SDPLR_NT)
+k_lit_axpy(const DevCtrl* __restrict__ c, FactorArena A, long long N, int h, int i, int mode, const double* __restrict__ rho,
+           double* __restrict__ a, int slot, int nb, const double* __restrict__ partials, int check_done) {
+  __shared__ double sh[8];
+  const int dn = check_done ? c->done : 0;
+  const int j = lit_slot(c->latest, h, i);
+  const double dot = reduce_partials(slot_partials(partials, slot), nb, sh);   // every block: the same sum in the same order
+  if (dn) return;
+  double coef;
+  if (mode == 0) {
+    const double al = rho[j] * dot;
+    coef = -al;
+    if (blockIdx.x == 0 && threadIdx.x == 0) a[j] = al;
+  } else {
+    coef = a[j] - rho[j] * dot;
+  }
+  const double* v = aslot(A, (mode == 0 ? as_y0(A) : AS_S0) + j);
+  double* dir = aslot(A, AS_D);
+  const long long stride = (long long)gridDim.x * SDPLR_NT;
+  for (long long e = (long long)blockIdx.x * SDPLR_NT + threadIdx.x; e < N; e += stride) dir[e] += coef * v[e];
+}
+// dir ← −dir (negate), y_next ← −G, partials of ⟨dir, G⟩ (src/sdplr.jl:201) for k_descent
+__global__ void __launch_bounds__(SDPLR_NT)
+k_lit_finish(const DevCtrl* __restrict__ c, FactorArena A, long long N, int h, int negate, double* __restrict__ partials,
+             int check_done) {
+  __shared__ double sh[8];
+  const int dn = check_done ? c->done : 0;
+  const int latest = c->latest;
+  if (dn) return;
+  const double* G = aslot(A, AS_G);
+  double* dir = aslot(A, AS_D);
+  double* ynext = aslot(A, as_y0(A) + (latest % h));
+  double desc = 0.0;
+  const long long stride = (long long)gridDim.x * SDPLR_NT;
+  for (long long e = (long long)blockIdx.x * SDPLR_NT + threadIdx.x; e < N; e += stride) {
+    const double g = G[e];
+    const double d = negate ? -dir[e] : dir[e];
+    dir[e] = d;
+    ynext[e] = -g;
+    desc += d * g;
+  }
+  desc = block_sum1(desc, sh);
+  if (threadIdx.x == 0) slot_partials(partials, SLOT_DESCENT)[blockIdx.x] = desc;
+}
+// lbfgs_update! (src/lbfgs.jl:129-149): dir *= α, s_j = dir, y_j += G, partials of ⟨y_j, s_j⟩; j = latest mod h
+__global__ void __launch_bounds__(SDPLR_NT)
+k_lit_update(const DevCtrl* __restrict__ c, FactorArena A, long long N, int h, double* __restrict__ partials, int check_done) {
+  __shared__ double sh[8];
+  const int dn = check_done ? (c->done | c->reldelta_exit) : 0;   // :239-241 breaks before lbfgs_update!
+  const int j = c->latest % h;
+  const double alpha = c->alpha;
+  if (dn) return;
+  const double* G = aslot(A, AS_G);
+  double* dir = aslot(A, AS_D);
+  double* Sj = aslot(A, AS_S0 + j);
+  double* Yj = aslot(A, as_y0(A) + j);
+  double t = 0.0;
+  const long long stride = (long long)gridDim.x * SDPLR_NT;
+  for (long long e = (long long)blockIdx.x * SDPLR_NT + threadIdx.x; e < N; e += stride) {
+    const double sn = alpha * dir[e];
+    const double yn = Yj[e] + G[e];
+    dir[e] = sn;
+    Sj[e] = sn;
+    Yj[e] = yn;
+    t += yn * sn;
+  }
+  t = block_sum1(t, sh);
+  if (threadIdx.x == 0) slot_partials(partials, SLOT_GRAM)[blockIdx.x] = t;
+}
+// ρ_j = 1/⟨y_j, s_j⟩ (:146), latest = j (:148).  One block.
+__global__ void __launch_bounds__(SDPLR_NT)
+k_lit_rho(DevCtrl* __restrict__ c, int h, double* __restrict__ rho, int nb, const double* __restrict__ partials, int check_done) {
+  __shared__ double sh[8];
+  const int dn = check_done ? (c->done | c->reldelta_exit) : 0;
+  const int j = c->latest % h;
+  const double ys = reduce_partials(slot_partials(partials, SLOT_GRAM), nb, sh);
+  if (dn) return;
+  if (threadIdx.x == 0) {
+    rho[j] = 1.0 / ys;
+    c->latest = j + 1;
+  }
+}
+
 // ---- R += α·dirt  (src/sdplr.jl:219) ------------------------------------------------------------------
 __global__ void __launch_bounds__(SDPLR_NT)
 k_axpy_R(const DevCtrl* __restrict__ c, double* __restrict__ R, const double* __restrict__ D,

@@ -138,6 +138,9 @@ struct sdplr_hip_solver {
   bool tiles_deferred = false;   // an instance of the resident route: the tiles (multi-launch route) are built when first needed
   bool tile_attr_done = false;
   bool tile_panels = false;  // SDPLR_HIP_TILE_PANELS: 128-byte half-row gathers, two passes over the lists (experiment)
+  // numlbfgsvecs > SDPLR_HMAX: the two-loop recursion as written (k_dense.h, k_lit_*), ρ and a in device arrays of their own
+  bool lit = false;
+  double *lit_rho = nullptr, *lit_a = nullptr;
   bool no_pdrop = false;     // SDPLR_HIP_NO_PDROP: the step kernel keeps P = A_g·R (P += α·W) instead of carrying G forward
   bool pdrop_now = false;    // this inner loop runs the P-less step kernel (decided at loop entry)
   // G is the gradient at the device's (R, λ, σ) with y as its g! left it: true after fg! / g! / an inner loop, cleared by
@@ -1308,7 +1311,7 @@ int32_t sdplr_hip_create(int64_t n, int64_t m, int64_t r, int64_t h, sdplr_hip_s
   if (!out) return fail(nullptr, SDPLR_ERR_INVALID_ARG, "create: null out");
   *out = nullptr;
   if (n < 1 || m < 0 || r < 1 || h < 0) return fail(nullptr, SDPLR_ERR_INVALID_ARG, "create: bad sizes");
-  if (h > SDPLR_HMAX) return fail(nullptr, SDPLR_ERR_INVALID_ARG, "create: numlbfgsvecs > 16 is not supported");
+  if (h > 4096) return fail(nullptr, SDPLR_ERR_INVALID_ARG, "create: numlbfgsvecs > 4096");   // (> 16: the literal two-loop route, k_dense.h)
   if (n >= (1LL << 31) - 1 || m >= (1LL << 31) - 2 || n * r >= (1LL << 40))
     return fail(nullptr, SDPLR_ERR_INVALID_ARG, "create: sizes exceed the int32 index range of the device layout");
   if (have_device() <= 0) return fail(nullptr, SDPLR_ERR_NO_DEVICE, "no usable HIP device (libsdplr_hip has no CPU fallback)");
@@ -1717,6 +1720,12 @@ int32_t sdplr_hip_finalize(S* s) {
   lap("vectors + control block");
   // ---- structured fast path: classify the sparse matrices ----
   s->dot_descent = getenv("SDPLR_HIP_DOT_DESCENT") != nullptr;
+  s->lit = s->h > SDPLR_HMAX;
+  if (s->lit) {
+    s->dot_descent = true;      // no Gram data: ⟨dir, G⟩ by reduction (k_descent)
+    if ((rc = dzero(s, &s->lit_rho, (size_t)s->h))) return rc;
+    if ((rc = dzero(s, &s->lit_a, (size_t)s->h))) return rc;
+  }
   if (const char* e = getenv("SDPLR_HIP_GRAPH_ITERS")) s->graph_iters = std::max(1, std::min(atoi(e), 64));
   s->no_lrfuse = getenv("SDPLR_HIP_NO_LRFUSE") != nullptr;
   s->force_graph = getenv("SDPLR_HIP_FORCE_GRAPH") != nullptr;
@@ -2098,8 +2107,8 @@ double* vec_ptr(S* s, int32_t which, int64_t* len, bool* in_ctrl) {
     case SDPLR_V_PV: *len = m; return s->pv;
     case SDPLR_V_A_RD: *len = m + 1; return s->A_RD;
     case SDPLR_V_A_DD: *len = m + 1; return s->A_DD;
-    case SDPLR_V_LBFGS_RHO: *len = s->h; *in_ctrl = true; return s->hc->rho;
-    case SDPLR_V_LBFGS_A: *len = s->h; *in_ctrl = true; return s->hc->a;
+    case SDPLR_V_LBFGS_RHO: *len = s->h; *in_ctrl = !s->lit; return s->lit ? s->lit_rho : s->hc->rho;
+    case SDPLR_V_LBFGS_A: *len = s->h; *in_ctrl = !s->lit; return s->lit ? s->lit_a : s->hc->a;
     case SDPLR_V_UVT: *len = s->nnzT; return s->sp.UVt0;
     case SDPLR_V_TRIU_S_NZVAL: *len = s->nnzT; return s->sp.triu_nzval;
     case SDPLR_V_S_NZVAL: *len = s->nnzS; return s->sp.nzval;
@@ -2366,6 +2375,10 @@ void enq_f(S* s) {
 // 1-block seam kernel: fold update partials / loop tests / two-loop coefficients (k_dense.h)
 void enq_boundary(S* s, int jfixed, int fin_mode, int do_loop, int do_coeff, int desc_mode = 0) {
   ProfScope ps(s, "lbfgs_boundary");
+  if (s->lit) {   // histories beyond SDPLR_HMAX keep no Gram data: the seam folds the norms and makes the loop tests only
+    k_lbfgs_boundary<<<1, 1024, 0, s->stream>>>(s->ctrl, 0, 0, 0, do_loop, 0, 1, s->partials, 0);
+    return;
+  }
   k_lbfgs_boundary<<<1, 1024, 0, s->stream>>>(s->ctrl, (int)s->h, jfixed, fin_mode, do_loop, do_coeff, s->gram_nb, s->partials, desc_mode);
 }
 void enq_gram_row(S* s, int j) {
@@ -2376,7 +2389,7 @@ void enq_gram_row(S* s, int j) {
 }
 // make the Gram data consistent with the stored history and the current G (see k_dense.h)
 void ensure_gram(S* s) {
-  if (s->h == 0) return;
+  if (s->h == 0 || s->lit) { s->gram_dirty = s->sg_stale = s->ynext_pending = false; return; }
   if (s->gram_dirty || s->ynext_pending) {
     ProfScope ps(s, "gram_recompute");
     for (int j = 0; j < (int)s->h; j++) enq_gram_row(s, j);
@@ -2396,9 +2409,22 @@ void enq_lbfgs_dir(S* s, int negate, int in_loop, int apply_fallback, bool skip_
   // Inside the device-driven loop ⟨dir, G⟩ is evaluated by the seam kernel from the Gram data (the same data
   // the direction's coefficients come from) and the fallback is taken by k_lbfgs_dir itself: one launch fewer
   // per iteration.  The stand-alone operator (and SDPLR_HIP_DOT_DESCENT=1) reduces the dot product instead.
-  const int analytic = (in_loop && apply_fallback && !s->dot_descent) ? 1 : 0;
+  const int analytic = (in_loop && apply_fallback && !s->dot_descent && !s->lit) ? 1 : 0;
   enq_boundary(s, 0, in_loop ? 1 : 0, in_loop, 1, analytic ? (negate ? 1 : 2) : 0);
-  {
+  if (s->lit) {   // numlbfgsvecs > SDPLR_HMAX: the recursion as written (k_dense.h, k_lit_*)
+    ProfScope ps(s, "lbfgs_dir");
+    const int h = (int)s->h, nb = s->nb_upd;
+    k_lit_copy<<<s->nb_dense, SDPLR_NT, 0, s->stream>>>(s->ctrl, s->arena, s->N, in_loop);
+    for (int i = 0; i < h; i++) {          // newest → oldest (src/lbfgs.jl:94-102)
+      k_lit_dot<<<nb, SDPLR_NT, 0, s->stream>>>(s->ctrl, s->arena, s->N, h, i, 0, SLOT_GRAM + 1, s->partials, in_loop);
+      k_lit_axpy<<<s->nb_dense, SDPLR_NT, 0, s->stream>>>(s->ctrl, s->arena, s->N, h, i, 0, s->lit_rho, s->lit_a, SLOT_GRAM + 1, nb, s->partials, in_loop);
+    }
+    for (int i = h - 1; i >= 0; i--) {     // oldest → newest (:104-113)
+      k_lit_dot<<<nb, SDPLR_NT, 0, s->stream>>>(s->ctrl, s->arena, s->N, h, i, 1, SLOT_GRAM + 1, s->partials, in_loop);
+      k_lit_axpy<<<s->nb_dense, SDPLR_NT, 0, s->stream>>>(s->ctrl, s->arena, s->N, h, i, 1, s->lit_rho, s->lit_a, SLOT_GRAM + 1, nb, s->partials, in_loop);
+    }
+    k_lit_finish<<<s->nb_dense, SDPLR_NT, 0, s->stream>>>(s->ctrl, s->arena, s->N, h, negate, s->partials, in_loop);
+  } else {
     ProfScope ps(s, "lbfgs_dir");
     // (history loads non-temporal only when the arena does not fit the 256 MiB Infinity Cache: k_dense.h, NTH)
     static const long long nt_above = getenv("SDPLR_HIP_DIR_NT_ABOVE_MB") ? atoll(getenv("SDPLR_HIP_DIR_NT_ABOVE_MB")) << 20 : 200LL << 20;
@@ -2420,6 +2446,11 @@ void enq_lbfgs_update(S* s, int chk) {
   if (s->h == 0) return;
   s->gram_nb = s->nb_upd;
   ProfScope ps(s, "lbfgs_update");
+  if (s->lit) {
+    k_lit_update<<<s->nb_upd, SDPLR_NT, 0, s->stream>>>(s->ctrl, s->arena, s->N, (int)s->h, s->partials, chk);
+    k_lit_rho<<<1, SDPLR_NT, 0, s->stream>>>(s->ctrl, (int)s->h, s->lit_rho, s->nb_upd, s->partials, chk);
+    return;
+  }
   k_lbfgs_update<true><<<s->nb_upd, SDPLR_NT, 0, s->stream>>>(s->ctrl, s->arena, s->N, (int)s->h, 0, 1, 0, chk, s->partials);
   for (int l0 = 4; l0 < (int)s->h; l0 += 4)   // longer histories: the dots of the new pair with the other windows of four slots
     k_lbfgs_update<false><<<s->nb_upd, SDPLR_NT, 0, s->stream>>>(s->ctrl, s->arena, s->N, (int)s->h, 0, 1, l0, chk, s->partials);
@@ -3323,6 +3354,10 @@ int32_t sdplr_hip_lbfgs_clear(S* s) {
   NEED_FINAL_RW(s);
   // the 2h history slots are neighbours in the arena: one fill (a small solve clears the history once per major iteration)
   if (s->h > 0) HIPCK(s, hipMemsetAsync(aslot(s->arena, AS_S0), 0, (size_t)2 * s->h * s->arena.stride * sizeof(double), s->stream));
+  if (s->lit) {
+    HIPCK(s, hipMemsetAsync(s->lit_rho, 0, (size_t)s->h * sizeof(double), s->stream));
+    HIPCK(s, hipMemsetAsync(s->lit_a, 0, (size_t)s->h * sizeof(double), s->stream));
+  }
   int rc = pull(s);
   if (rc) return rc;
   memset(s->hc->rho, 0, sizeof s->hc->rho); memset(s->hc->a, 0, sizeof s->hc->a);

@@ -91,7 +91,7 @@ def test_operators_match_oracle_and_dense(hip_abi, oracle_abi, family, seed, n, 
     g.close(); o.close()
 
 
-@pytest.mark.parametrize("h", [0, 1, 2, 3, 4, 6, 9])
+@pytest.mark.parametrize("h", [0, 1, 2, 3, 4, 6, 9, 17, 20])     # (> 16: the literal two-loop route, k_lit_*)
 @pytest.mark.parametrize("r", [2, 3, 32])
 def test_lbfgs_matches_oracle(hip_abi, oracle_abi, h, r):
     """lbfgs_dir!/lbfgs_update!/lbfgs_clear! (src/lbfgs.jl) incl. the cyclic wrap and host-written slots."""
@@ -272,11 +272,14 @@ def test_inner_loop_trajectory_over_history_lengths(hip_abi, oracle_abi, family,
     normC, normb = data.normC(), float(np.linalg.norm(data.b))
     sg, so = g.fg(normC, normb), o.fg(normC, normb)
     k = 3 * h + 2
-    rg = g.inner_loop(normC, normb, True, True, False, 0.0, -1e300, k, 0.0, *sg)
-    ro = o.inner_loop(normC, normb, True, True, False, 0.0, -1e300, k, 0.0, *so)
+    arm = data.has_inequalities
+    if arm:
+        k = h + 3          # (Armijo: a backtracking decision can flip on round-off further out)
+    rg = g.inner_loop(normC, normb, True, True, arm, 0.0, -1e300, k, 0.0, *sg)
+    ro = o.inner_loop(normC, normb, True, True, arm, 0.0, -1e300, k, 0.0, *so)
     assert rg[4] == ro[4] == k
-    assert np.allclose(rg[:3], ro[:3], rtol=1e-7, atol=1e-12), (rg, ro)
-    assert rel(g.Rt, o.Rt) < 1e-7
+    assert np.allclose(rg[:3], ro[:3], rtol=1e-6 if arm else 1e-7, atol=1e-12), (rg, ro)
+    assert rel(g.Rt, o.Rt) < (1e-5 if arm else 1e-7)
     assert g.get_scalar(cabi.S_LBFGS_LATEST) == o.get_scalar(cabi.S_LBFGS_LATEST)
     assert np.allclose(g.get_vec(cabi.V_LBFGS_RHO), o.get_vec(cabi.V_LBFGS_RHO), rtol=1e-6)
     g.close(); o.close()
@@ -956,7 +959,10 @@ def test_lanczos_band_form_matches_gather_form_and_oracle(hip_abi, oracle_abi, m
         assert abs(a[5] - b[5]) <= 1e-6 * scale and abs(a[1] - b[1]) <= 1e-6 * scale and a[1] == a[5]
 
 
-@pytest.mark.parametrize("family,r,h", [("maxcut", 128, 12), ("maxcut", 64, 16), ("minimum_bisection", 96, 7), ("lovasz_theta", 128, 5)])
+@pytest.mark.parametrize("family,r,h", [("maxcut", 128, 12), ("maxcut", 64, 16), ("minimum_bisection", 96, 7), ("lovasz_theta", 128, 5),
+                                        # numlbfgsvecs beyond the Gram form's 16 (src/lbfgs.jl:35-47 allocates any m): the recursion as
+                                        # written, on the structured, the rank-one and the edge path, graph replay and eager
+                                        ("maxcut", 8, 20), ("minimum_bisection", 6, 33), ("lovasz_theta", 4, 18), ("ineq_0.05", 4, 24)])
 def test_wide_ranks_and_long_histories(hip_abi, oracle_abi, family, r, h):
     """Ranks beyond one DPP row (r = 64 … 128: whole-wave row groups, the tile kernel's wide instantiations — built without
     scratch since round 3) together with histories longer than the fused kernels' four pairs (numlbfgsvecs up to the
