@@ -1187,6 +1187,111 @@ k_spmm_fast(DevSparse sg, int m, DevFast ff, const double* __restrict__ R, const
   }
 }
 
+// ---- fg! on the singleton fast path (src/coreop.jl:323-349) ---------------------------------------------------------
+// The gather kernel run on (R, R) instead of (R, D) leaves P = A_g·R, v_k·‖R_j‖² = 𝒜(RRᵀ)_k for the row-attached constraints
+// (in its A_DD output) and the block partials of ⟨R, P⟩ = ⟨A_g, RRᵀ⟩: f! and g! are then two m- / n-sized passes.
+// k_fg_fast_tail: f!'s tail (:16-29) + copy2y_λ_sub_pvio! (:229-236) for the row-attached slots — one constraint per
+// thread — and, by block 0, A_g's own slot from the ⟨R, P⟩ partials.  Partials: SLOT_F (Σ(ỹ² − λ²)/2σ), SLOT_PVNORM2.
+__global__ void __launch_bounds__(SDPLR_NT)
+k_fg_fast_tail(DevCtrl* __restrict__ c, int m, int gid_g, const double* __restrict__ AA, double* __restrict__ pv_raw,
+               const double* __restrict__ b, const double* __restrict__ lb, double* __restrict__ pv,
+               const double* __restrict__ lam, const double* __restrict__ lam_ub, double* __restrict__ y,
+               int nb_pd, double* __restrict__ partials) {
+  __shared__ double sh[8];
+  const double sigma = c->sigma;
+  double fs = 0.0, pn = 0.0;
+  if (blockIdx.x == 0) {   // A_g's slot: 𝒜(RRᵀ)_g = ⟨R, P⟩
+    const double v0 = reduce_partials(slot_partials(partials, SLOT_PD), nb_pd, sh);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double v = v0, yk = 1.0;                               // (the cost slot: y = 1, src/coreop.jl:235)
+      if (gid_g < m) {
+        v -= b[gid_g];
+        const double pc = fmax(v, lb[gid_g]);
+        pv[gid_g] = pc;
+        pn += pc * pc;
+        const double l = lam[gid_g], yt = fmin(lam_ub[gid_g], l - sigma * v);
+        fs += (yt * yt - l * l) / (2 * sigma);
+        yk = -yt;
+      }
+      pv_raw[gid_g] = v;
+      y[gid_g] = yk;
+    }
+  }
+  const int stride = gridDim.x * SDPLR_NT;
+  for (int i = blockIdx.x * SDPLR_NT + threadIdx.x; i <= m; i += stride) {
+    if (i == gid_g) continue;
+    if (i == m) {   // the cost matrix as a row-attached entry
+      pv_raw[i] = AA[i];
+      y[i] = 1.0;
+      continue;
+    }
+    const double v = AA[i] - b[i];                           // (:20)
+    pv_raw[i] = v;
+    const double pc = fmax(v, lb[i]);                        // (:22)
+    pv[i] = pc;
+    pn += pc * pc;
+    const double l = lam[i], yt = fmin(lam_ub[i], l - sigma * v);   // (:27)
+    fs += (yt * yt - l * l) / (2 * sigma);                   // (:28)
+    y[i] = -yt;                                              // src/coreop.jl:233
+  }
+  double two[2] = {fs, pn};
+  __syncthreads();
+  __shared__ double sh2[2 * (SDPLR_NT / 64)];
+  block_sum<2>(two, sh2);
+  if (threadIdx.x == 0) {
+    slot_partials(partials, SLOT_F)[blockIdx.x] = two[0];
+    slot_partials(partials, SLOT_PVNORM2)[blockIdx.x] = two[1];
+  }
+}
+// G = 2·(y_g·P + d(y)∘R) (src/coreop.jl:305-317 on the structured form) with the ‖G‖² partials
+template <int LPR, int VEC>
+__global__ void __launch_bounds__(SDPLR_NT)
+k_fg_fast_G(int n, DevFast ff, const double* __restrict__ R, const double* __restrict__ P, double* __restrict__ G, int r,
+            const double* __restrict__ yvec, double* __restrict__ partials) {
+  __shared__ double sh[8];
+  constexpr int GR = SDPLR_NT / LPR;
+  const int lane = threadIdx.x % LPR;
+  const long long total = (long long)gridDim.x * GR;
+  const double yg = yvec[ff.gid_g];
+  double nrm = 0.0;
+  for (long long j = (long long)blockIdx.x * GR + threadIdx.x / LPR; j < n; j += total) {
+    double dj = 0.0;
+    for (int e = ff.drow_ptr[j]; e < ff.drow_ptr[j + 1]; e++) dj += ff.drow_val[e] * yvec[ff.drow_gid[e]];
+    for (int ch = lane * VEC; ch < r; ch += LPR * VEC) {
+      const vecd<VEC> x = ldrow<VEC>(R + j * r + ch), pp = ldrow<VEC>(P + j * r + ch);
+      vecd<VEC> g;
+#pragma unroll
+      for (int q = 0; q < VEC; q++) {
+        g.v[q] = pp.v[q] * yg + x.v[q] * dj;
+        g.v[q] *= 2.0;
+        nrm += g.v[q] * g.v[q];
+      }
+      strow<VEC>(G + j * r + ch, g);
+    }
+  }
+  nrm = block_sum1(nrm, sh);
+  if (threadIdx.x == 0) slot_partials(partials, SLOT_GNORM2)[blockIdx.x] = nrm;
+}
+// obj, ℒ, grad_norm, primal_vio_norm (src/coreop.jl:16,25-30,334-347).  One block.
+__global__ void __launch_bounds__(SDPLR_NT)
+k_fg_fast_fin(DevCtrl* __restrict__ c, int m, const double* __restrict__ pv_raw, int nb_m, int nb_g,
+              const double* __restrict__ partials) {
+  __shared__ double sh[8];
+  const double fs = reduce_partials(slot_partials(partials, SLOT_F), nb_m, sh);
+  __syncthreads();
+  const double p2 = reduce_partials(slot_partials(partials, SLOT_PVNORM2), nb_m, sh);
+  __syncthreads();
+  const double g2 = reduce_partials(slot_partials(partials, SLOT_GNORM2), nb_g, sh);
+  if (threadIdx.x != 0) return;
+  const double obj = pv_raw[m];
+  c->obj = obj;
+  c->L = obj + fs;
+  const double g = sqrt(g2), pq = sqrt(p2);
+  c->gnorm = c->grel ? g / c->normC : g;
+  c->pvnorm = c->prel ? pq / c->normb : pq;
+}
+
 // ---- column-sweep form of k_spmm_fast --------------------------------------------------------------------
 // A sub-wave group owns a tile of K consecutive rows.  The tile's nonzeros are stored sorted by COLUMN
 // (entry = local row << SDPLR_TILE_COLBITS | column, value), so every group walks its list from column 0 to column n−1, and

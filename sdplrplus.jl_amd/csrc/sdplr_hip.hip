@@ -3297,6 +3297,40 @@ int32_t sdplr_hip_fg(S* s, double normC, double normb, int32_t grel, int32_t pre
     if (pn) *pn = s->hc->pvnorm;
     return sync_check(s);
   }
+  // the singleton fast path without low-rank matrices (MaxCut, CutNorm): P = A_g·R by the gather kernel on (R, R), whose
+  // epilogue also leaves 𝒜(RRᵀ) of the row-attached constraints and the partials of ⟨R, P⟩ — then two m- / n-sized passes
+  // instead of the generic twelve kernels (SDDMM, segmented reduction, S assembly, SpMM: ≈ 190 µs at the north-star size)
+  if (s->fast && s->fast_singleton && s->lr.ST == 0 && s->use_tile && !s->tiles_deferred && s->tile_lpr == tile_shape_lpr(s) &&
+      s->n * s->r * 8 < (1LL << 32) && getenv("SDPLR_HIP_NO_FAST_FG") == nullptr) {
+    if ((rc = tile_lds_attr(s))) return rc;
+    double *R = aslot(s->arena, AS_R), *G = aslot(s->arena, AS_G), *P = fast_P(s);
+    if (!s->all_covered) HIPCK(s, hipMemsetAsync(s->A_DD, 0, (s->m + 1) * sizeof(double), s->stream));   // fill!(out, 0), src/coreop.jl:39
+    {
+      ProfScope ps(s, "spmm_P");
+      const size_t lds = ((size_t)SDPLR_NT * s->VEC * (s->tile.K + 1) + (size_t)(SDPLR_NT / s->tile_lpr) * (2 * s->tile.K + 8)) * sizeof(double);
+      if (s->tile.gdiag) { TLV_DISPATCH((k_spmm_tile<LPR, VEC, 0, true><<<s->nb_tile, SDPLR_NT, lds, s->stream>>>(s->tile, (int)s->n, (int)s->m, s->ff, R, R, P, P, (int)s->r, s->lambda, s->pv_raw, s->A_RD, s->A_DD, s->partials, s->ctrl, 0, s->lr, s->lr_part, 0))) }
+      else { TLV_DISPATCH((k_spmm_tile<LPR, VEC, 0><<<s->nb_tile, SDPLR_NT, lds, s->stream>>>(s->tile, (int)s->n, (int)s->m, s->ff, R, R, P, P, (int)s->r, s->lambda, s->pv_raw, s->A_RD, s->A_DD, s->partials, s->ctrl, 0, s->lr, s->lr_part, 0))) }
+    }
+    {
+      ProfScope ps(s, "fg_tail");
+      k_fg_fast_tail<<<s->nb_m, SDPLR_NT, 0, s->stream>>>(s->ctrl, (int)s->m, s->ff.gid_g, s->A_DD, s->pv_raw, s->b, s->pv_lb, s->pv, s->lambda, s->lambda_ub, s->y, s->nb_tile, s->partials);
+    }
+    {
+      ProfScope ps(s, "fg_G");
+      LV_DISPATCH((k_fg_fast_G<LPR, VEC><<<s->nb_spmm, SDPLR_NT, 0, s->stream>>>((int)s->n, s->ff, R, P, G, (int)s->r, s->y, s->partials)))
+    }
+    k_fg_fast_fin<<<1, SDPLR_NT, 0, s->stream>>>(s->ctrl, (int)s->m, s->pv_raw, s->nb_m, s->nb_spmm, s->partials);
+    s->P_valid = true; s->P_age = 0;
+    s->S_stale = true; s->S_from_y = true;   // y is current, S is assembled by whoever reads it next (ensure_S)
+    s->sg_stale = true;
+    s->G_consistent = true;
+    s->G_age = 0;
+    if ((rc = pull(s))) return rc;
+    if (L) *L = s->hc->L;
+    if (gn) *gn = s->hc->gnorm;
+    if (pn) *pn = s->hc->pvnorm;
+    return sync_check(s);
+  }
   enq_f(s);
   enq_g(s, 0, false);
   s->S_stale = false;
