@@ -257,6 +257,12 @@ end
 
 "primes the library's pools (HIP streams, events, pinned staging) for `n` handles alive at once — optional, before a batch"
 hip_warmup(n::Integer) = hip_check(ccall((:sdplr_hip_warmup, LIBSDPLR_HIP), Int32, (Int32,), n), C_NULL)
+# what the library's pools cache and no handle uses goes back to the HIP runtime (a process that shares the GPU)
+hip_trim_pools() = hip_check(ccall((:sdplr_hip_trim_pools, LIBSDPLR_HIP), Int32, ()), C_NULL)
+# one rank = one GPU: sticky — every later call of this process, from any task / thread, is bound to the device
+hip_set_device(dev::Integer) = hip_check(ccall((:sdplr_hip_set_device, LIBSDPLR_HIP), Int32, (Int32,), dev), C_NULL)
+# `update_lambda` of sdplr_hip_major_iteration / HIPMajorItem: continue a loop that ran out of its iteration budget
+const SDPLR_MAJOR_RESUME = Int32(2)
 
 "approx_mineigval_lanczos(var, aux, q) — src/coreop.jl:461-514 (the start vector replaces the internal randn of :473)"
 function approx_mineigval_lanczos(var::SolverVars, aux::HIPAux, q::Integer)
