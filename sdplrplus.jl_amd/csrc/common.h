@@ -45,6 +45,10 @@ struct DevCtrl {
   // ---- per-iteration scalars ----
   double L, lastval, gnorm, pvnorm, alpha, descent, alpha_max;
   double pv2_extra;    // ‖pv‖² share of slots committed by a scalar kernel (singleton fast path)
+  // the cost slot's new value decided by the step kernel's line-search head (k_fast_step2<…, LSH>): every block of that
+  // kernel READS obj, so block 0 leaves the new value here and the seam kernel that follows stores it (obj and pv_raw[m])
+  double obj_next;
+  int obj_pending, pad2_;
   double biquad[5];
   // ---- Lanczos (src/coreop.jl:461-500) ----
   int lz_done;

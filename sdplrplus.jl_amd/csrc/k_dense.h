@@ -317,7 +317,8 @@ __device__ inline void seam_serial_small(SeamLds& gd, int jfixed, int fin_mode, 
 // global round trips.
 __global__ void __launch_bounds__(1024)
 k_lbfgs_boundary(DevCtrl* __restrict__ c, int h, int jfixed, int fin_mode, int do_loop, int do_coeff,
-                 int nb_partials, const double* __restrict__ partials, int desc_mode) {
+                 int nb_partials, const double* __restrict__ partials, int desc_mode, double* __restrict__ pv_raw = nullptr,
+                 int m = 0) {
   __shared__ SeamLds gd;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
 #ifdef SDPLR_STAMPS
@@ -327,6 +328,7 @@ k_lbfgs_boundary(DevCtrl* __restrict__ c, int h, int jfixed, int fin_mode, int d
   // and the partials (summed whether or not the flags will want them) — so the kernel pays one memory round
   // trip, not flag → count → partials.
   const int gp = c->gram_pending, np = c->norms_pending;
+  const int op = c->obj_pending;   // the cost slot's new value left by the step kernel's line-search head (k_fast_step2<…, LSH>)
   // (the control block's words go to registers here and into LDS only after the partials have been requested: an LDS
   // store of a loaded value makes the wave wait for that load where the store stands in the program)
   static_assert(sizeof(DevCtrl) / 8 <= 1024, "one word of the control block per thread");
@@ -379,8 +381,13 @@ k_lbfgs_boundary(DevCtrl* __restrict__ c, int h, int jfixed, int fin_mode, int d
   if (tid < (int)(sizeof(DevCtrl) / 8)) reinterpret_cast<unsigned long long*>(&gd.c)[tid] = cw;
   const bool fin = (fin_mode == 2) || (fin_mode == 1 && gp);
   const bool norms = np != 0;
-  if (!fin && !do_coeff && !do_loop && !norms) return;
+  if (!fin && !do_coeff && !do_loop && !norms && !op) return;
   __syncthreads();
+  if (tid == 0 && op) {   // obj[] = primal_vio_raw[m+1] (src/linesearch.jl:118-121), on behalf of that head
+    gd.c.obj = gd.c.obj_next;
+    gd.c.obj_pending = 0;
+    if (pv_raw != nullptr) pv_raw[m] = gd.c.obj_next;
+  }
 #ifdef SDPLR_STAMPS
   const unsigned long long st1 = __builtin_amdgcn_s_memtime();
 #endif

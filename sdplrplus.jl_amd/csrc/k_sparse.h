@@ -14,6 +14,7 @@
 #pragma once
 #include "common.h"
 #include "k_dense.h"
+#include "k_scalar.h"   // quartic_argmin (the line-search head of k_fast_step2)
 
 struct DevSparse {
   int n, nnzT, nnzS, nnzAgg, n_sparse;
@@ -812,7 +813,12 @@ k_fast_lr_ws(DevLowRank lr, int r, double* __restrict__ W, const double* __restr
 // and G_old streams through this kernel anyway (for y_j): the gradient is carried forward incrementally, exactly as P was
 // (P += α·W), at 2N bytes less per iteration.  d(y_old) is read off y before the commit overwrites it.  G is rebuilt from
 // scratch by every fg! / g! (each major iteration) and after SDPLR_HIP_P_REFRESH_ITERS incremental steps.
-template <int LPR, int VEC, int HMU, bool COMMIT, bool PDROP = false>
+// LSH (with PDROP; A_g = the cost matrix is the only slot not attached to a row): the scalar stage of the exact line search
+// (k_ls_solve_fast: fold of the ten line-search sums, quartic, α*, ℒ(α*), relative-decrease test, commit of the cost slot) runs
+// as a prologue of EVERY block — the same partials summed in the same order, the same arithmetic: the same α in every block, bit
+// for bit — instead of as a single-block kernel between the gather kernel and this one: one launch and one boundary less per
+// iteration (≈ 8 µs) for ≈ 4 µs of prologue.  Block 0 stores the scalars; obj, which every block reads, is handed to the seam.
+template <int LPR, int VEC, int HMU, bool COMMIT, bool PDROP = false, bool LSH = false>
 __global__ void __launch_bounds__(SDPLR_NT)
 k_fast_step2(int n, int m, DevFast ff, double* __restrict__ R, double* __restrict__ D,
              double* __restrict__ P, const double* __restrict__ W, double* Gout, int r,
@@ -820,7 +826,7 @@ k_fast_step2(int n, int m, DevFast ff, double* __restrict__ R, double* __restric
              double* __restrict__ pv_raw, const double* __restrict__ lb, double* __restrict__ pv,
              const double* __restrict__ A_RD, const double* __restrict__ A_DD, DevLowRank lr,
              const double* __restrict__ WS, double* __restrict__ partials, DevCtrl* __restrict__ c,
-             int check_done, FactorArena A, int h, int gold_in_G) {
+             int check_done, FactorArena A, int h, int gold_in_G, int nb_ls = 0) {
   constexpr int HA = HMU > 0 ? HMU : 1;
   __shared__ double sh[2 * (SDPLR_NT / 64)];
   extern __shared__ double accl[];  // HMU > 0: [5·HMU][NT] running Gram sums, one column per lane
@@ -830,8 +836,79 @@ k_fast_step2(int n, int m, DevFast ff, double* __restrict__ R, double* __restric
   constexpr int G = SDPLR_NT / LPR;
   const int lane = threadIdx.x % LPR;
   const long long total = (long long)gridDim.x * G;
-  const double a = c->alpha, sigma = c->sigma, yg = yvec[ff.gid_g];
-  const bool upd = HMU > 0 && c->reldelta_exit == 0;
+  const double sigma = c->sigma;
+  double a, yg;
+  bool upd;
+  if constexpr (LSH) {
+    __shared__ double shl[10 * (SDPLR_NT / 64)];
+    const double obj0 = c->obj, amax = c->alpha_max, last = c->lastval, feps = c->fprec_eps;
+    double s10[10];
+    {
+      // the partials, 16 bytes per lane and column (k_ls_solve_fast's fetch: nb_ls ≤ 1024 producers, absent entries masked)
+      constexpr int PT = 2;
+      double2 v[10][PT];
+      const int ncols = (nb_ls + 2 * SDPLR_NT - 1) / (2 * SDPLR_NT);
+#pragma unroll
+      for (int q = 0; q < PT; q++) {
+        const int i = (int)threadIdx.x + SDPLR_NT * q;
+        if (q < ncols) {
+#pragma unroll
+          for (int k = 0; k < 8; k++) v[k][q] = reinterpret_cast<const double2*>(slot_partials(partials, SLOT_LS + k))[i];
+          v[8][q] = reinterpret_cast<const double2*>(slot_partials(partials, SLOT_PD))[i];
+          v[9][q] = reinterpret_cast<const double2*>(slot_partials(partials, SLOT_DW))[i];
+        } else {
+#pragma unroll
+          for (int k = 0; k < 10; k++) v[k][q].x = v[k][q].y = 0.0;
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 10; k++) {
+        s10[k] = 0.0;
+#pragma unroll
+        for (int q = 0; q < PT; q++) {
+          const int i = 2 * ((int)threadIdx.x + SDPLR_NT * q);
+          s10[k] += (i < nb_ls) ? v[k][q].x : 0.0;
+          s10[k] += (i + 1 < nb_ls) ? v[k][q].y : 0.0;
+        }
+      }
+    }
+    block_sum<10>(s10, shl);   // (k_ls_solve_fast's order: lane → wave → the four waves)
+    const double g_rd = s10[8] + s10[8], g_dd = s10[9];
+    double bq[5];
+    bq[0] = obj0 - s10[0] + sigma * s10[1] / 2;      // src/linesearch.jl:44-56 (the cost slot is p0, p1, p2)
+    bq[1] = g_rd - s10[2] + sigma * s10[3];
+    bq[2] = g_dd - s10[4] + sigma * s10[5] / 2;
+    bq[3] = sigma * s10[6];
+    bq[4] = sigma * s10[7] / 2;
+    double al = 0.0, f = bq[0];
+    const int rc = quartic_argmin(bq, amax, &al, &f);
+    if (rc != 0) {
+      if (blockIdx.x == 0 && threadIdx.x == 0 && !dn) {
+        c->err = rc;
+        c->done = 1;
+      }
+      return;
+    }
+    const double rel_delta = (last - f) / fmax(1.0, fmax(fabs(f), fabs(last)));   // src/sdplr.jl:238
+    upd = HMU > 0 && !(rel_delta < feps);
+    a = al;
+    yg = 1.0;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && !dn) {
+      for (int k = 0; k < 5; k++) c->biquad[k] = bq[k];
+      c->alpha = al;
+      c->L = f;
+      c->reldelta_exit = upd ? 0 : 1;
+      const_cast<double*>(A_RD)[m] = g_rd;    // ⟨A_g, RDᵀ+DRᵀ⟩ = 2⟨P, D⟩ (= 2⟨R, W⟩)
+      const_cast<double*>(A_DD)[m] = g_dd;    // ⟨A_g, DDᵀ⟩ = ⟨D, W⟩
+      c->obj_next = obj0 + al * (al * g_dd + g_rd);   // commit of the cost slot (src/linesearch.jl:118-121): stored by the seam
+      c->obj_pending = 1;
+      c->pv2_extra = 0.0;
+    }
+  } else {
+    a = c->alpha;
+    yg = yvec[ff.gid_g];
+    upd = HMU > 0 && c->reldelta_exit == 0;
+  }
   // slot j's stream carries −G_old (parked by lbfgs_dir!) or, with gold_in_G, the G array itself: ±G_old
   const double gs = (HMU > 0 && gold_in_G) ? (c->fallback ? 1.0 : -1.0) : 1.0;
   const int jslot = HMU > 0 ? (c->latest % h) : 0;

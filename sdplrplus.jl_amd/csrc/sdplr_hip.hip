@@ -141,6 +141,7 @@ struct sdplr_hip_solver {
   // numlbfgsvecs > SDPLR_HMAX: the two-loop recursion as written (k_dense.h, k_lit_*), ρ and a in device arrays of their own
   bool lit = false;
   double *lit_rho = nullptr, *lit_a = nullptr;
+  bool no_lshead = false;    // SDPLR_HIP_NO_LSHEAD: the line-search scalar stage stays a kernel of its own
   bool no_pdrop = false;     // SDPLR_HIP_NO_PDROP: the step kernel keeps P = A_g·R (P += α·W) instead of carrying G forward
   bool pdrop_now = false;    // this inner loop runs the P-less step kernel (decided at loop entry)
   // G is the gradient at the device's (R, λ, σ) with y as its g! left it: true after fg! / g! / an inner loop, cleared by
@@ -1731,6 +1732,7 @@ int32_t sdplr_hip_finalize(S* s) {
   s->force_graph = getenv("SDPLR_HIP_FORCE_GRAPH") != nullptr;
   s->no_updfuse = getenv("SDPLR_HIP_NO_UPDFUSE") != nullptr;
   s->no_pdrop = getenv("SDPLR_HIP_NO_PDROP") != nullptr;
+  s->no_lshead = getenv("SDPLR_HIP_NO_LSHEAD") != nullptr;
   s->tile_panels = getenv("SDPLR_HIP_TILE_PANELS") != nullptr;
   if (s->have_sparse && getenv("SDPLR_HIP_NO_FAST") == nullptr) {
     std::vector<int> general;
@@ -2376,10 +2378,10 @@ void enq_f(S* s) {
 void enq_boundary(S* s, int jfixed, int fin_mode, int do_loop, int do_coeff, int desc_mode = 0) {
   ProfScope ps(s, "lbfgs_boundary");
   if (s->lit) {   // histories beyond SDPLR_HMAX keep no Gram data: the seam folds the norms and makes the loop tests only
-    k_lbfgs_boundary<<<1, 1024, 0, s->stream>>>(s->ctrl, 0, 0, 0, do_loop, 0, 1, s->partials, 0);
+    k_lbfgs_boundary<<<1, 1024, 0, s->stream>>>(s->ctrl, 0, 0, 0, do_loop, 0, 1, s->partials, 0, s->pv_raw, (int)s->m);
     return;
   }
-  k_lbfgs_boundary<<<1, 1024, 0, s->stream>>>(s->ctrl, (int)s->h, jfixed, fin_mode, do_loop, do_coeff, s->gram_nb, s->partials, desc_mode);
+  k_lbfgs_boundary<<<1, 1024, 0, s->stream>>>(s->ctrl, (int)s->h, jfixed, fin_mode, do_loop, do_coeff, s->gram_nb, s->partials, desc_mode, s->pv_raw, (int)s->m);
 }
 void enq_gram_row(S* s, int j) {
   s->gram_nb = s->nb_upd;
@@ -2707,7 +2709,11 @@ void enq_iteration_fast2(S* s) {
   } else {
     enq_lowrank(s, R, D, 2, 2, s->A_RD, s->A_DD, 1);
   }
-  {
+  // the scalar stage as the step kernel's own prologue (k_sparse.h, LSH): with the P-less kernel, the cost matrix the only
+  // slot not attached to a row, and ≤ 1024 producers of line-search partials
+  const int nb_ls = (s->use_tile && s->tile_lpr == tile_shape_lpr(s) && s->n * s->r * 8 < (1LL << 32)) ? s->nb_tile : s->nb_spmm;
+  const bool lsh = upd_fused && s->pdrop_now && s->n_extra == 1 && s->lr.ST == 0 && nb_ls <= 4 * SDPLR_NT && !s->no_lshead;
+  if (!lsh) {
     ProfScope ps(s, "ls_solve_fast");
     k_ls_solve_fast<<<1, SDPLR_LSF_NT, 0, s->stream>>>(s->ctrl, (int)s->m, s->ff.gid_g, s->n_extra, s->extra_slots, (s->use_tile && s->tile_lpr == tile_shape_lpr(s) && s->n * s->r * 8 < (1LL << 32)) ? s->nb_tile : s->nb_spmm, s->A_RD, s->A_DD, s->lambda, s->lambda_ub, s->pv_raw, s->pv_lb, s->pv, s->y, s->lr.ST, (int)s->r, s->lr.col_gid, s->lr.Dcat, s->lr_W, s->lr_WS, s->partials, 1, lr_fused ? 1 : 0, s->lr.n_lr, s->lr.mat_ptr, s->lr.mat_gid, nullptr, s->extra_head);
   }
@@ -2715,7 +2721,9 @@ void enq_iteration_fast2(S* s) {
   // two kernels — 166 VGPRs and scratch — and dropped)
   {
     ProfScope ps(s, "fast_step");                                                     // :219-234
-    if (upd_fused && s->pdrop_now) {   // … P-less: G carried forward from G_old (k_sparse.h, PDROP)
+    if (lsh) {   // … P-less, with the line-search scalar stage as its prologue
+      LV_DISPATCH((k_fast_step2<LPR, VEC, 4, true, true, true><<<s->nb_step, SDPLR_NT, 5 * 4 * SDPLR_NT * sizeof(double), s->stream>>>((int)s->n, (int)s->m, s->ff, R, D, P, W, G, (int)s->r, s->y, s->lambda, s->lambda_ub, s->pv_raw, s->pv_lb, s->pv, s->A_RD, s->A_DD, s->lr, s->lr_WS, s->partials, s->ctrl, 1, s->arena, (int)s->h, 1, nb_ls)))
+    } else if (upd_fused && s->pdrop_now) {   // … P-less: G carried forward from G_old (k_sparse.h, PDROP)
       LV_DISPATCH((k_fast_step2<LPR, VEC, 4, true, true><<<s->nb_step, SDPLR_NT, 5 * 4 * SDPLR_NT * sizeof(double), s->stream>>>((int)s->n, (int)s->m, s->ff, R, D, P, W, G, (int)s->r, s->y, s->lambda, s->lambda_ub, s->pv_raw, s->pv_lb, s->pv, s->A_RD, s->A_DD, s->lr, s->lr_WS, s->partials, s->ctrl, 1, s->arena, (int)s->h, 1)))
     } else if (upd_fused) {   // … and lbfgs_update! (:244-246) in the same pass
       LV_DISPATCH((k_fast_step2<LPR, VEC, 4, true><<<s->nb_step, SDPLR_NT, 5 * 4 * SDPLR_NT * sizeof(double), s->stream>>>((int)s->n, (int)s->m, s->ff, R, D, P, W, G, (int)s->r, s->y, s->lambda, s->lambda_ub, s->pv_raw, s->pv_lb, s->pv, s->A_RD, s->A_DD, s->lr, s->lr_WS, s->partials, s->ctrl, 1, s->arena, (int)s->h, s->dot_descent ? 0 : 1)))

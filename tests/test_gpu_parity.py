@@ -612,6 +612,7 @@ def test_recycled_device_blocks_do_not_leak_state(hip_abi):
 @pytest.mark.parametrize("family,toggles", [
     ("maxcut", ["SDPLR_HIP_NO_FAST"]), ("maxcut", ["SDPLR_HIP_NO_FAST2"]), ("maxcut", ["SDPLR_HIP_NO_GRAPH"]),
     ("maxcut", ["SDPLR_HIP_NO_PDROP"]), ("cutnorm", ["SDPLR_HIP_NO_PDROP"]), ("maxcut", ["SDPLR_HIP_NO_PDROP", "SDPLR_HIP_NO_GRAPH"]),
+    ("maxcut", ["SDPLR_HIP_NO_LSHEAD"]), ("cutnorm", ["SDPLR_HIP_NO_LSHEAD", "SDPLR_HIP_NO_GRAPH"]),
     ("maxcut", ["SDPLR_HIP_NO_UPDFUSE"]), ("minimum_bisection", ["SDPLR_HIP_NO_UPDFUSE"]),
     ("mu_conductance_0.05", ["SDPLR_HIP_NO_TILE"]), ("mu_conductance_0.05", ["SDPLR_HIP_NO_UPDFUSE"]),
     ("ineq_0.05", ["SDPLR_HIP_NO_TILE", "SDPLR_HIP_NO_UPDFUSE"]),
