@@ -584,7 +584,7 @@ def other_configs(sj, abi):
                         ("LovaszTheta", problems.lovasz_theta_data)):
         ds = [build(g) for g in graphs[:9]]
         kw2 = dict(ptol=1e-2, objtol=1e-2, seed=0, prior_trace_bound=1.0 if name == "LovaszTheta" else 800.0, maxtime=60.0)
-        if name != "LovaszTheta":   # (Lovász-θ on these graphs takes ≈ 6e4 inner iterations per instance, ≈ 13 s for the nine: one pass)
+        if name != "LovaszTheta":   # (Lovász-θ on these graphs takes ≈ 6e4 inner iterations per instance, ≈ 7 s for the nine: one pass)
             batch.solve_local(ds, 0, 1, 10, concurrency=conc, lockstep=True, **kw2)
         abi.device_synchronize()
         t0 = time.perf_counter()
@@ -593,7 +593,7 @@ def other_configs(sj, abi):
         gp = (r_[:, 1] - r_[:, 2]) / np.maximum(1e-300, np.minimum(np.abs(r_[:, 1]), np.abs(r_[:, 2])))
         out["batch_G1_G9_" + name] = {"workload": f"{name} on Gset G1–G9 (exps/gen_batch_test.jl:1-3), rank 10, ptol=objtol=1e-2, lockstep driver, one GPU",
                                       "instances": 9, "wall_s": w_, "inner_iterations_total": int(r_[:, 3].sum()),
-                                      "route": "multi-launch (edge path)" if name == "LovaszTheta" else "resident",
+                                      "route": "multi-launch edge path, one launch per kernel for the group (k_group.h)" if name == "LovaszTheta" else "resident",
                                       "max_abs_relative_gap": float(np.max(np.abs(gp)))}
     out["seconds_spent"] = time.perf_counter() - t_all
     return out

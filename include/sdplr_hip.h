@@ -277,7 +277,9 @@ int32_t sdplr_hip_dual_obj(sdplr_hip_solver* s, double trace_bound, int64_t iter
  * workgroup per instance
  * — B CUs busy from one stream, one argument table up, one result table back — and every other instance of the batch is
  * served by the single-instance entry point named in each struct (on a few host threads of the library's own, each handle
- * on its stream), so the call is total.  Each item is exactly the
+ * on its stream), so the call is total.  In sdplr_hip_batch_major_iteration the instances of the multi-launch EDGE path
+ * (disjoint single-entry constraints: Lovász-θ) that share every launch dimension run their while loops (src/sdplr.jl:190-278)
+ * behind one launch per kernel for the group, block row ↔ instance, after their own λ update / fg! (k_group.h).  Each item is exactly the
  * argument list of that entry point; `status` is what it would have returned for that instance (the function itself
  * returns the first non-zero status, or an argument error).  Results are bit-identical to the single-instance calls.
  * Handles of one call must be distinct and must not be used by other threads during the call.                        */
@@ -340,8 +342,10 @@ int32_t sdplr_hip_factor_dot(sdplr_hip_solver* s, int32_t slot_a, int32_t slot_b
  * workgroup owns the instance for the whole loop), out[9] Lanczos runs as one resident launch, out[10] fg! calls as
  * one resident launch, out[11] of those launches (loops, Lanczos runs, fg!) the ones this instance shared with others
  * (sdplr_hip_batch_*), out[12] the inner loops (calls) that ran the step kernel WITHOUT P = A_g·R (the gradient carried
- * forward from G_old: cost matrix = the general sparse matrix, no low-rank term on the multi-launch route).  Writes
- * min(cap, 13) entries, *n_written says how many.                                                               */
+ * forward from G_old: cost matrix = the general sparse matrix, no low-rank term on the multi-launch route), out[13] the
+ * inner loops this instance ran behind launches SHARED with other instances of a batch call on the multi-launch edge
+ * path (one launch per kernel of the while body for the whole group, sdplr_hip_batch_major_iteration).  Writes
+ * min(cap, 14) entries, *n_written says how many.                                                               */
 int32_t sdplr_hip_get_stats(const sdplr_hip_solver* s, int64_t* out, int32_t cap, int32_t* n_written);
 
 /* ---- per-kernel device timing (hipEvent pairs on the handle's stream) ------------------------ */

@@ -15,8 +15,11 @@ graphs = [problems.graph_from_edges(int(z[f"G{k}_n"]), z[f"G{k}"]) for k in rang
 graphs += [problems.gnp_graph(800, 0.06, seed) for seed in range(10, 65)]
 datas = [problems.maxcut_data(g) for g in graphs]
 kw = dict(ptol=1e-2, objtol=1e-2, seed=0, prior_trace_bound=800.0, printlevel=0)
+if os.environ.get("PROBE_FAMILY") == "lovasz":      # Lovász-θ on G1–G9 (multi-launch edge path; shared launches per group)
+    datas = [problems.lovasz_theta_data(g) for g in graphs[:9]]
+    kw["prior_trace_bound"] = 1.0
 batch.solve_lockstep(datas[:4], 10, **kw)
-for rep in range(2):
+for rep in range(1 if os.environ.get('PROBE_FAMILY') else 2):
     laps = {"setup": 0.0, "calls": 0.0, "python": 0.0}
     t00 = time.perf_counter()
     cfgs = []
@@ -61,7 +64,8 @@ for rep in range(2):
         t2 = time.perf_counter()
         laps["calls"] += t1 - t0
         laps["python"] += t2 - t1
-        rounds.append((kinds, round(1e3 * (t1 - t0), 2), round(1e3 * (t2 - t1), 2)))
+        its = [r[4] for q, r in zip(reqs, resp) if q[0] == "major_iteration" and not isinstance(r, Exception)]
+        rounds.append((kinds, round(1e3 * (t1 - t0), 2), round(1e3 * (t2 - t1), 2), (max(its), sum(its)) if its else ()))
     t0 = time.perf_counter()
     for v in solvers:
         v.close()

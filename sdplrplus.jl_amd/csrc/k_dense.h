@@ -315,10 +315,7 @@ __device__ inline void seam_serial_small(SeamLds& gd, int jfixed, int fin_mode, 
 // The control block is staged through LDS whole (one coalesced load while the partials are being summed,
 // one coalesced store at the end): the serial part then runs on LDS latencies, not on a dozen dependent
 // global round trips.
-__global__ void __launch_bounds__(1024)
-k_lbfgs_boundary(DevCtrl* __restrict__ c, int h, int jfixed, int fin_mode, int do_loop, int do_coeff,
-                 int nb_partials, const double* __restrict__ partials, int desc_mode, double* __restrict__ pv_raw = nullptr,
-                 int m = 0) {
+__device__ __forceinline__ void lbfgs_boundary_body(DevCtrl* __restrict__ c, int h, int jfixed, int fin_mode, int do_loop, int do_coeff, int nb_partials, const double* __restrict__ partials, int desc_mode, double* __restrict__ pv_raw, int m) {
   __shared__ SeamLds gd;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
 #ifdef SDPLR_STAMPS
@@ -417,6 +414,12 @@ k_lbfgs_boundary(DevCtrl* __restrict__ c, int h, int jfixed, int fin_mode, int d
   }
 #endif
 }
+__global__ void __launch_bounds__(1024)
+k_lbfgs_boundary(DevCtrl* __restrict__ c, int h, int jfixed, int fin_mode, int do_loop, int do_coeff,
+                 int nb_partials, const double* __restrict__ partials, int desc_mode, double* __restrict__ pv_raw = nullptr,
+                 int m = 0) {
+  lbfgs_boundary_body(c, h, jfixed, fin_mode, do_loop, do_coeff, nb_partials, partials, desc_mode, pv_raw, m);
+}
 
 // ---- direction: dir = ∓(G − Σ α_l y_l + Σ γ_l s_l); y_next = −G; partial ⟨dir, G⟩ -----------------
 // src/lbfgs.jl:84 (copy), :94-113 (as one combination), :116-118 (negate), :121-123 (y_next = −grad),
@@ -425,10 +428,8 @@ k_lbfgs_boundary(DevCtrl* __restrict__ c, int h, int jfixed, int fin_mode, int d
 // 256 MiB Infinity Cache, so that the once-per-kernel history streams do not evict the direction the gather kernel is about
 // to re-read (north-star instance, 333 MB: +4 %); a working set that FITS the cache (Lovász-θ stand-in, 140 MB) is served
 // from it on every pass, and there the hint only loses that (−2.3 %): plain loads.
-template <int HM, bool NTH = true>
-__global__ void __launch_bounds__(SDPLR_NT)
-k_lbfgs_dir(const DevCtrl* __restrict__ c, FactorArena A, long long N, int h, int negate,
-            int check_done, double* __restrict__ partials, int inline_fallback) {
+template <int HM, bool NTH>
+__device__ __forceinline__ void lbfgs_dir_body(const DevCtrl* __restrict__ c, FactorArena A, long long N, int h, int negate, int check_done, double* __restrict__ partials, int inline_fallback) {
   __shared__ double sh[8];
   const int dn = check_done ? c->done : 0;  // fetched with the coefficients, tested before the first pass
   double* G = aslot(A, AS_G);
@@ -536,6 +537,12 @@ k_lbfgs_dir(const DevCtrl* __restrict__ c, FactorArena A, long long N, int h, in
   if (inline_fallback) return;  // no consumer for the partials: ⟨dir, G⟩ came from the seam kernel
   desc = block_sum1(desc, sh);
   if (threadIdx.x == 0) slot_partials(partials, SLOT_DESCENT)[blockIdx.x] = desc;
+}
+template <int HM, bool NTH = true>
+__global__ void __launch_bounds__(SDPLR_NT)
+k_lbfgs_dir(const DevCtrl* __restrict__ c, FactorArena A, long long N, int h, int negate,
+            int check_done, double* __restrict__ partials, int inline_fallback) {
+  lbfgs_dir_body<HM, NTH>(c, A, N, h, negate, check_done, partials, inline_fallback);
 }
 
 // descent = Σ partials (src/sdplr.jl:201); with `apply`, the steepest-descent fallback of

@@ -449,16 +449,7 @@ k_lz_update2(DevCtrl* __restrict__ c, int n, int step, double* __restrict__ Av, 
 #define SDPLR_LSF_LRW 512     /* doubles of low-rank projections staged in LDS (2·ST·r) */
 #define SDPLR_LSF_LRN 16      /* low-rank matrices whose line-search values are kept in LDS */
 struct ExtraHead { int k[4]; };   // the first extra slots by value: their data is requested without waiting for the index list
-__global__ void __launch_bounds__(SDPLR_LSF_NT)
-k_ls_solve_fast(DevCtrl* __restrict__ c, int m, int gid_g, int n_extra, const int* __restrict__ extra,
-                int nb, double* __restrict__ A_RD, double* __restrict__ A_DD,
-                const double* __restrict__ lam, const double* __restrict__ lam_ub,
-                double* __restrict__ pv_raw, const double* __restrict__ lb, double* __restrict__ pv,
-                double* __restrict__ y, int lr_ST, int r, const int* __restrict__ lr_col_gid,
-                const double* __restrict__ lr_D, double* __restrict__ lrW, double* __restrict__ lrWS,
-                const double* __restrict__ partials, int check_done,
-                int lr_tail, int lr_n, const int* __restrict__ lr_mat_ptr, const int* __restrict__ lr_mat_gid,
-                const double* __restrict__ red2, ExtraHead eh) {
+__device__ __forceinline__ void ls_solve_fast_body(DevCtrl* __restrict__ c, int m, int gid_g, int n_extra, const int* __restrict__ extra, int nb, double* __restrict__ A_RD, double* __restrict__ A_DD, const double* __restrict__ lam, const double* __restrict__ lam_ub, double* __restrict__ pv_raw, const double* __restrict__ lb, double* __restrict__ pv, double* __restrict__ y, int lr_ST, int r, const int* __restrict__ lr_col_gid, const double* __restrict__ lr_D, double* __restrict__ lrW, double* __restrict__ lrWS, const double* __restrict__ partials, int check_done, int lr_tail, int lr_n, const int* __restrict__ lr_mat_ptr, const int* __restrict__ lr_mat_gid, const double* __restrict__ red2, ExtraHead eh) {
   __shared__ double sh[10 * (SDPLR_LSF_NT / 64)];
 #ifdef SDPLR_STAMPS
   const unsigned long long st0 = __builtin_amdgcn_s_memtime();
@@ -764,4 +755,16 @@ k_ls_solve_fast(DevCtrl* __restrict__ c, int m, int gid_g, int n_extra, const in
     lrW[t] = w;
     lrWS[t] = yc * dc * w;
   }
+}
+__global__ void __launch_bounds__(SDPLR_LSF_NT)
+k_ls_solve_fast(DevCtrl* __restrict__ c, int m, int gid_g, int n_extra, const int* __restrict__ extra,
+                int nb, double* __restrict__ A_RD, double* __restrict__ A_DD,
+                const double* __restrict__ lam, const double* __restrict__ lam_ub,
+                double* __restrict__ pv_raw, const double* __restrict__ lb, double* __restrict__ pv,
+                double* __restrict__ y, int lr_ST, int r, const int* __restrict__ lr_col_gid,
+                const double* __restrict__ lr_D, double* __restrict__ lrW, double* __restrict__ lrWS,
+                const double* __restrict__ partials, int check_done,
+                int lr_tail, int lr_n, const int* __restrict__ lr_mat_ptr, const int* __restrict__ lr_mat_gid,
+                const double* __restrict__ red2, ExtraHead eh) {
+  ls_solve_fast_body(c, m, gid_g, n_extra, extra, nb, A_RD, A_DD, lam, lam_ub, pv_raw, lb, pv, y, lr_ST, r, lr_col_gid, lr_D, lrW, lrWS, partials, check_done, lr_tail, lr_n, lr_mat_ptr, lr_mat_gid, red2, eh);
 }

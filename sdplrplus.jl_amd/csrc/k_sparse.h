@@ -1844,11 +1844,8 @@ k_spmm_both(DevSparse sp, const double* __restrict__ X, double* __restrict__ Y, 
 // G = 2·R·S of the in-loop g! with lbfgs_update! riding along (see upd_row): hub blocks first, then short rows;
 // every block contributes one entry to each Gram partial slot (hub block b → b, short block b → nb_long + b)
 // EDGE: S is not read from its assembled array — entry p is s_one[p]·y[s_gid[p]] (see DevSparse, "edge path")
-template <int LPR, int VEC, int HMU, bool EDGE = false>
-__global__ void __launch_bounds__(SDPLR_NT)
-k_spmm_both_upd(DevSparse sp, const double* __restrict__ X, double* Y, int r, double scale, DevLowRank lr,
-                const double* __restrict__ WS, int slot, double* __restrict__ partials, DevCtrl* __restrict__ c,
-                int nb_long, FactorArena A, int h, const double* __restrict__ D, const double* __restrict__ yv = nullptr) {
+template <int LPR, int VEC, int HMU, bool EDGE>
+__device__ __forceinline__ void spmm_both_upd_body(DevSparse sp, const double* __restrict__ X, double* Y, int r, double scale, DevLowRank lr, const double* __restrict__ WS, int slot, double* __restrict__ partials, DevCtrl* __restrict__ c, int nb_long, FactorArena A, int h, const double* __restrict__ D, const double* __restrict__ yv) {
   extern __shared__ double upd_accl[];
   if (c->done) return;
   const UpdCtx u = upd_ctx<HMU>(c, A, h, D, upd_accl);
@@ -1858,6 +1855,13 @@ k_spmm_both_upd(DevSparse sp, const double* __restrict__ X, double* Y, int r, do
   else
     spmm_rows<LPR, VEC, HMU, EDGE>(sp, X, Y, r, scale, lr, WS, slot, partials, c, 0, nullptr, blockIdx.x - nb_long, nb_short, &u, yv);
   upd_flush<HMU>(u, c, partials, blockIdx.x, blockIdx.x == 0);
+}
+template <int LPR, int VEC, int HMU, bool EDGE = false>
+__global__ void __launch_bounds__(SDPLR_NT)
+k_spmm_both_upd(DevSparse sp, const double* __restrict__ X, double* Y, int r, double scale, DevLowRank lr,
+                const double* __restrict__ WS, int slot, double* __restrict__ partials, DevCtrl* __restrict__ c,
+                int nb_long, FactorArena A, int h, const double* __restrict__ D, const double* __restrict__ yv = nullptr) {
+  spmm_both_upd_body<LPR, VEC, HMU, EDGE>(sp, X, Y, r, scale, lr, WS, slot, partials, c, nb_long, A, h, D, yv);
 }
 
 // hub rows of the SpMV: one block per row, 256 lanes stride the row
@@ -2064,10 +2068,7 @@ k_lz_step(int n, DevCtrl* __restrict__ c, const double* __restrict__ uprev, cons
 #define SDPLR_EDGE_POS 2   /* pattern positions per sub-wave group and trip (1 and 2 equal, 4: 196 VGPRs, slower) */
 #endif
 template <int LPR, int VEC, int LRN>
-__global__ void __launch_bounds__(SDPLR_NT)
-k_sddmm_edge(DevSparse sp, int m, const double* __restrict__ U, const double* __restrict__ V, int r,
-             double* __restrict__ A_RD, double* __restrict__ A_DD, DevLowRank lr, double* __restrict__ lr_part,
-             double* __restrict__ partials, const DevCtrl* __restrict__ c) {
+__device__ __forceinline__ void sddmm_edge_body(DevSparse sp, int m, const double* __restrict__ U, const double* __restrict__ V, int r, double* __restrict__ A_RD, double* __restrict__ A_DD, DevLowRank lr, double* __restrict__ lr_part, double* __restrict__ partials, const DevCtrl* __restrict__ c) {
   __shared__ double sh[2 * (SDPLR_NT / 64)];
   __shared__ double lrs[LRN > 0 ? 2 * SDPLR_NT * VEC : 1];
   if (c->done) return;
@@ -2176,6 +2177,13 @@ k_sddmm_edge(DevSparse sp, int m, const double* __restrict__ U, const double* __
     slot_partials(partials, SLOT_DW)[blockIdx.x] = acc[1];
   }
 }
+template <int LPR, int VEC, int LRN>
+__global__ void __launch_bounds__(SDPLR_NT)
+k_sddmm_edge(DevSparse sp, int m, const double* __restrict__ U, const double* __restrict__ V, int r,
+             double* __restrict__ A_RD, double* __restrict__ A_DD, DevLowRank lr, double* __restrict__ lr_part,
+             double* __restrict__ partials, const DevCtrl* __restrict__ c) {
+  sddmm_edge_body<LPR, VEC, LRN>(sp, m, U, V, r, A_RD, A_DD, lr, lr_part, partials, c);
+}
 
 // Everything between k_sddmm_edge and the scalar stage that is a sum, in one grid:
 //   blocks [0, nout):            projection sums W[t] = Σ_blocks lr_part[t][·]                 (as k_lr_reduce)
@@ -2183,11 +2191,7 @@ k_sddmm_edge(DevSparse sp, int m, const double* __restrict__ U, const double* __
 //   the rest (nb_c blocks):      the eight line-search sums (src/linesearch.jl:36-56) over the constraints the
 //                                scalar stage does not take itself — λ, primal_vio_raw, A_RD, A_DD read coalesced —
 //                                as block partials in SLOT_LS + 0..7
-__global__ void __launch_bounds__(SDPLR_NT)
-k_edge_sums(int nout, int nb, const double* __restrict__ lr_part, double* __restrict__ W, double* __restrict__ red2,
-            int nb_c, int m, int n_extra, const int* __restrict__ extra, const double* __restrict__ lam,
-            const double* __restrict__ pv_raw, const double* __restrict__ A_RD, const double* __restrict__ A_DD,
-            double* __restrict__ partials, const DevCtrl* __restrict__ c) {
+__device__ __forceinline__ void edge_sums_body(int nout, int nb, const double* __restrict__ lr_part, double* __restrict__ W, double* __restrict__ red2, int nb_c, int m, int n_extra, const int* __restrict__ extra, const double* __restrict__ lam, const double* __restrict__ pv_raw, const double* __restrict__ A_RD, const double* __restrict__ A_DD, double* __restrict__ partials, const DevCtrl* __restrict__ c) {
   __shared__ double sh[8 * (SDPLR_NT / 64)];
   const int dn = c->done;
   const int t = blockIdx.x;
@@ -2231,6 +2235,13 @@ k_edge_sums(int nout, int nb, const double* __restrict__ lr_part, double* __rest
     for (int k = 0; k < 8; k++) slot_partials(partials, SLOT_LS + k)[bc] = s[k];
   }
 }
+__global__ void __launch_bounds__(SDPLR_NT)
+k_edge_sums(int nout, int nb, const double* __restrict__ lr_part, double* __restrict__ W, double* __restrict__ red2,
+            int nb_c, int m, int n_extra, const int* __restrict__ extra, const double* __restrict__ lam,
+            const double* __restrict__ pv_raw, const double* __restrict__ A_RD, const double* __restrict__ A_DD,
+            double* __restrict__ partials, const DevCtrl* __restrict__ c) {
+  edge_sums_body(nout, nb, lr_part, W, red2, nb_c, m, n_extra, extra, lam, pv_raw, A_RD, A_DD, partials, c);
+}
 
 // The two independent jobs between the scalar stage and the SpMM of g!, in one grid:
 //   blocks [0, nb_ax):   R += α·dirt                                                          (src/sdplr.jl:219)
@@ -2240,12 +2251,7 @@ k_edge_sums(int nout, int nb, const double* __restrict__ lr_part, double* __rest
 //                        OWNER: the thread that forms y_k stores y_k·nzval_one into the ≤ 2 entries of S that
 //                        matrix k owns (src/coreop.jl:205-227 without the scatter-add or the map)
 //   the rest:            the entries of S the multi-entry matrix owns (its y comes from the scalar stage)
-__global__ void __launch_bounds__(SDPLR_NT)
-k_edge_step(DevSparse sp, DevCtrl* __restrict__ c, double* __restrict__ R, const double* __restrict__ D, long long N, int nb_ax, int nb_c,
-            int m, int n_extra, const int* __restrict__ extra, double* __restrict__ pv_raw,
-            const double* __restrict__ A_RD, const double* __restrict__ A_DD, const double* __restrict__ lb,
-            double* __restrict__ pv, double* __restrict__ y, const double* __restrict__ lam,
-            const double* __restrict__ lam_ub, double* __restrict__ partials, int nb_gnorm) {
+__device__ __forceinline__ void edge_step_body(DevSparse sp, DevCtrl* __restrict__ c, double* __restrict__ R, const double* __restrict__ D, long long N, int nb_ax, int nb_c, int m, int n_extra, const int* __restrict__ extra, double* __restrict__ pv_raw, const double* __restrict__ A_RD, const double* __restrict__ A_DD, const double* __restrict__ lb, double* __restrict__ pv, double* __restrict__ y, const double* __restrict__ lam, const double* __restrict__ lam_ub, double* __restrict__ partials, int nb_gnorm) {
   __shared__ double sh[8];
   if (c->done) return;
   const double a = c->alpha, sigma = c->sigma;
@@ -2302,6 +2308,14 @@ k_edge_step(DevSparse sp, DevCtrl* __restrict__ c, double* __restrict__ R, const
       c->nb_gnorm = nb_gnorm;
     }
   }
+}
+__global__ void __launch_bounds__(SDPLR_NT)
+k_edge_step(DevSparse sp, DevCtrl* __restrict__ c, double* __restrict__ R, const double* __restrict__ D, long long N, int nb_ax, int nb_c,
+            int m, int n_extra, const int* __restrict__ extra, double* __restrict__ pv_raw,
+            const double* __restrict__ A_RD, const double* __restrict__ A_DD, const double* __restrict__ lb,
+            double* __restrict__ pv, double* __restrict__ y, const double* __restrict__ lam,
+            const double* __restrict__ lam_ub, double* __restrict__ partials, int nb_gnorm) {
+  edge_step_body(sp, c, R, D, N, nb_ax, nb_c, m, n_extra, extra, pv_raw, A_RD, A_DD, lb, pv, y, lam, lam_ub, partials, nb_gnorm);
 }
 
 // ================================================================================================

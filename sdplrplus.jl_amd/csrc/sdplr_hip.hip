@@ -30,6 +30,7 @@
 #include "k_sparse.h"
 #include "k_eig.h"
 #include "k_resident.h"
+#include "k_group.h"
 
 namespace {
 
@@ -219,7 +220,7 @@ struct sdplr_hip_solver {
   double* scratchV = nullptr;
   // counters (sdplr_hip_get_stats)
   int64_t st_captures = 0, st_capture_failed = 0, st_capture_skipped = 0, st_graph_batches = 0,
-          st_eager_batches = 0, st_lz_graph = 0, st_lz_eager = 0, st_iters = 0, st_rs_loops = 0, st_rs_lz = 0, st_rs_fg = 0, st_rs_shared = 0, st_pdrop = 0;
+          st_eager_batches = 0, st_lz_graph = 0, st_lz_eager = 0, st_iters = 0, st_rs_loops = 0, st_rs_lz = 0, st_rs_fg = 0, st_rs_shared = 0, st_pdrop = 0, st_grp_loops = 0;
 
   // profiling
   bool prof_on = false;
@@ -3228,10 +3229,10 @@ int32_t sdplr_hip_At_right_device(S* s, const double* x, double* yd, int64_t k) 
 
 int32_t sdplr_hip_get_stats(const S* s, int64_t* out, int32_t cap, int32_t* n_written) {
   if (!s || !out || cap < 0) return SDPLR_ERR_INVALID_ARG;
-  const int64_t v[13] = {s->st_captures, s->st_capture_failed, s->st_capture_skipped, s->st_graph_batches,
+  const int64_t v[14] = {s->st_captures, s->st_capture_failed, s->st_capture_skipped, s->st_graph_batches,
                          s->st_eager_batches, s->st_lz_graph, s->st_lz_eager, s->st_iters, s->st_rs_loops, s->st_rs_lz, s->st_rs_fg,
-                         s->st_rs_shared, s->st_pdrop};
-  const int32_t k = std::min<int32_t>(cap, 13);
+                         s->st_rs_shared, s->st_pdrop, s->st_grp_loops};
+  const int32_t k = std::min<int32_t>(cap, 14);
   for (int32_t i = 0; i < k; i++) out[i] = v[i];
   if (n_written) *n_written = k;
   return SDPLR_OK;
@@ -4146,6 +4147,181 @@ void run_singles(const std::vector<int>& idx, F&& one) {
     });
   for (auto& x : th) x.join();
 }
+
+// ---- a group of edge-path instances behind shared launches (k_group.h) ------------------------------------------------
+// What the group shares: every launch dimension and template argument of the seven kernels of enq_iteration_edge.
+bool edge_group_applies(const S* s, const sdplr_hip_major_item& q) {
+  const bool off = getenv("SDPLR_HIP_NO_GROUP_LAUNCH") != nullptr;
+  if (off || !s || !s->finalized || s->fast || s->lit || s->prof_on || s->h < 1 || s->HM != 4) return false;
+  if (q.update_lambda == SDPLR_MAJOR_RESUME || q.max_local_iters < 1) return false;
+  if (!edge_applies(s, q.use_armijo) || rs_loop_applies(s, q.use_armijo) || !s->all_covered) return false;
+  return s->edge_lr_fused && s->r <= (int64_t)s->LPR * s->VEC;
+}
+std::vector<long long> edge_group_key(const S* s) {
+  const int nb_c = blocks_for(s->m + 1, SDPLR_NT, 1024);
+  const int nb_big = s->sp.n_big_pos > 0 ? blocks_for(s->sp.n_big_pos, SDPLR_NT, 256) : 0;
+  return {s->LPR, s->VEC, s->h, s->r, s->nb_dense, s->nb_edge, nb_c, nb_big, s->nb_spmm, std::min(s->sp.n_long_rows, 256), s->lr.ST};
+}
+struct GroupMember {
+  sdplr_hip_major_item* q;
+  int dirt_was_from;
+};
+// The inner while loops (src/sdplr.jl:190-278) of `mem` — ≥ 2 instances of one key, each with ℒ, ‖∇ℒ‖, ‖pv‖ of its fg! in
+// its item — as shared launches on the first member's stream.  Entry and exit per member are those of inner_loop_impl on
+// the edge path (control block in, pending Gram rows, closing seam, bookkeeping); the caller holds the shared API lock.
+int run_edge_group(std::vector<GroupMember>& mem) {
+  const int B = (int)mem.size();
+  S* s = mem[0].q->s;               // the leader: its stream carries the shared launches, its shape is everybody's
+  hipStream_t st = s->stream;
+  for (GroupMember& g : mem) {      // ---- entry, per member
+    sdplr_hip_major_item& q = *g.q;
+    S* sk = q.s;
+    const bool hc_was_valid = sk->hc_valid;
+    g.dirt_was_from = sk->dirt_from;
+    sk->dirt_from = -1;             // (the direction kernel overwrites dirt: a pending dirt ← s_latest is dropped)
+    sk->hc_valid = false;
+    sk->G_consistent = false;
+    const bool gram_work = sk->gram_dirty || sk->ynext_pending || sk->sg_stale;
+    ensure_gram(sk);
+    sk->hc_valid = hc_was_valid && !gram_work;
+    int rc = pull_if_stale(sk);
+    if (rc) return rc;
+    sk->hc_valid = false;
+    DevCtrl* c = sk->hc;
+    c->done = 0; c->exit_reason = 0; c->err = 0; c->use_armijo = 0;
+    c->iters = 0; c->max_iters = q.max_local_iters; c->reldelta_exit = 0; c->norms_pending = 0; c->pv2_extra = 0.0;
+    c->cur_gtol = q.cur_gtol; c->fprec_eps = q.fprec_eps; c->normC = q.normC; c->normb = q.normb;
+    c->grel = q.gtol_relative; c->prel = q.ptol_relative;
+    c->L = q.lagrangian; c->gnorm = q.grad_norm; c->pvnorm = q.primal_vio_norm; c->alpha = 0.0; c->alpha_max = 1.0;
+    if ((rc = push(sk))) return rc;   // (waits: the shared launches run on another stream)
+    sk->S_stale = true; sk->S_from_y = true;
+  }
+  // ---- the argument tables: one row per member and kernel, one copy up
+  BatchBuf bb;
+  hipEvent_t ev2 = nullptr;
+  if (bb.init() != hipSuccess || pool_event(&ev2) != hipSuccess) return fail(s, SDPLR_ERR_ALLOC, "batch_major_iteration: staging blocks");
+  struct EvFree { hipEvent_t e; ~EvFree() { if (e) pool_event_free(e); } } ev2_free{ev2};
+  size_t off = 0;
+  auto region = [&](size_t bytes) { const size_t o = off; off += batch_up(bytes); return o; };
+  const size_t o_seam = region(B * sizeof(GrpSeamArgs)), o_dir = region(B * sizeof(GrpDirArgs)), o_sd = region(B * sizeof(GrpSddmmArgs)),
+               o_sum = region(B * sizeof(GrpSumsArgs)), o_ls = region(B * sizeof(GrpLsArgs)), o_step = region(B * sizeof(GrpStepArgs)),
+               o_sp = region(B * sizeof(GrpSpmmArgs)), o_ctrl = region(B * sizeof(DevCtrl*));
+  const size_t table_bytes = off;
+  const size_t o_poll = region(2 * B * sizeof(int));
+  if (off > ARENA_CHUNK) return fail(s, SDPLR_ERR_INVALID_ARG, "batch_major_iteration: group too large for one staging block");
+  const int nb_c = blocks_for(s->m + 1, SDPLR_NT, 1024);
+  const int nb_big = s->sp.n_big_pos > 0 ? blocks_for(s->sp.n_big_pos, SDPLR_NT, 256) : 0;
+  const int nbl = std::min(s->sp.n_long_rows, 256);
+  const int nout = 2 * s->lr.ST * (int)s->r;
+  for (int b = 0; b < B; b++) {
+    S* k = mem[b].q->s;
+    double *R = aslot(k->arena, AS_R), *G = aslot(k->arena, AS_G), *D = aslot(k->arena, AS_D);
+    GrpSeamArgs& a0 = reinterpret_cast<GrpSeamArgs*>(bb.host + o_seam)[b];
+    a0 = GrpSeamArgs{k->ctrl, (int)k->h, 0, 1, 1, 1, spmm_upd_blocks(k), k->partials, 1, (int)k->m, k->pv_raw};
+    GrpDirArgs& a1 = reinterpret_cast<GrpDirArgs*>(bb.host + o_dir)[b];
+    a1 = GrpDirArgs{k->ctrl, k->arena, k->N, (int)k->h, 1, 1, 2, k->partials};
+    GrpSddmmArgs& a2 = reinterpret_cast<GrpSddmmArgs*>(bb.host + o_sd)[b];
+    a2 = GrpSddmmArgs{k->sp, k->lr, (int)k->m, (int)k->r, R, D, k->A_RD, k->A_DD, k->lr_part, k->partials, k->ctrl};
+    GrpSumsArgs& a3 = reinterpret_cast<GrpSumsArgs*>(bb.host + o_sum)[b];
+    a3 = GrpSumsArgs{nout, k->nb_edge, nb_c, (int)k->m, k->n_edge_extra, k->lr_part, k->lr_W, k->red10, k->edge_extra,
+                     k->lambda, k->pv_raw, k->A_RD, k->A_DD, k->partials, k->ctrl};
+    GrpLsArgs& a4 = reinterpret_cast<GrpLsArgs*>(bb.host + o_ls)[b];
+    a4 = GrpLsArgs{k->ctrl, (int)k->m, k->sp.big_gid, k->n_edge_extra, nb_c, k->lr.ST, (int)k->r, 1, 1, k->lr.n_lr, k->edge_extra,
+                   k->A_RD, k->A_DD, k->lambda, k->lambda_ub, k->pv_raw, k->pv_lb, k->pv, k->y, k->lr.col_gid, k->lr.Dcat, k->lr_W,
+                   k->lr_WS, k->partials, k->lr.mat_ptr, k->lr.mat_gid, k->red10, k->edge_extra_head};
+    GrpStepArgs& a5 = reinterpret_cast<GrpStepArgs*>(bb.host + o_step)[b];
+    a5 = GrpStepArgs{k->sp, k->ctrl, R, D, k->N, k->nb_dense, nb_c, (int)k->m, k->n_edge_extra, k->nb_spmm + nbl, k->edge_extra,
+                     k->pv_raw, k->A_RD, k->A_DD, k->pv_lb, k->pv, k->y, k->lambda, k->lambda_ub, k->partials};
+    GrpSpmmArgs& a6 = reinterpret_cast<GrpSpmmArgs*>(bb.host + o_sp)[b];
+    a6 = GrpSpmmArgs{k->sp, k->lr, k->arena, R, G, (int)k->r, SLOT_GNORM2, nbl, (int)k->h, 2.0, k->lr_WS, k->partials, k->ctrl, D};
+    reinterpret_cast<DevCtrl**>(bb.host + o_ctrl)[b] = k->ctrl;
+    k->gram_nb = spmm_upd_blocks(k);
+  }
+  HIPCK(s, hipMemcpyAsync(bb.dev, bb.host, table_bytes, hipMemcpyHostToDevice, st));
+  const dim3 g1(1, B), g_dir(s->nb_dense, B), g_sd(s->nb_edge, B), g_sum(nout + 2 + nb_c, B), g_step(s->nb_dense + nb_c + nb_big, B),
+      g_sp(s->nb_spmm + nbl, B);
+  auto enq_iter = [&]() {
+    k_grp_boundary<<<g1, 1024, 0, st>>>(reinterpret_cast<const GrpSeamArgs*>(bb.dev + o_seam));
+    k_grp_dir<4><<<g_dir, SDPLR_NT, 0, st>>>(reinterpret_cast<const GrpDirArgs*>(bb.dev + o_dir));
+    LV_DISPATCH((k_grp_sddmm_edge<LPR, VEC, 1><<<g_sd, SDPLR_NT, 0, st>>>(reinterpret_cast<const GrpSddmmArgs*>(bb.dev + o_sd))))
+    k_grp_edge_sums<<<g_sum, SDPLR_NT, 0, st>>>(reinterpret_cast<const GrpSumsArgs*>(bb.dev + o_sum));
+    k_grp_ls_solve_fast<<<g1, SDPLR_LSF_NT, 0, st>>>(reinterpret_cast<const GrpLsArgs*>(bb.dev + o_ls));
+    k_grp_edge_step<<<g_step, SDPLR_NT, 0, st>>>(reinterpret_cast<const GrpStepArgs*>(bb.dev + o_step));
+    LV_DISPATCH((k_grp_spmm_both_upd<LPR, VEC><<<g_sp, SDPLR_NT, 5 * 4 * SDPLR_NT * sizeof(double), st>>>(reinterpret_cast<const GrpSpmmArgs*>(bb.dev + o_sp))))
+  };
+  hipEvent_t ev[2] = {bb.ev, ev2};
+  const bool dbg = getenv("SDPLR_HIP_DEBUG") != nullptr;
+  double t_enq = 0.0, t_wait = 0.0;
+  int n_batches = 0;
+  auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  auto launch_batch = [&](int slot) -> int {
+    const double ta = now();
+    n_batches++;
+    for (int i = 0; i < 8; i++) enq_iter();
+    int* dpoll = reinterpret_cast<int*>(bb.dev + o_poll) + slot * B;
+    k_grp_poll<<<1, 64, 0, st>>>(reinterpret_cast<const DevCtrl* const*>(bb.dev + o_ctrl), B, dpoll);
+    HIPCK(s, hipGetLastError());
+    HIPCK(s, hipMemcpyAsync(bb.host + o_poll + slot * B * sizeof(int), dpoll, B * sizeof(int), hipMemcpyDeviceToHost, st));
+    HIPCK(s, hipEventRecord(ev[slot], st));
+    t_enq += now() - ta;
+    return SDPLR_OK;
+  };
+  // (the device decides every exit — the iteration budget too, at the seam — except the time budget: the smallest one given
+  // stops the group, and whoever is still running leaves with EXIT_TIME as on the single-instance route)
+  double budget = 0.0;
+  for (GroupMember& g : mem) if (g.q->time_budget_s > 0) budget = budget > 0 ? std::min(budget, g.q->time_budget_s) : g.q->time_budget_s;
+  const auto t0 = std::chrono::steady_clock::now();
+  bool timed_out = false;
+  int rc, cur = 0;
+  if ((rc = launch_batch(cur))) return rc;
+  for (;;) {
+    if ((rc = launch_batch(cur ^ 1))) return rc;   // speculative: queued behind batch `cur`
+    const double tw = now();
+    HIPCK(s, hipEventSynchronize(ev[cur]));
+    t_wait += now() - tw;
+    const int* dn = reinterpret_cast<const int*>(bb.host + o_poll) + cur * B;
+    bool all = true;
+    for (int b = 0; b < B; b++) all = all && dn[b] != 0;
+    if (all) break;
+    if (budget > 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > budget) { timed_out = true; break; }
+    cur ^= 1;
+  }
+  HIPCK(s, hipStreamSynchronize(st));
+  if (dbg)
+    fprintf(stderr, "[sdplr_hip] edge group of %d: %d batches of 8 iterations, host enqueue %.3f ms, host wait %.3f ms, wall %.3f ms\n", B,
+            n_batches, 1e3 * t_enq, 1e3 * t_wait, 1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+  int first_rc = SDPLR_OK;
+  for (GroupMember& g : mem) {      // ---- exit, per member
+    sdplr_hip_major_item& q = *g.q;
+    S* sk = q.s;
+    sk->gram_nb = spmm_upd_blocks(sk);
+    sk->S_stale = true; sk->S_from_y = true;
+    enq_boundary(sk, 0, 1, 0, 0);
+    if ((rc = pull(sk))) { q.status = rc; if (!first_rc) first_rc = rc; continue; }
+    DevCtrl* c = sk->hc;
+    int why = c->done ? c->exit_reason : (timed_out ? EXIT_TIME : -1);
+    if (c->iters > 0 && c->err == 0 && why != EXIT_RELDELTA) sk->dirt_from = c->latest - 1;
+    else if (c->iters == 0) sk->dirt_from = g.dirt_was_from;
+    sk->sg_stale = (why == EXIT_RELDELTA);
+    sk->ynext_pending = (why == EXIT_RELDELTA) && sk->h > 0;
+    if (c->err == SDPLR_ERR_NOT_DESCENT) {
+      c->err = 0; c->done = 0;
+      (void)push(sk);
+      q.status = fail(sk, SDPLR_ERR_NOT_DESCENT, "Error: cubic[1] should be less than 0.");
+      if (!first_rc) first_rc = q.status;
+      continue;
+    }
+    sk->st_iters += c->iters;
+    sk->P_age += c->iters;
+    sk->G_age = 0;
+    sk->G_consistent = true;
+    sk->st_grp_loops++;
+    q.lagrangian = c->L; q.grad_norm = c->gnorm; q.primal_vio_norm = c->pvnorm; q.last_alpha = c->alpha; q.obj = c->obj;
+    q.iters_done = c->iters; q.exit_reason = why;
+    q.status = SDPLR_OK;
+  }
+  return first_rc;
+}
 }  // namespace
 
 extern "C" {
@@ -4226,6 +4402,8 @@ int32_t sdplr_hip_batch_fg(int32_t count, sdplr_hip_fg_item* it) {
 int32_t sdplr_hip_batch_major_iteration(int32_t count, sdplr_hip_major_item* it) {
   if (count < 0 || (count > 0 && !it)) return fail(nullptr, SDPLR_ERR_INVALID_ARG, "batch_major_iteration: bad args");
   std::vector<int> single;
+  std::map<std::vector<long long>, std::vector<int>> egroups;   // edge-path instances that can share their launches (k_group.h)
+  int dev = -1;
   // an item keeps SDPLR_ERR_UNSERVED until it has actually been served: a call that returns early (argument checks, staging
   // blocks) must not leave OK beside zeroed outputs
   for (int i = 0; i < count; i++) it[i].status = SDPLR_ERR_UNSERVED;
@@ -4233,7 +4411,6 @@ int32_t sdplr_hip_batch_major_iteration(int32_t count, sdplr_hip_major_item* it)
     std::vector<const S*> hs;
     for (int i = 0; i < count; i++) hs.push_back(it[i].s);
     if (!batch_handles_distinct(hs)) return fail(nullptr, SDPLR_ERR_INVALID_ARG, "batch_major_iteration: a handle appears twice");   // (before any handle is dereferenced)
-    int dev = -1;
     if (!batch_one_device(hs, &dev)) return fail(nullptr, SDPLR_ERR_INVALID_ARG, "batch_major_iteration: the handles live on different devices");
     ApiShared api_guard(dev);
     std::map<ShapeKey, std::vector<int>> groups;
@@ -4250,9 +4427,12 @@ int32_t sdplr_hip_batch_major_iteration(int32_t count, sdplr_hip_major_item* it)
         groups[{pd ? 1 : 0, rs_vec(s)}].push_back(i);
       } else {
         if (s) s->G_consistent = was_consistent;   // (the single-instance entry point looks at it itself)
-        single.push_back(i);
+        if (edge_group_applies(s, it[i])) egroups[edge_group_key(s)].push_back(i);
+        else single.push_back(i);
       }
     }
+    for (auto& g : egroups)
+      if (g.second.size() < 2) { single.insert(single.end(), g.second.begin(), g.second.end()); g.second.clear(); }
     const size_t max_rows = ARENA_CHUNK / (batch_up(sizeof(RsLoopArgs)) + 128);
     for (auto& g : groups) {
       std::vector<int>& idx = g.second;
@@ -4326,6 +4506,40 @@ int32_t sdplr_hip_batch_major_iteration(int32_t count, sdplr_hip_major_item* it)
           q.iters_done = iters; q.exit_reason = why;
         }
       }
+    }
+  }
+  // edge-path groups: [λ update] → σ → lbfgs_clear! → fg! per instance through the single-instance entry points (a dozen launches
+  // each, once per major iteration), then the while loops of those that enter it (src/sdplr.jl:190) as shared launches
+  for (auto& g : egroups) {
+    const std::vector<int>& idx = g.second;
+    if (idx.empty()) continue;
+    run_singles(idx, [&](int i) {
+      sdplr_hip_major_item& q = it[i];
+      int32_t rc = SDPLR_OK;
+      if (q.update_lambda) rc = sdplr_hip_update_lambda(q.s);
+      if (!rc) rc = sdplr_hip_set_scalar(q.s, SDPLR_S_SIGMA, q.sigma);
+      if (!rc) rc = sdplr_hip_lbfgs_clear(q.s);
+      if (!rc) rc = sdplr_hip_fg(q.s, q.normC, q.normb, q.gtol_relative, q.ptol_relative, &q.lagrangian, &q.grad_norm, &q.primal_vio_norm);
+      q.last_alpha = 0.0; q.iters_done = 0; q.exit_reason = EXIT_GTOL;
+      if (!rc) rc = sdplr_hip_get_scalar(q.s, SDPLR_S_OBJ, &q.obj);
+      q.status = rc ? rc : SDPLR_ERR_UNSERVED;
+    });
+    std::vector<GroupMember> live;
+    for (int i : idx) {
+      sdplr_hip_major_item& q = it[i];
+      if (q.status != SDPLR_ERR_UNSERVED) continue;               // (its prologue failed)
+      if (!(q.grad_norm > q.cur_gtol)) { q.status = SDPLR_OK; continue; }   // src/sdplr.jl:190: the loop is not entered
+      live.push_back(GroupMember{&q, -1});
+    }
+    if (live.size() >= 2) {
+      ApiShared api_guard(dev);
+      (void)run_edge_group(live);   // (the members' status carries the outcome)
+    } else if (live.size() == 1) {
+      sdplr_hip_major_item& q = *live[0].q;
+      q.status = sdplr_hip_inner_loop(q.s, q.normC, q.normb, q.gtol_relative, q.ptol_relative, q.use_armijo, q.cur_gtol, q.fprec_eps,
+                                      q.max_local_iters, q.time_budget_s, &q.lagrangian, &q.grad_norm, &q.primal_vio_norm, &q.last_alpha,
+                                      &q.iters_done, &q.exit_reason);
+      if (!q.status) q.status = sdplr_hip_get_scalar(q.s, SDPLR_S_OBJ, &q.obj);
     }
   }
   run_singles(single, [&](int i) {

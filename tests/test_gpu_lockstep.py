@@ -206,3 +206,55 @@ def test_batch_time_budget_and_iteration_budget(hip_abi):
     assert [r[4] for r in res] == [2, 30, 9] and [r[5] for r in res] == [2, 2, 2]
     for s in A:
         s.close()
+
+
+def test_edge_path_group_shares_its_launches_bit_for_bit(hip_abi):
+    """Lovász-θ instances (multi-launch edge path: too many constraints for the resident route) in one batch call: those of
+    one launch shape run their while loops behind SHARED launches (k_group.h: blockIdx.y ↔ instance, the single-instance
+    kernel bodies) — every output and the whole device state equal the single-instance calls bit for bit, with per-item
+    iteration budgets, through four rounds (λ update on / off), next to an instance of another route."""
+    specs = [("lovasz_theta", 1, 40), ("lovasz_theta", 2, 40), ("lovasz_theta", 3, 44), ("maxcut", 4, 30), ("lovasz_theta", 5, 38)]
+    datas = [make_data(f, s, n, 0.3)[0] for f, s, n in specs]
+    A = [make_solver(hip_abi, d, 6, seed=7)[0] for d in datas]
+    B = [make_solver(hip_abi, d, 6, seed=7)[0] for d in datas]
+    norms = [(d.normC(), float(np.linalg.norm(d.b))) for d in datas]
+    assert cabi.batch_fg(hip_abi, A, [(nc, nb, 1, 1) for nc, nb in norms]) == \
+        [s.fg(nc, nb, True, True) + (s.obj,) for s, (nc, nb) in zip(B, norms)]
+    for rnd, upd in enumerate((0, 1, 1, 0)):
+        sig = 2.0 * (rnd + 1)
+        args = [(nc, nb, 1, 1, 0, upd, sig, 1e-3, 1e-30, (7, 30, 12, 9, 50)[k] + rnd, 0.0) for k, (nc, nb) in enumerate(norms)]
+        ma = cabi.batch_major_iteration(hip_abi, A, args)
+        mb = [s.major_iteration(*a) + (s.obj,) for s, a in zip(B, args)]
+        assert ma == mb, rnd
+    for a, b in zip(A, B):
+        for name in ("Rt", "Gt", "dirt", "y", "λ", "primal_vio_raw"):
+            assert np.array_equal(getattr(a, name), getattr(b, name)), name
+        for j in range(4):
+            assert np.array_equal(a.get_factor(cabi.F_LBFGS_S + j), b.get_factor(cabi.F_LBFGS_S + j))
+            assert np.array_equal(a.get_factor(cabi.F_LBFGS_Y + j), b.get_factor(cabi.F_LBFGS_Y + j))
+        assert np.array_equal(a.get_vec(cabi.V_LBFGS_RHO), b.get_vec(cabi.V_LBFGS_RHO))
+        assert a.σ == b.σ and a.obj == b.obj
+    grouped = [s.stats()["group_launch_loops"] for s in A]
+    assert grouped[3] == 0 and sum(1 for g in grouped if g == 4) >= 2, grouped
+    assert all(s.stats()["group_launch_loops"] == 0 for s in B)
+    # the state the group left is a state the single calls continue from
+    for a, b, (nc, nb) in zip(A, B, norms):
+        assert a.inner_loop(nc, nb, True, True, False, 0.0, -1e300, 3, 0.0, *a.fg(nc, nb)) == \
+            b.inner_loop(nc, nb, True, True, False, 0.0, -1e300, 3, 0.0, *b.fg(nc, nb))
+        a.close()
+        b.close()
+
+
+def test_lockstep_solves_of_an_edge_path_group(hip_abi, monkeypatch):
+    """Whole Lovász-θ solves side by side (shared launches for the while loops) = the solves one by one, bit for bit; and
+    with the shared launches switched off."""
+    datas = [make_data("lovasz_theta", s, 36, 0.25)[0] for s in (1, 2, 3, 4)]
+    kw = dict(KW, prior_trace_bound=1.0, maxtime=60.0)   # (tr X = 1 is a constraint of this family)
+    one = [sj.sdplr(data=d, r=7, **kw) for d in datas]
+    many = batch.solve_lockstep(datas, 7, **kw)
+    for a, b in zip(one, many):
+        assert not isinstance(b, Exception), b
+        same(a, b)
+    monkeypatch.setenv("SDPLR_HIP_NO_GROUP_LAUNCH", "1")
+    for a, b in zip(one, batch.solve_lockstep(datas, 7, **kw)):
+        same(a, b)
