@@ -8,7 +8,7 @@ import numpy as np
 import sdplrplus_jl_amd as sj
 from sdplrplus_jl_amd import batch
 from helpers import make_data
-FAMS = ["maxcut", "maxcut", "maxcut", "minimum_bisection", "cutnorm", "ineq_0.05", "mu_conductance_0.1"]
+FAMS = ["maxcut", "maxcut", "lovasz_theta", "lovasz_theta", "lovasz_theta", "minimum_bisection", "cutnorm", "ineq_0.05", "mu_conductance_0.1"]
 rng = np.random.Generator(np.random.PCG64(int(sys.argv[1]) if len(sys.argv) > 1 else 0))
 G = int(sys.argv[2]) if len(sys.argv) > 2 else 12
 bad = total = 0

@@ -1271,8 +1271,12 @@ int32_t sdplr_hip_device_count(int32_t* count) {
 int32_t sdplr_hip_set_device(int32_t device) {
   ApiShared api_guard;
   if (have_device() <= 0) return fail(nullptr, SDPLR_ERR_NO_DEVICE, "no HIP device");
+  if (device < 0 || device >= have_device()) return fail(nullptr, SDPLR_ERR_INVALID_ARG, "set_device: no such device");
   hipError_t e = hipSetDevice(device);
-  if (e != hipSuccess) return fail(nullptr, SDPLR_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(e));
+  if (e != hipSuccess) {
+    (void)hipGetLastError();   // (the refusal must not surface as the next call's "last error")
+    return fail(nullptr, SDPLR_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(e));
+  }
   g_device.store(device, std::memory_order_relaxed);   // sticky: every later call without a handle, from any thread, binds to it
   return SDPLR_OK;
 }

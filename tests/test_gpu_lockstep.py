@@ -258,3 +258,35 @@ def test_lockstep_solves_of_an_edge_path_group(hip_abi, monkeypatch):
     monkeypatch.setenv("SDPLR_HIP_NO_GROUP_LAUNCH", "1")
     for a, b in zip(one, batch.solve_lockstep(datas, 7, **kw)):
         same(a, b)
+
+
+def test_handles_follow_the_device_set_for_the_process(hip_abi):
+    """`sdplr_hip_set_device` is sticky (a new host thread starts on device 0, hipSetDevice is per thread): handles created
+    and driven from fresh threads live on the device set once from the main thread, a device that does not exist is refused
+    and leaves the setting alone, and the pools give their cached blocks back on request."""
+    import threading
+    assert hip_abi.set_device(0) == cabi.OK
+    assert hip_abi.set_device(4096) != cabi.OK
+    data = make_data("maxcut", 1, 40, 0.3)[0]
+    nc, nb = data.normC(), float(np.linalg.norm(data.b))
+    ref = make_solver(hip_abi, data, 6, seed=7)[0]
+    want = ref.fg(nc, nb, True, True)
+    out = {}
+
+    def build():
+        out["s"] = make_solver(hip_abi, data, 6, seed=7)[0]
+
+    def drive():
+        out["fg"] = out["s"].fg(nc, nb, True, True)
+    for fn in (build, drive):
+        t = threading.Thread(target=fn)
+        t.start()
+        t.join()
+    assert out["fg"] == want
+    assert cabi.batch_fg(hip_abi, [ref, out["s"]], [(nc, nb, 1, 1)] * 2) == [want + (ref.obj,)] * 2
+    ref.close()
+    out["s"].close()
+    assert hip_abi.trim_pools() == cabi.OK
+    again = make_solver(hip_abi, data, 6, seed=7)[0]      # (the pools refill)
+    assert again.fg(nc, nb, True, True) == want
+    again.close()

@@ -146,3 +146,23 @@ def test_batch_calls_reject_a_handle_listed_twice(hip_abi):
     assert hip_abi.batch_fg(2, arr) == cabi.ERR_INVALID_ARG
     assert hip_abi.batch_fg(0, None) == cabi.OK
     assert hip_abi.batch_major_iteration(-1, None) == cabi.ERR_INVALID_ARG
+
+
+def test_a_refused_batch_call_leaves_no_item_looking_served(hip_abi):
+    """A batch call that returns before it has served its items (here: the duplicate-handle check) leaves every item at
+    ERR_UNSERVED — never OK beside zeroed outputs — and the Python wrapper raises on the call's own return code."""
+    for Item, fn in ((cabi.FgItem, hip_abi.batch_fg), (cabi.MajorItem, hip_abi.batch_major_iteration), (cabi.DualItem, hip_abi.batch_dual_obj)):
+        arr = (Item * 3)()
+        arr[0].s = arr[2].s = 12345
+        arr[1].s = 54321
+        for k in range(3):
+            arr[k].status = cabi.OK
+        assert fn(3, arr) == cabi.ERR_INVALID_ARG
+        assert [int(arr[k].status) for k in range(3)] == [cabi.ERR_UNSERVED] * 3
+
+    class Fake:
+        def __init__(self, h):
+            import ctypes
+            self._h = ctypes.c_void_p(h)
+    with pytest.raises(cabi.SdplrError):
+        cabi.batch_fg(hip_abi, [Fake(12345), Fake(12345)], [(1.0, 1.0, 1, 1)] * 2)
