@@ -2,8 +2,8 @@
 //
 // A small instance of this family (Gset G1: n = 800, 19 176 edge constraints, rank 10) cannot take the resident route — its
 // (m+1)-vectors alone are 5 × 150 KB — and on the multi-launch route its seven kernels per inner iteration each fill a few
-// CUs for 2–4 µs: the solve runs at the LAUNCH rate (≈ 2.9 µs per launch whatever the number of host threads or streams:
-// DESIGN.md §12), and a batch of such instances does not overlap.  Here the seven kernels of the while body
+// CUs for 5–15 µs: one stream per instance is a chain of small dependent launches, and a batch overlaps only as far as the
+// host threads of the batch call get their launches in.  Here the seven kernels of the while body
 // (src/sdplr.jl:190-278) are launched ONCE for the whole group, blockIdx.y ↔ instance: every kernel is the single-instance
 // body (k_dense.h / k_sparse.h / k_scalar.h, `*_body`) behind a wrapper that fetches its arguments from row blockIdx.y of
 // a table in device memory instead of the launch's argument block.  The instances keep their own control blocks, so each
