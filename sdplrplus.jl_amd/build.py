@@ -7,7 +7,7 @@ import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc", "sdplr_hip.hip")
-DEPS = [os.path.join(HERE, "csrc", f) for f in ("common.h", "k_dense.h", "k_sparse.h", "k_scalar.h", "k_eig.h", "k_resident.h")]
+DEPS = [os.path.join(HERE, "csrc", f) for f in ("common.h", "k_dense.h", "k_sparse.h", "k_scalar.h", "k_eig.h", "k_resident.h", "k_group.h")]
 DEPS.append(os.path.join(os.path.dirname(HERE), "include", "sdplr_hip.h"))
 OUT = os.path.join(HERE, "lib", "libsdplr_hip.so")
 
