@@ -104,6 +104,7 @@ struct RsEll {
   const double* val;      // same shape, or null: every off-diagonal entry has the value `one`
   double one;
   const double* gdiag;    // [n]
+  int sl0 = 0, sl_step = 1;   // the slices this workgroup takes: sl0, sl0 + sl_step, … (a team member: its rank, the team's size)
 };
 
 // NCH chunks (VEC doubles each, from chunk c0) of Y_j = Σ_k a_jk·X_k for the 64 rows of one slice, X in LDS (row-major):
@@ -216,7 +217,7 @@ __device__ __forceinline__ void rs_ell_spmm_chunks(const RsEll& E, const double*
   const int wave = threadIdx.x >> 6, wl = threadIdx.x & 63;
   const double one = E.one;
 #pragma nounroll
-  for (int sl = wave; sl < E.n_slices; sl += SDPLR_RS_NW) {
+  for (int sl = E.sl0 + wave * E.sl_step; sl < E.n_slices; sl += SDPLR_RS_NW * E.sl_step) {
     const int idx = sl * 64 + wl;
     const int jp = E.perm[idx];
     const int len = E.len[idx];
@@ -231,13 +232,13 @@ __device__ __forceinline__ void rs_ell_spmm_chunks(const RsEll& E, const double*
     vecd<VEC> xr[DOTS ? NCH : 1];
     if (EARLY) {
 #pragma unroll
-      for (int c = 0; c < NCH; c++) xr[c] = ldrow<VEC>(dots.R + (long long)j * r + (c0 + c) * VEC);
+      for (int c = 0; c < NCH; c++) xr[c] = ldrow_nt<VEC>(dots.R + (long long)j * r + (c0 + c) * VEC);   // (past L1: in a team the row may be a team-mate's)
     }
     vecd<VEC> w[NCH];
     rs_ell_pass<VEC, MODE, NCH>(ep, vp, width, len, one, Xl, r, c0, j, gd, n, w);
     if (DOTS && !EARLY) {
 #pragma unroll
-      for (int c = 0; c < NCH; c++) xr[c] = ldrow<VEC>(dots.R + (long long)j * r + (c0 + c) * VEC);
+      for (int c = 0; c < NCH; c++) xr[c] = ldrow_nt<VEC>(dots.R + (long long)j * r + (c0 + c) * VEC);
     }
     if (jp >= 0) {
 #pragma unroll
@@ -523,7 +524,48 @@ struct RsLoopArgs {
   double in_sigma, in_gtol, in_fprec, in_normC, in_normb;
   long long in_max_iters;
   double* out;                          // [8]: ℒ, ‖G‖, ‖primal_vio‖, α, obj, iters, exit_reason, err
+  // TEAM (rs_loop_run<…, TEAM>): team_w workgroups of ONE XCD share the instance; this one is team_rank.  xch: the team's
+  // exchange block in global memory — [team_w][32] Gram / norm partials | [team_w][16] line-search partials | as unsigned:
+  // arrival counter, failure flag, the members' XCC ids (zeroed by the host before the launch).
+  int team_w, team_rank;
+  double* xch;
 };
+#define SDPLR_RS_TEAM_MAX 4
+#define SDPLR_RS_XCH_DOUBLES (48 * SDPLR_RS_TEAM_MAX + 8)
+#define SDPLR_ERR_TEAM_PLACEMENT (-101)   /* the members did not land on one XCD, or not all of them arrived: nothing was touched, the host relaunches without a team */
+#define SDPLR_ERR_TEAM_TIMEOUT (-102)     /* a member never arrived at a team barrier (the grid was not co-resident) */
+
+// Team barrier (k_rs_loop<…, TEAM>): every wave's stores are complete (s_waitcnt + the workgroup barrier) before ONE lane adds to
+// the team's counter in L2; the poll is an agent-scope atomic load.  What a member then reads of its team-mates' data it reads
+// past its L1 (non-temporal loads) — the members sit on one XCD (checked at entry: HW_REG_XCC_ID) and share its L2, so no
+// L2 write-back / invalidate (≈ 3.5 µs per member and barrier) is needed.  Every spin is bounded.
+struct RsTeamSync {
+  unsigned* ctr;
+  unsigned target;
+  int W;
+};
+__device__ __forceinline__ bool rs_team_barrier(RsTeamSync& ts, int* sh_ok) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  ts.target += (unsigned)ts.W;
+  if (threadIdx.x == 0) {
+    // (the add returns the count: the last member to arrive does not poll at all; bit 31 of the counter is the failure flag)
+    unsigned v = __hip_atomic_fetch_add(ts.ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+    long long spins = 0;
+    while (!(v & 0x80000000u) && (v & 0x7FFFFFFFu) < ts.target) {
+      __builtin_amdgcn_s_sleep(1);
+      v = __hip_atomic_load(ts.ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (++spins > (1LL << 20)) {   // (≈ 1 s)
+        (void)__hip_atomic_fetch_or(ts.ctr, 0x80000000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        v |= 0x80000000u;
+      }
+    }
+    *sh_ok = (v & 0x80000000u) ? 0 : 1;
+  }
+  __syncthreads();
+  return *sh_ok != 0;
+}
+__device__ __forceinline__ double rs_ld_nt(const double* p) { return __builtin_nontemporal_load(p); }
 
 // constraint data of the rows a thread owns (row j = tid + q·NT): registers for q < RPT, global memory beyond
 // (λ_ub and the lower bound of the violation — ±∞ on equality constraints — are read where COMMIT needs them, once per
@@ -547,8 +589,16 @@ __device__ __forceinline__ RsRow rs_load_row(const RsLoopArgs& a, int j) {
 // PDROP (A_g is the cost matrix: y_g ≡ 1; the caller vouches that G is the gradient at the device's state, or has fg! run
 // in the prologue): STEP carries G forward — G_new = G_old + 2(αW + d_new∘R_new − d_old∘R_old), as k_fast_step2<…, PDROP>
 // does — and P is neither read nor written: two of STEP's seventeen streams gone, and no P = A_g·R at the loop's entry.
-template <int VEC, int HM, bool PDROP>
+// TEAM (with PDROP, no rank-one matrix): team_w workgroups run this loop on ONE instance.  Each member forms the whole
+// direction in its own LDS (DIR is a ninth of the iteration and needs every row anyway) and takes its share of the rest:
+// the slices trank, trank + W, … of the SpMM, the rows [row_lo, row_hi) of the line-search sums, the commit and STEP.  Three
+// exchanges per iteration through the team's block in global memory, each behind a team barrier: the Gram / norm partials
+// of STEP (→ SEAM, made by every member for itself: same sums, same order, the same control block in every member), the
+// rows of W with their dots (SpMM → line search), the ten line-search sums (→ SOLVE, again by every member).  Rank 0 alone
+// runs the prologue, stores the scalars of the extra slot and the control block, and leaves dirt.
+template <int VEC, int HM, bool PDROP, bool TEAM = false>
 __device__ __forceinline__ void rs_loop_run(const RsLoopArgs& a) {
+  static_assert(!TEAM || PDROP, "teams run the P-less loop");
   extern __shared__ __attribute__((aligned(16))) double rs_lds[];   // (16-byte LDS reads: an 8-byte-aligned base behind the static LDS made every ds_read_b128 a misaligned access — 5× slower)
   __shared__ SeamLds gd;
   __shared__ double sred[(5 * HM + 2 > 10 ? 5 * HM + 2 : 10) * SDPLR_RS_NW];
@@ -562,6 +612,16 @@ __device__ __forceinline__ void rs_loop_run(const RsLoopArgs& a) {
   const int n = a.n, m = a.m, r = a.r, h = a.h;
   const long long N = (long long)n * r;
   const long long Npad = rs_npad(n, r);
+  // this workgroup's share of the rows (everything, without a team)
+  const int TW = TEAM ? a.team_w : 1, trank = TEAM ? a.team_rank : 0;
+  const int rpm = (n + TW - 1) / TW;
+  const int row_lo = TEAM ? min(n, trank * rpm) : 0, row_hi = TEAM ? min(n, row_lo + rpm) : n;
+  __shared__ int sh_team_ok;
+  __shared__ double sh_pvg, sh_tflag;
+  double* const xg = a.xch;                                   // [TW][32]
+  double* const xl = TEAM ? a.xch + 32 * TW : nullptr;        // [TW][16]
+  unsigned* const xi = TEAM ? reinterpret_cast<unsigned*>(a.xch + 48 * TW) : nullptr;
+  RsTeamSync ts{xi, 0u, TW};
   double* Dl = rs_lds;                 // [Npad] the direction (or R while P is being refreshed), then the zero row
   for (long long e = N + threadIdx.x; e < Npad; e += SDPLR_RS_NT) Dl[e] = 0.0;
   const bool rows_global = a.rowvec != nullptr;
@@ -583,6 +643,36 @@ __device__ __forceinline__ void rs_loop_run(const RsLoopArgs& a) {
   // σ as the block holds it on entry: the λ update of the prologue runs BEFORE var.σ[] is written (src/sdplr.jl:358-362
   // come before :366-369), so it must not see the σ the argument row brings
   const double sigma_on_entry = gd.c.sigma;
+  if constexpr (TEAM) {   // all members on one XCD?  (placement is the dispatcher's: observed round-robin, never promised)
+    if (tid == 0) {
+      unsigned xcc;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+      __hip_atomic_store(xi + 2 + trank, (xcc & 0xFu) + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // (a member that never arrives HERE — the grid is not co-resident: the GPU is oversubscribed — is a placement failure
+    // like any other: nothing has been touched yet.  Past this barrier every member is resident for good.)
+    bool ok = rs_team_barrier(ts, &sh_team_ok);
+    int code = ok ? 0 : SDPLR_ERR_TEAM_PLACEMENT;
+    if (ok) {
+      __syncthreads();
+      if (tid == 0) {
+        const unsigned x0 = __hip_atomic_load(xi + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int same = 1;
+        for (int k = 1; k < TW; k++) same &= (__hip_atomic_load(xi + 2 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == x0) ? 1 : 0;
+        sh_team_ok = same;
+      }
+      __syncthreads();
+      if (!sh_team_ok) code = SDPLR_ERR_TEAM_PLACEMENT;
+    }
+    if (code != 0) {   // nothing has been touched: the host relaunches the instance without a team
+      if (trank == 0 && tid == 0) {
+        a.c->err = code;
+        if (a.out != nullptr) a.out[7] = (double)code;
+      }
+      return;
+    }
+  }
+  if (!TEAM || trank == 0) {   // (rank 0 runs the head of the major iteration alone)
   if (a.in_set) {   // (sdplr_hip_major_iteration: var.σ[], the loop's parameters and counters)
     __syncthreads();
     if (tid == 0) {
@@ -623,6 +713,30 @@ __device__ __forceinline__ void rs_loop_run(const RsLoopArgs& a) {
       rs_fg_body<VEC>(f, gd.c, Dl, rdl, djl, sred, fsh, w0l);
     }
   }
+  }
+  if constexpr (TEAM) {   // the control block as the head left it → the other members (through global memory)
+    __syncthreads();
+    if (trank == 0)
+      for (int t = tid; t < (int)(sizeof(DevCtrl) / 8); t += NT)
+        reinterpret_cast<unsigned long long*>(a.c)[t] = reinterpret_cast<const unsigned long long*>(&gd.c)[t];
+    if (!rs_team_barrier(ts, &sh_team_ok)) {
+      if (trank == 0 && tid == 0) {
+        a.c->err = SDPLR_ERR_TEAM_TIMEOUT;
+        if (a.out != nullptr) a.out[7] = (double)SDPLR_ERR_TEAM_TIMEOUT;
+      }
+      return;
+    }
+    if (trank != 0)
+      for (int t = tid; t < (int)(sizeof(DevCtrl) / 8); t += NT)
+        reinterpret_cast<unsigned long long*>(&gd.c)[t] = __builtin_nontemporal_load(reinterpret_cast<const unsigned long long*>(a.c) + t);
+    if (tid == 0) {
+      sh_pvg = rs_ld_nt(a.pv_raw + a.gid_g);
+      sh_tflag = 0.0;
+      for (int k = 0; k < 5 * SDPLR_HMAX; k++) gd.red[k] = 0.0;
+      gd.nrm[0] = gd.nrm[1] = 0.0;
+    }
+    __syncthreads();
+  }
   if (has_lr && !a.pre_fg) {   // w0 = Rᵀb and ws = y_c·D·w0 at the point and multipliers the previous g! left
     for (long long e = tid; e < N; e += NT) Dl[e] = R[e];
     __syncthreads();
@@ -632,20 +746,23 @@ __device__ __forceinline__ void rs_loop_run(const RsLoopArgs& a) {
     __syncthreads();
   }
   // constraint data of this thread's rows: constant over the call except primal_vio_raw, which the thread owns
-  RsRow rw_[SDPLR_RS_RPT];
+  // (a team member owns at most ⌈n/W⌉ rows: one per thread up to n = 1024; the second register set is what tipped the team
+  // kernels into scratch)
+  constexpr int RPT = TEAM ? 1 : SDPLR_RS_RPT;
+  RsRow rw_[RPT];
 #pragma unroll
-  for (int q = 0; q < SDPLR_RS_RPT; q++) {
-    const int j = tid + q * NT;
-    if (j < n) rw_[q] = rs_load_row(a, j);
+  for (int q = 0; q < RPT; q++) {
+    const int j = row_lo + tid + q * NT;
+    if (j < row_hi) rw_[q] = rs_load_row(a, j);
     else { rw_[q].k = -1; rw_[q].v = rw_[q].lam = rw_[q].pvr = 0.0; }
   }
   if (PDROP && !a.pre_fg) {   // d_j at the multipliers the previous g! left (fg! in the prologue has just formed them)
 #pragma unroll
-    for (int q = 0; q < SDPLR_RS_RPT; q++) {
-      const int j = tid + q * NT;
-      if (j < n) djl[j] = (rw_[q].k >= 0) ? rw_[q].v * a.y[rw_[q].k] : 0.0;
+    for (int q = 0; q < RPT; q++) {
+      const int j = row_lo + tid + q * NT;
+      if (j < row_hi) djl[j] = (rw_[q].k >= 0) ? rw_[q].v * a.y[rw_[q].k] : 0.0;
     }
-    for (int j = tid + SDPLR_RS_RPT * NT; j < n; j += NT) {
+    for (int j = row_lo + tid + RPT * NT; j < row_hi; j += NT) {
       const int k = a.row_k[j];
       djl[j] = (k >= 0) ? a.row_v[j] * a.y[k] : 0.0;
     }
@@ -670,6 +787,35 @@ __device__ __forceinline__ void rs_loop_run(const RsLoopArgs& a) {
     // 116 bytes of scratch per lane without this, 217 and none with it)
     tid = tid0;
     asm volatile("" : "+v"(tid));
+    if constexpr (TEAM) {   // every member's partials of the 5h Gram sums and the two norms → every member
+      // (lane k of wave 0 carries entry k: one store, one round of TW loads in flight together, the sum in rank order)
+      if (tid < 32) {
+        const int q = tid / HM, l = tid % HM;
+        double mine = 0.0;
+        if (tid < 5 * HM) mine = gd.red[q * SDPLR_HMAX + l];
+        else if (tid < 5 * HM + 2) mine = gd.nrm[tid - 5 * HM];
+        else if (tid == 31 && trank == 0) mine = (a.budget_ticks > 0 && (long long)wall_clock64() - t_start > a.budget_ticks) ? 1.0 : 0.0;
+        xg[32 * trank + tid] = mine;
+      }
+      if (!rs_team_barrier(ts, &sh_team_ok)) {
+        if (tid == 0) { gd.c.err = SDPLR_ERR_TEAM_TIMEOUT; gd.c.done = 1; }
+        __syncthreads();
+        break;
+      }
+      if (tid < 32) {
+        double v[SDPLR_RS_TEAM_MAX];
+#pragma unroll
+        for (int k = 0; k < SDPLR_RS_TEAM_MAX; k++) v[k] = rs_ld_nt(xg + 32 * min(k, TW - 1) + tid);
+        double t = 0.0;
+#pragma unroll
+        for (int k = 0; k < SDPLR_RS_TEAM_MAX; k++) t += (k < TW) ? v[k] : 0.0;
+        const int q = tid / HM, l = tid % HM;
+        if (tid < 5 * HM) gd.red[q * SDPLR_HMAX + l] = t;
+        else if (tid < 5 * HM + 2) gd.nrm[tid - 5 * HM] = t;
+        else if (tid == 31) sh_tflag = v[0];
+      }
+      __syncthreads();
+    }
     // ================= SEAM =================
     // (the Gram sums and the norms of the iteration that just ended were folded into gd.red / gd.nrm by STEP)
     if (tid == 0) {
@@ -681,7 +827,8 @@ __device__ __forceinline__ void rs_loop_run(const RsLoopArgs& a) {
         default: seam_serial(gd, h, 0, 1, 1, 1, have_upd, have_norms, 1);
       }
       // time budget (src/sdplr.jl:272-277): tested where the iteration budget is; the device's own exits win
-      if (!gd.c.done && a.budget_ticks > 0 && (long long)wall_clock64() - t_start > a.budget_ticks) {
+      // (a team takes rank 0's reading of the clock, exchanged with the partials above: every member must decide alike)
+      if (!gd.c.done && (TEAM ? sh_tflag != 0.0 : (a.budget_ticks > 0 && (long long)wall_clock64() - t_start > a.budget_ticks))) {
         gd.c.iters -= 1;
         gd.c.done = 1;
         gd.c.exit_reason = EXIT_TIME;
@@ -714,12 +861,13 @@ __device__ __forceinline__ void rs_loop_run(const RsLoopArgs& a) {
       // 16-byte ones it takes half of that.  The same sums per element, in the same order.
       auto dir_unit = [&](auto tag, long long e) {
         constexpr int W = decltype(tag)::value;
-        const vecd<W> g = ldrow<W>(Gm + e);
+        // (a team member reads G and the history past its L1: most of their rows are its team-mates')
+        const vecd<W> g = TEAM ? ldrow_nt<W>(Gm + e) : ldrow<W>(Gm + e);
         vecd<W> yv[HM], sv[HM];
 #pragma unroll
         for (int k = 0; k < HM; k++) {
-          yv[k] = ldrow<W>(yp[k] + e);
-          sv[k] = ldrow<W>(sp_[k] + e);
+          yv[k] = TEAM ? ldrow_nt<W>(yp[k] + e) : ldrow<W>(yp[k] + e);
+          sv[k] = TEAM ? ldrow_nt<W>(sp_[k] + e) : ldrow<W>(sp_[k] + e);
         }
         vecd<W> d;
 #pragma unroll
@@ -731,7 +879,9 @@ __device__ __forceinline__ void rs_loop_run(const RsLoopArgs& a) {
           for (int k = HM - 1; k >= 0; k--) rr += cg[k] * sv[k].v[q];     // oldest → newest (:104-113)
           d.v[q] = fb ? -g.v[q] : -rr;                                    // (:116-118); fallback: src/sdplr.jl:202-205
         }
-        if (fb) strow<W>(Gm + e, d);
+        // (G ← −G of the fallback, src/sdplr.jl:202-205: in a team G keeps its sign — another member may still be reading
+        // the element — and STEP takes G_old with the sign it has)
+        if (fb && !TEAM) strow<W>(Gm + e, d);
         strow<W>(Dl + e, d);
       };
       const long long U2 = N / 2;
@@ -748,9 +898,24 @@ __device__ __forceinline__ void rs_loop_run(const RsLoopArgs& a) {
     double rw_sum = 0.0, dw_sum = 0.0;
     {
       const RsDots dots{R, rdl, ddl};
-      rs_ell_spmm_dots<VEC>(a.E, Dl, n, r, a.W, dots, rw_sum, dw_sum);
+      if constexpr (TEAM) {
+        RsEll Et = a.E;
+        Et.sl0 = trank;
+        Et.sl_step = TW;
+        rs_ell_spmm_dots<VEC>(Et, Dl, n, r, a.W, dots, rw_sum, dw_sum);
+      } else {
+        rs_ell_spmm_dots<VEC>(a.E, Dl, n, r, a.W, dots, rw_sum, dw_sum);
+      }
     }
-    __syncthreads();
+    if constexpr (TEAM) {   // the rows of W and their dots → the members that own them in the line search and STEP
+      if (!rs_team_barrier(ts, &sh_team_ok)) {
+        if (tid == 0) { gd.c.err = SDPLR_ERR_TEAM_TIMEOUT; gd.c.done = 1; }
+        __syncthreads();
+        break;
+      }
+    } else {
+      __syncthreads();
+    }
     RS_STAMP(7);
     RS_STAMP(2);
     double acc[10];
@@ -765,7 +930,7 @@ __device__ __forceinline__ void rs_loop_run(const RsLoopArgs& a) {
         if (rw.k < 0) return;
         int kk = rw.k;
         asm volatile("" : "+v"(kk));   // (opaque: see commit_row)
-        const double rd = rdl[j], dd = ddl[j];
+        const double rd = TEAM ? rs_ld_nt(rdl + j) : rdl[j], dd = TEAM ? rs_ld_nt(ddl + j) : ddl[j];
         const double q1 = rw.v * (rd + rd), q2 = rw.v * dd;
         a.A_RD[kk] = q1;
         a.A_DD[kk] = q2;
@@ -785,11 +950,39 @@ __device__ __forceinline__ void rs_loop_run(const RsLoopArgs& a) {
         }
       };
 #pragma unroll
-      for (int q = 0; q < SDPLR_RS_RPT; q++)
-        if (tid + q * NT < n) ls_row(tid + q * NT, rw_[q]);
-      for (int j = tid + SDPLR_RS_RPT * NT; j < n; j += NT) ls_row(j, rs_load_row(a, j));
+      for (int q = 0; q < RPT; q++)
+        if (row_lo + tid + q * NT < row_hi) ls_row(row_lo + tid + q * NT, rw_[q]);
+      for (int j = row_lo + tid + RPT * NT; j < row_hi; j += NT) ls_row(j, rs_load_row(a, j));
     }
     rs_sum_to0<10>(acc, sred);
+    if constexpr (TEAM) {   // the ten sums of every member → every member (added in rank order)
+      __shared__ double sh_ls[10];
+      if (tid == 0) {
+#pragma unroll
+        for (int k = 0; k < 10; k++) sh_ls[k] = acc[k];
+      }
+      __syncthreads();
+      if (tid < 10) xl[16 * trank + tid] = sh_ls[tid];
+      if (!rs_team_barrier(ts, &sh_team_ok)) {
+        if (tid == 0) { gd.c.err = SDPLR_ERR_TEAM_TIMEOUT; gd.c.done = 1; }
+        __syncthreads();
+        break;
+      }
+      if (tid < 10) {
+        double v[SDPLR_RS_TEAM_MAX];
+#pragma unroll
+        for (int k = 0; k < SDPLR_RS_TEAM_MAX; k++) v[k] = rs_ld_nt(xl + 16 * min(k, TW - 1) + tid);
+        double t = 0.0;
+#pragma unroll
+        for (int k = 0; k < SDPLR_RS_TEAM_MAX; k++) t += (k < TW) ? v[k] : 0.0;
+        sh_ls[tid] = t;
+      }
+      __syncthreads();
+      if (tid == 0) {
+#pragma unroll
+        for (int k = 0; k < 10; k++) acc[k] = sh_ls[k];
+      }
+    }
     RS_STAMP(3);
     // ================= SOLVE =================
     if (tid == 0) {
@@ -797,9 +990,12 @@ __device__ __forceinline__ void rs_loop_run(const RsLoopArgs& a) {
       const double sigma = c.sigma;
       const int kg = a.gid_g;
       const double g_rd = acc[8] + acc[8], g_dd = acc[9];
-      a.A_RD[kg] = g_rd;   // ⟨A_g, RDᵀ+DRᵀ⟩ = 2⟨P, D⟩
-      a.A_DD[kg] = g_dd;   // ⟨A_g, DDᵀ⟩ = ⟨D, W⟩
-      double pvg = a.pv_raw[kg], lg = 0.0, lubg = 0.0, lbg = 0.0;
+      const bool st0 = !TEAM || trank == 0;   // (every member solves; rank 0 stores)
+      if (st0) {
+        a.A_RD[kg] = g_rd;   // ⟨A_g, RDᵀ+DRᵀ⟩ = 2⟨P, D⟩
+        a.A_DD[kg] = g_dd;   // ⟨A_g, DDᵀ⟩ = ⟨D, W⟩
+      }
+      double pvg = TEAM ? sh_pvg : a.pv_raw[kg], lg = 0.0, lubg = 0.0, lbg = 0.0;
       if (kg < m) {
         lg = a.lam[kg];
         lubg = a.lam_ub[kg];
@@ -861,17 +1057,18 @@ __device__ __forceinline__ void rs_loop_run(const RsLoopArgs& a) {
         sh_upd = c.reldelta_exit ? 0 : 1;
         // commit of A_g's slot (src/linesearch.jl:118-124, src/coreop.jl:229-236)
         const double v = pvg + al * (al * g_dd + g_rd);
-        a.pv_raw[kg] = v;
+        if (st0) a.pv_raw[kg] = v;
+        if (TEAM) sh_pvg = v;
         double yk = 1.0, pv2 = 0.0;
         if (kg == m) {
           c.obj = v;
         } else {
           const double pc = fmax(v, lbg);
-          a.pv[kg] = pc;
+          if (st0) a.pv[kg] = pc;
           pv2 = pc * pc;
           yk = -fmin(lubg, lg - sigma * v);
         }
-        a.y[kg] = yk;
+        if (st0) a.y[kg] = yk;
         sh_yg = yk;
         if (has_lr) {   // commit of the rank-one matrix's slot; W0 ← W0 + α·W1 = R_newᵀb; WS = y_c·D·W0  (k_ls_solve_fast's tail)
           const int kc = a.lr.gid;
@@ -914,7 +1111,7 @@ __device__ __forceinline__ void rs_loop_run(const RsLoopArgs& a) {
           asm volatile("" : "+v"(kk));
           const int kb = kk < m ? kk : 0;
           const double lub = (kk < m) ? a.lam_ub[kb] : 0.0, lbv = (kk < m) ? a.lb[kb] : 0.0;
-          const double rd = rdl[j], dd = ddl[j];
+          const double rd = TEAM ? rs_ld_nt(rdl + j) : rdl[j], dd = TEAM ? rs_ld_nt(ddl + j) : ddl[j];
           const double q1 = rw.v * (rd + rd), q2 = rw.v * dd;
           const double v = rw.pvr + al * (al * q2 + q1);     // src/linesearch.jl:118
           rw.pvr = v;
@@ -936,9 +1133,9 @@ __device__ __forceinline__ void rs_loop_run(const RsLoopArgs& a) {
         djl[j] = dj;
       };
 #pragma unroll
-      for (int q = 0; q < SDPLR_RS_RPT; q++)
-        if (tid + q * NT < n) commit_row(tid + q * NT, rw_[q]);
-      for (int j = tid + SDPLR_RS_RPT * NT; j < n; j += NT) {
+      for (int q = 0; q < RPT; q++)
+        if (row_lo + tid + q * NT < row_hi) commit_row(row_lo + tid + q * NT, rw_[q]);
+      for (int j = row_lo + tid + RPT * NT; j < row_hi; j += NT) {
         RsRow rw = rs_load_row(a, j);
         commit_row(j, rw);
       }
@@ -948,7 +1145,7 @@ __device__ __forceinline__ void rs_loop_run(const RsLoopArgs& a) {
     // ================= STEP =================
     {
       // y_j = G_new − G_old: G_old is still in the G array (sign-flipped if the fallback negated it)
-      const double gs = fb ? 1.0 : -1.0;
+      const double gs = (fb && !TEAM) ? 1.0 : -1.0;
       double* const Sj = aslot(a.A, AS_S0 + jslot);
       double* const Yj = aslot(a.A, as_y0(a.A) + jslot);
       const double* slp[HM];
@@ -961,16 +1158,16 @@ __device__ __forceinline__ void rs_loop_run(const RsLoopArgs& a) {
       // element by element in units of VEC doubles, like DIR (every stream fully coalesced, all lanes busy whatever the
       // rank); the row of a unit — for d_j — advances with it
       {
-        const long long U = N / VEC;                       // (VEC = 2 only for even r)
+        const long long U0 = (long long)row_lo * r / VEC, U = (long long)row_hi * r / VEC;   // (VEC = 2 only for even r)
         const int adv = NT * VEC, adv_q = adv / r, adv_r = adv % r;
-        int j = (tid * VEC) / r, ch = (tid * VEC) % r;
+        int j = (int)(((U0 + tid) * VEC) / r), ch = (int)(((U0 + tid) * VEC) % r);
 #pragma nounroll
-        for (long long u = tid; u < U; u += NT) {
+        for (long long u = U0 + tid; u < U; u += NT) {
           const long long e = u * VEC;
           const vecd<VEC> x0 = ldrow<VEC>(R + e), gold = ldrow<VEC>(Gm + e);
           vecd<VEC> p0;
           if (!PDROP) p0 = ldrow<VEC>(a.P + e);
-          const vecd<VEC> w = ldrow<VEC>(a.W + e);
+          const vecd<VEC> w = TEAM ? ldrow_nt<VEC>(a.W + e) : ldrow<VEC>(a.W + e);   // (rows of W come from the member whose slice holds them)
           const vecd<VEC> d = ldrow<VEC>(Dl + e);
           vecd<VEC> sv[HM], yv[HM];
           if (upd) {
@@ -1060,13 +1257,14 @@ __device__ __forceinline__ void rs_loop_run(const RsLoopArgs& a) {
 #endif
   // dirt as the reference leaves it when the loop is left
   __syncthreads();
+  if (TEAM && trank != 0) return;   // (every member's stores were complete at the last team barrier; rank 0 closes the call)
   if (dir_ran) {
     // … = the unscaled direction after a relative-decrease exit (no lbfgs_update!), s_latest = α·dirt otherwise
     // (`dirt *= α`, src/lbfgs.jl:142, is not stored inside the loop)
     double* const Dg = aslot(a.A, AS_D);
     const bool scaled = gd.c.iters > 0 && gd.c.err == 0 && gd.c.exit_reason != EXIT_RELDELTA;
     const double* const Sl = aslot(a.A, AS_S0 + (gd.c.latest - 1));
-    for (long long e = tid; e < N; e += NT) Dg[e] = scaled ? Sl[e] : Dl[e];
+    for (long long e = tid; e < N; e += NT) Dg[e] = scaled ? (TEAM ? rs_ld_nt(Sl + e) : Sl[e]) : Dl[e];
   }
   // the control block goes back whole (done / exit_reason / iters / L / norms / Gram data / latest …)
   if (tid == 0) {
@@ -1092,6 +1290,26 @@ __global__ void __launch_bounds__(SDPLR_RS_NT)
 k_rs_loop_batch(const RsLoopArgs* __restrict__ items) {
   const RsLoopArgs a = items[blockIdx.x];
   rs_loop_run<VEC, HM, PDROP>(a);
+}
+// Teams: the members of a team are blocks b, b + 8, b + 16, … — dealt to the same XCD by the dispatcher's round-robin
+// (checked by the members themselves).  Grid 8·W·⌈count/8⌉: block b is rank (b/8) mod W of instance ((b/8)/W)·8 + b mod 8.
+template <int VEC, int HM>
+__global__ void __launch_bounds__(SDPLR_RS_NT)
+k_rs_team_batch(const RsLoopArgs* __restrict__ items, int count, int W) {
+  const int xcd = blockIdx.x % 8, q = blockIdx.x / 8;
+  const int inst = (q / W) * 8 + xcd;
+  if (inst >= count) return;
+  RsLoopArgs a = items[inst];
+  a.team_w = W;
+  a.team_rank = q % W;
+  rs_loop_run<VEC, HM, true, true>(a);
+}
+template <int VEC, int HM>
+__global__ void __launch_bounds__(SDPLR_RS_NT)
+k_rs_team(RsLoopArgs a) {   // one instance: grid 8·(W − 1) + 1, the blocks b ≡ 0 (mod 8) are the team
+  if (blockIdx.x % 8 != 0) return;
+  a.team_rank = blockIdx.x / 8;
+  rs_loop_run<VEC, HM, true, true>(a);
 }
 
 // ---- approx_mineigval_lanczos's recurrence (src/coreop.jl:473-500) in one launch -----------------------------------

@@ -143,6 +143,8 @@ struct sdplr_hip_solver {
   bool lit = false;
   double *lit_rho = nullptr, *lit_a = nullptr;
   bool no_lshead = false;    // SDPLR_HIP_NO_LSHEAD: the line-search scalar stage stays a kernel of its own
+  bool no_team = false;      // a team launch found its members on different XCDs: this handle runs without teams from then on
+  double* rs_xch = nullptr;  // the team's exchange block (k_resident.h, RsLoopArgs::xch)
   bool no_pdrop = false;     // SDPLR_HIP_NO_PDROP: the step kernel keeps P = A_g·R (P += α·W) instead of carrying G forward
   bool pdrop_now = false;    // this inner loop runs the P-less step kernel (decided at loop entry)
   // G is the gradient at the device's (R, λ, σ) with y as its g! left it: true after fg! / g! / an inner loop, cleared by
@@ -726,8 +728,18 @@ int sync_check(S* s) {
 constexpr size_t RS_LDS_MAX = 150 * 1024;   // dynamic LDS of a resident kernel (≈ 9.6 KB more are static: control block, reduction scratch)
 // D (with the SpMM's zero row) | ⟨R_j,D_j⟩ | ‖D_j‖² | d_j | four r-vectors of the rank-one matrix.  When that is more than
 // a CU has but the direction alone fits, the three per-row vectors move to global memory (k_resident.h, RsLoopArgs::rowvec).
+// Workgroups per instance on the resident loop (k_resident.h, TEAM): a function of the instance alone — never of the batch it
+// travels in — so that batch calls and single calls run the same kernel on it.  The P-less loop without a rank-one matrix.
+int rs_team_w(const S* s) {
+  if (s->no_team) return 1;
+  const char* e = getenv("SDPLR_HIP_TEAM");
+  const int want = e ? atoi(e) : 2;   // (two: a 64-instance batch still fits the GPU twice over; four gains another 13 % per iteration)
+  if (want < 2 || s->n < 128 || s->h < 1 || s->h > 4 || s->lr.ST != 0 || s->no_pdrop || s->ff.gid_g != (int)s->m) return 1;
+  return std::min(want, SDPLR_RS_TEAM_MAX);
+}
 bool rs_rows_global(const S* s) {
   const size_t full = ((size_t)rs_npad(s->n, s->r) + 3 * (size_t)s->n + 4 * (size_t)s->r) * sizeof(double);
+  if (rs_team_w(s) > 1) return true;   // (the members of a team share the per-row vectors through global memory)
   return full > RS_LDS_MAX && getenv("SDPLR_HIP_NO_RESIDENT_ROWVEC") == nullptr;
 }
 size_t rs_loop_lds(const S* s) {
@@ -1200,6 +1212,7 @@ int build_rs_ell(S* s, const std::vector<int>& g_ptr, const std::vector<int>& g_
   if (!uniform && (rc = upload(s, &E.val, val))) return rc;
   if ((rc = upload(s, &E.gdiag, gdiag))) return rc;
   if (!s->rs_rowvec && (rc = dzero(s, &s->rs_rowvec, (size_t)3 * n))) return rc;   // (12.8 KB at n = 1600; used only when rs_rows_global)
+  if (!s->rs_xch && (rc = dzero(s, &s->rs_xch, SDPLR_RS_XCH_DOUBLES))) return rc;
   s->rs_ok = true;
   return SDPLR_OK;
 }
@@ -2830,7 +2843,13 @@ int enq_resident_loop(S* s, double time_budget_s, bool refresh_P, bool pre_lambd
   RsLoopArgs a = rs_loop_args(s, time_budget_s, refresh_P, pre_lambda, pre_clear_fg);
   if (in) rs_loop_set_in(a, *in);
   const size_t lds = rs_loop_lds(s);
-  if (pdrop) { RS_VEC_DISPATCH(s, ({ RS_SET_ATTR((k_rs_loop<VEC, 4, true>)); k_rs_loop<VEC, 4, true><<<1, SDPLR_RS_NT, lds, s->stream>>>(a); })) }
+  const int W = pdrop ? rs_team_w(s) : 1;
+  if (W > 1) {   // a team: W workgroups of one XCD (blocks 0, 8, …: k_resident.h)
+    a.team_w = W;
+    a.xch = s->rs_xch;
+    HIPCK(s, hipMemsetAsync(s->rs_xch + 48 * W, 0, 8 * sizeof(double), s->stream));   // arrival counter, failure flag, XCC ids
+    RS_VEC_DISPATCH(s, ({ RS_SET_ATTR((k_rs_team<VEC, 4>)); k_rs_team<VEC, 4><<<8 * (W - 1) + 1, SDPLR_RS_NT, lds, s->stream>>>(a); }))
+  } else if (pdrop) { RS_VEC_DISPATCH(s, ({ RS_SET_ATTR((k_rs_loop<VEC, 4, true>)); k_rs_loop<VEC, 4, true><<<1, SDPLR_RS_NT, lds, s->stream>>>(a); })) }
   else { RS_VEC_DISPATCH(s, ({ RS_SET_ATTR((k_rs_loop<VEC, 4, false>)); k_rs_loop<VEC, 4, false><<<1, SDPLR_RS_NT, lds, s->stream>>>(a); })) }
   HIPCK(s, hipGetLastError());
   s->st_rs_loops++;
@@ -2860,6 +2879,19 @@ int run_resident_loop(S* s, double time_budget_s, bool pre_lambda, bool pre_clea
   if (pre_clear_fg) { s->st_rs_fg++; s->gram_dirty = false; }
   if ((rc = pull_blocking(s))) return rc;
   DevCtrl* c = s->hc;
+  if (c->err == SDPLR_ERR_TEAM_PLACEMENT) {   // the members were not dealt to one XCD: nothing was touched — once more, without a team
+    c->err = 0;
+    s->no_team = true;
+    if ((rc = push(s))) return rc;
+    if ((rc = enq_resident_loop(s, time_budget_s, refresh, pre_lambda, pre_clear_fg, in, pdrop))) return rc;
+    s->st_rs_loops--;
+    if ((rc = pull_blocking(s))) return rc;
+  }
+  if (c->err == SDPLR_ERR_TEAM_TIMEOUT) {
+    c->err = 0; c->done = 0;
+    (void)push(s);
+    return fail(s, SDPLR_ERR_HIP, "resident loop: a team member never arrived at a barrier (the grid was not co-resident)");
+  }
   const int why_rs = c->exit_reason;
   // (`dirt *= α`, src/lbfgs.jl:142: the kernel itself left dirt = s_latest)
   // no iteration ran after the fg! of the prologue: the dots with G are those of a cleared history (zero, exact)
@@ -4428,7 +4460,7 @@ int32_t sdplr_hip_batch_major_iteration(int32_t count, sdplr_hip_major_item* it)
       // (fg! runs in the prologue: G is fresh, the P-less loop applies; a resumed loop takes the kernel it was capped in)
       const bool pd = s && rs_can_drop_P(s) && (!resume || (was_consistent && s->pdrop_now));
       if (s && s->finalized && it[i].max_local_iters >= 1 && rs_loop_applies(s, it[i].use_armijo) && rs_fg_applies(s)) {
-        groups[{pd ? 1 : 0, rs_vec(s)}].push_back(i);
+        groups[{(pd ? 1 : 0) + 10 * (pd ? rs_team_w(s) : 1), rs_vec(s)}].push_back(i);   // (kernel, team size | shape)
       } else {
         if (s) s->G_consistent = was_consistent;   // (the single-instance entry point looks at it itself)
         if (edge_group_applies(s, it[i])) egroups[edge_group_key(s)].push_back(i);
@@ -4437,9 +4469,13 @@ int32_t sdplr_hip_batch_major_iteration(int32_t count, sdplr_hip_major_item* it)
     }
     for (auto& g : egroups)
       if (g.second.size() < 2) { single.insert(single.end(), g.second.begin(), g.second.end()); g.second.clear(); }
-    const size_t max_rows = ARENA_CHUNK / (batch_up(sizeof(RsLoopArgs)) + 128);
     for (auto& g : groups) {
       std::vector<int>& idx = g.second;
+      const bool g_pd = g.first.first % 10 != 0;
+      const int g_w = g.first.first / 10;          // workgroups per instance (a team: k_resident.h, TEAM)
+      // (a team's members must all be resident at once: one 512-thread workgroup per CU, 256 CUs)
+      const size_t max_rows = std::min<size_t>(ARENA_CHUNK / (batch_up(sizeof(RsLoopArgs)) + 128 + (g_w > 1 ? SDPLR_RS_XCH_DOUBLES * sizeof(double) : 0)),
+                                               g_w > 1 ? (size_t)(192 / g_w) : (size_t)1 << 30);
       if (idx.size() < 2) {   // a lone shape: the single-instance entry point (which looks at G_consistent itself)
         for (int i : idx) it[i].s->G_consistent = was_cons[i] != 0;
         single.insert(single.end(), idx.begin(), idx.end());
@@ -4454,7 +4490,11 @@ int32_t sdplr_hip_batch_major_iteration(int32_t count, sdplr_hip_major_item* it)
           return fail(s, SDPLR_ERR_ALLOC, "batch_major_iteration: staging blocks");
         }
         RsLoopArgs* tab = reinterpret_cast<RsLoopArgs*>(bb.host);
-        const size_t res_off = batch_up(nb * sizeof(RsLoopArgs));
+        // (teams: each instance's exchange block rides the staging block — zeroed here, copied up with the table)
+        const size_t xch_off = batch_up(nb * sizeof(RsLoopArgs));
+        const size_t xch_bytes = g_w > 1 ? nb * SDPLR_RS_XCH_DOUBLES * sizeof(double) : 0;
+        const size_t res_off = batch_up(xch_off + xch_bytes);
+        if (xch_bytes) memset(bb.host + xch_off, 0, xch_bytes);
         size_t lds = 0;
         for (size_t k = 0; k < nb; k++) {
           const sdplr_hip_major_item& q = it[idx[lo + k]];
@@ -4472,12 +4512,17 @@ int32_t sdplr_hip_batch_major_iteration(int32_t count, sdplr_hip_major_item* it)
           in.grel = q.gtol_relative; in.prel = q.ptol_relative; in.max_iters = q.max_local_iters;
           rs_loop_set_in(a, in);
           a.out = reinterpret_cast<double*>(bb.dev + res_off) + 8 * k;
+          if (g_w > 1) {
+            a.team_w = g_w;
+            a.xch = reinterpret_cast<double*>(bb.dev + xch_off) + k * SDPLR_RS_XCH_DOUBLES;
+          }
           tab[k] = a;
           lds = std::max(lds, rs_loop_lds(sk));
         }
         const RsLoopArgs* dtab = reinterpret_cast<const RsLoopArgs*>(bb.dev);
-        int rc = batch_round_trip(s, bb, nb * sizeof(RsLoopArgs), res_off, nb * 8 * sizeof(double), [&](hipStream_t st) {
-          if (g.first.first) { RS_VEC_DISPATCH(s, ({ RS_SET_ATTR((k_rs_loop_batch<VEC, 4, true>)); k_rs_loop_batch<VEC, 4, true><<<(int)nb, SDPLR_RS_NT, lds, st>>>(dtab); })) }
+        int rc = batch_round_trip(s, bb, g_w > 1 ? xch_off + xch_bytes : nb * sizeof(RsLoopArgs), res_off, nb * 8 * sizeof(double), [&](hipStream_t st) {
+          if (g_w > 1) { RS_VEC_DISPATCH(s, ({ RS_SET_ATTR((k_rs_team_batch<VEC, 4>)); k_rs_team_batch<VEC, 4><<<8 * g_w * (((int)nb + 7) / 8), SDPLR_RS_NT, lds, st>>>(dtab, (int)nb, g_w); })) }
+          else if (g_pd) { RS_VEC_DISPATCH(s, ({ RS_SET_ATTR((k_rs_loop_batch<VEC, 4, true>)); k_rs_loop_batch<VEC, 4, true><<<(int)nb, SDPLR_RS_NT, lds, st>>>(dtab); })) }
           else { RS_VEC_DISPATCH(s, ({ RS_SET_ATTR((k_rs_loop_batch<VEC, 4, false>)); k_rs_loop_batch<VEC, 4, false><<<(int)nb, SDPLR_RS_NT, lds, st>>>(dtab); })) }
         });
         const double* res = reinterpret_cast<const double*>(bb.host + res_off);
@@ -4489,8 +4534,19 @@ int32_t sdplr_hip_batch_major_iteration(int32_t count, sdplr_hip_major_item* it)
           const double* o = res + 8 * k;
           const int why = (int)o[6], err = (int)o[7];
           const int64_t iters = (int64_t)o[5];
+          if (err == SDPLR_ERR_TEAM_PLACEMENT) {   // not one XCD for this team: nothing was touched — the single-instance route, without teams
+            sk->no_team = true;
+            sk->G_consistent = was_cons[idx[lo + k]] != 0;
+            q.status = SDPLR_ERR_UNSERVED;
+            single.push_back(idx[lo + k]);
+            continue;
+          }
+          if (err == SDPLR_ERR_TEAM_TIMEOUT) {
+            q.status = fail(sk, SDPLR_ERR_HIP, "resident loop: a team member never arrived at a barrier (the grid was not co-resident)");
+            continue;
+          }
           // (the bookkeeping of run_resident_loop)
-          const bool pd = g.first.first != 0, resumed = q.update_lambda == SDPLR_MAJOR_RESUME;
+          const bool pd = g_pd, resumed = q.update_lambda == SDPLR_MAJOR_RESUME;
           sk->pdrop_now = pd;
           if (pd) sk->st_pdrop++;
           sk->P_valid = !pd; sk->P_age = (resumed ? sk->P_age : 0) + iters; sk->S_stale = true; sk->S_from_y = true;

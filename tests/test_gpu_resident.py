@@ -476,3 +476,63 @@ def test_major_iteration_is_the_sequence_it_stands_for(hip_abi, oracle_abi, upda
     assert rg[4] == ro[4] == 5 and np.allclose(rg[:3], ro[:3], rtol=1e-7)
     for s_ in (g, o, g2):
         s_.close()
+
+
+@pytest.mark.parametrize("W", [2, 4])
+@pytest.mark.parametrize("r", [10, 7])
+def test_resident_team_matches_the_single_workgroup_loop(hip_abi, oracle_abi, monkeypatch, W, r):
+    """SDPLR_HIP_TEAM=W (default 2; 1: none): W workgroups of one XCD share an instance inside the resident loop (k_resident.h, TEAM) — every
+    member forms the direction, each takes its slices of the SpMM and its rows of the line search, the commit and STEP;
+    Gram / norm partials, the rows of W with their dots and the ten line-search sums cross between them behind three team
+    barriers per iteration.  Same iterates as the one-workgroup loop up to the order of those sums, and the oracle's to
+    north_star's tolerance; even rank (16-byte pieces) and odd."""
+    data = problems.maxcut_data(gset("G1"))
+    normC, normb = data.normC(), float(np.linalg.norm(data.b))
+    monkeypatch.setenv("SDPLR_HIP_TEAM", "1")
+    one, o = pair(hip_abi, oracle_abi, data, r, 0)
+    s1 = one.fg(normC, normb)
+    r1 = run(one, normC, normb, 25, s1)
+    monkeypatch.setenv("SDPLR_HIP_TEAM", str(W))
+    team = make_solver(hip_abi, data, r, seed=0)[0]
+    st = team.fg(normC, normb)
+    assert st == s1
+    rt = run(team, normC, normb, 25, st)
+    ro = run(o, normC, normb, 25, o.fg(normC, normb))
+    assert rt[4] == r1[4] == ro[4] == 25 and rt[5] == r1[5]
+    assert np.allclose(rt[:3], r1[:3], rtol=1e-10) and rel(team.Rt, one.Rt) < 1e-9 and rel(team.Gt, one.Gt) < 1e-8
+    assert np.allclose(rt[:3], ro[:3], rtol=1e-8) and rel(team.Rt, o.Rt) < 1e-7
+    assert team.obj == pytest.approx(o.obj, rel=1e-8)
+    # the loop continues from the state a team left (and a team from the state one workgroup left)
+    a, b = run(team, normC, normb, 7, rt[:3]), run(one, normC, normb, 7, r1[:3])
+    assert a[4] == b[4] == 7 and np.allclose(a[:3], b[:3], rtol=1e-9)
+    monkeypatch.setenv("SDPLR_HIP_TEAM", "1")
+    a2, b2 = run(team, normC, normb, 5, a[:3]), run(one, normC, normb, 5, b[:3])
+    assert np.allclose(a2[:3], b2[:3], rtol=1e-9) and rel(team.Rt, one.Rt) < 1e-8
+    for s_ in (one, team, o):
+        s_.close()
+
+
+def test_resident_team_in_batch_calls_and_whole_solves(hip_abi, monkeypatch):
+    """Teams inside the lockstep batch calls (grid 8·W·⌈B/8⌉, block b = rank (b/8) mod W of instance ((b/8)/W)·8 + b mod 8):
+    the team size is a property of the instance, so a batch call and the single calls run the same kernel — bit for bit —
+    and a whole solve ends where the one-workgroup solve ends (to the solve's own tolerance)."""
+    datas = [problems.maxcut_data(gset(g)) for g in ("G1", "G2", "G3")] + [make_data("maxcut", 5, 60, 0.2)[0]]
+    kw = dict(ptol=1e-2, objtol=1e-2, maxtime=120.0, printlevel=0, prior_trace_bound=800.0)
+    monkeypatch.setenv("SDPLR_HIP_TEAM", "1")
+    plain = sj.sdplr(data=datas[0], r=10, **kw)
+    monkeypatch.setenv("SDPLR_HIP_TEAM", "4")
+    A = [make_solver(hip_abi, d, 10, seed=3)[0] for d in datas]
+    B = [make_solver(hip_abi, d, 10, seed=3)[0] for d in datas]
+    norms = [(d.normC(), float(np.linalg.norm(d.b))) for d in datas]
+    assert cabi.batch_fg(hip_abi, A, [(nc, nb, 1, 1) for nc, nb in norms]) == \
+        [s.fg(nc, nb, True, True) + (s.obj,) for s, (nc, nb) in zip(B, norms)]
+    for rnd, upd in enumerate((0, 1, 1)):
+        args = [(nc, nb, 1, 1, 0, upd, 2.0 * (rnd + 1), 1e-3, 1e-30, 9 + 3 * k + rnd, 0.0) for k, (nc, nb) in enumerate(norms)]
+        assert cabi.batch_major_iteration(hip_abi, A, args) == [s.major_iteration(*a) + (s.obj,) for s, a in zip(B, args)], rnd
+    for a, b in zip(A, B):
+        assert np.array_equal(a.Rt, b.Rt) and np.array_equal(a.Gt, b.Gt) and np.array_equal(a.dirt, b.dirt)
+        a.close()
+        b.close()
+    team = sj.sdplr(data=datas[0], r=10, **kw)
+    assert team["obj"] == pytest.approx(plain["obj"], rel=1e-5) and team["max_dual_value"] == pytest.approx(plain["max_dual_value"], rel=1e-5)
+    assert abs(team["iter"] - plain["iter"]) <= max(5, plain["iter"] // 10)
