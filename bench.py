@@ -570,13 +570,19 @@ def other_configs(sj, abi):
     dd = one.dims()
     Ns = 8.0 * dd["n"] * dd["r"]
     ell_bytes = 4.0 * (dd["nnzS"] - dd["n"]) + 8.0 * 4 * dd["n"]
-    it_bytes = 9 * Ns + (2 * Ns + ell_bytes) + 15 * Ns
+    # a team of W workgroups per instance (k_resident.h, TEAM; SDPLR_HIP_TEAM, default 2): every member forms the whole
+    # direction (9N each), the SpMM, the line search and STEP are shared out
+    team = max(1, min(4, int(os.environ.get("SDPLR_HIP_TEAM", "2")))) if dd["n"] >= 128 else 1
+    it_bytes = 9 * Ns * team + (2 * Ns + ell_bytes) + 15 * Ns
     one.close()
     out["config5_batch64"]["roofline"] = {
-        "bound": "l2-request-rate of ONE CU (resident route: a workgroup per instance; 64 of 256 CUs busy with the batch)",
-        "kernel": "k_rs_loop (one inner iteration = SEAM, DIR, SPMM, LSSUM, SOLVE, COMMIT, STEP inside one launch)",
-        "us_per_iteration": us_it, "bytes_per_iteration": it_bytes, "achieved": it_bytes / us_it / 1e3, "peak": 134.0,
-        "unit": "GB/s per CU", "frac": it_bytes / us_it / 1e3 / 134.0, "traffic": None}
+        "bound": f"l2-request-rate of the {team} CU(s) an instance runs on (resident route: a team of {team} workgroup(s) of one XCD per "
+                 f"instance; {64 * team} of 256 CUs busy with the batch)",
+        "kernel": "k_rs_team / k_rs_loop (one inner iteration = SEAM, DIR, SPMM, LSSUM, SOLVE, COMMIT, STEP inside one launch; "
+                  "three team barriers per iteration)",
+        "workgroups_per_instance": team,
+        "us_per_iteration": us_it, "bytes_per_iteration": it_bytes, "achieved": it_bytes / us_it / 1e3, "peak": 134.0 * team,
+        "unit": "GB/s for the team's CUs", "frac": it_bytes / us_it / 1e3 / (134.0 * team), "traffic": None}
     # ---- the reference's batch generator names three more problems (exps/gen_batch_test.jl:3); MinBisection (a rank-one
     # constraint) and CutNorm (2·800 vertices: per-row vectors through global memory) take the resident route too on
     # G1–G9, Lovász-θ (one constraint per edge) the multi-launch edge path ----
