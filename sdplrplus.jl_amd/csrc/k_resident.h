@@ -589,7 +589,7 @@ __device__ __forceinline__ RsRow rs_load_row(const RsLoopArgs& a, int j) {
 // PDROP (A_g is the cost matrix: y_g ≡ 1; the caller vouches that G is the gradient at the device's state, or has fg! run
 // in the prologue): STEP carries G forward — G_new = G_old + 2(αW + d_new∘R_new − d_old∘R_old), as k_fast_step2<…, PDROP>
 // does — and P is neither read nor written: two of STEP's seventeen streams gone, and no P = A_g·R at the loop's entry.
-// TEAM (with PDROP, no rank-one matrix): team_w workgroups run this loop on ONE instance.  Each member forms the whole
+// TEAM (with PDROP): team_w workgroups run this loop on ONE instance.  Each member forms the whole
 // direction in its own LDS (DIR is a ninth of the iteration and needs every row anyway) and takes its share of the rest:
 // the slices trank, trank + W, … of the SpMM, the rows [row_lo, row_hi) of the line-search sums, the commit and STEP.  Three
 // exchanges per iteration through the team's block in global memory, each behind a team barrier: the Gram / norm partials
@@ -617,7 +617,7 @@ __device__ __forceinline__ void rs_loop_run(const RsLoopArgs& a) {
   const int rpm = (n + TW - 1) / TW;
   const int row_lo = TEAM ? min(n, trank * rpm) : 0, row_hi = TEAM ? min(n, row_lo + rpm) : n;
   __shared__ int sh_team_ok;
-  __shared__ double sh_pvg, sh_tflag;
+  __shared__ double sh_pvg, sh_lrpv, sh_tflag;
   double* const xg = a.xch;                                   // [TW][32]
   double* const xl = TEAM ? a.xch + 32 * TW : nullptr;        // [TW][16]
   unsigned* const xi = TEAM ? reinterpret_cast<unsigned*>(a.xch + 48 * TW) : nullptr;
@@ -731,18 +731,20 @@ __device__ __forceinline__ void rs_loop_run(const RsLoopArgs& a) {
         reinterpret_cast<unsigned long long*>(&gd.c)[t] = __builtin_nontemporal_load(reinterpret_cast<const unsigned long long*>(a.c) + t);
     if (tid == 0) {
       sh_pvg = rs_ld_nt(a.pv_raw + a.gid_g);
+      sh_lrpv = has_lr ? rs_ld_nt(a.pv_raw + a.lr.gid) : 0.0;
       sh_tflag = 0.0;
       for (int k = 0; k < 5 * SDPLR_HMAX; k++) gd.red[k] = 0.0;
       gd.nrm[0] = gd.nrm[1] = 0.0;
     }
     __syncthreads();
   }
-  if (has_lr && !a.pre_fg) {   // w0 = Rᵀb and ws = y_c·D·w0 at the point and multipliers the previous g! left
+  // (in a team every member forms them for itself: fg! in the prologue left them in rank 0's LDS only)
+  if (has_lr && (TEAM || !a.pre_fg)) {   // w0 = Rᵀb and ws = y_c·D·w0 at the point and multipliers the previous g! left
     for (long long e = tid; e < N; e += NT) Dl[e] = R[e];
     __syncthreads();
     rs_colsum(Dl, a.lr.B, n, r, w0l);
     __syncthreads();
-    if (tid < r) wsl[tid] = a.y[a.lr.gid] * a.lr.D * w0l[tid];
+    if (tid < r) wsl[tid] = (TEAM ? rs_ld_nt(a.y + a.lr.gid) : a.y[a.lr.gid]) * a.lr.D * w0l[tid];
     __syncthreads();
   }
   // constraint data of this thread's rows: constant over the call except primal_vio_raw, which the thread owns
@@ -1020,9 +1022,11 @@ __device__ __forceinline__ void rs_loop_run(const RsLoopArgs& a) {
         }
         lr_q1 = 2.0 * (a.lr.D * s01);
         lr_q2 = a.lr.D * s11;
-        a.A_RD[kc] = lr_q1;
-        a.A_DD[kc] = lr_q2;
-        lr_pv = a.pv_raw[kc];
+        if (st0) {
+          a.A_RD[kc] = lr_q1;
+          a.A_DD[kc] = lr_q2;
+        }
+        lr_pv = TEAM ? sh_lrpv : a.pv_raw[kc];
         lr_l = a.lam[kc];
         acc[0] += lr_l * lr_pv;
         acc[1] += lr_pv * lr_pv;
@@ -1073,12 +1077,13 @@ __device__ __forceinline__ void rs_loop_run(const RsLoopArgs& a) {
         if (has_lr) {   // commit of the rank-one matrix's slot; W0 ← W0 + α·W1 = R_newᵀb; WS = y_c·D·W0  (k_ls_solve_fast's tail)
           const int kc = a.lr.gid;
           const double vc = lr_pv + al * (al * lr_q2 + lr_q1);
-          a.pv_raw[kc] = vc;
+          if (st0) a.pv_raw[kc] = vc;
+          if (TEAM) sh_lrpv = vc;
           const double pcc = fmax(vc, a.lb[kc]);
-          a.pv[kc] = pcc;
+          if (st0) a.pv[kc] = pcc;
           pv2 += pcc * pcc;
           const double yc = -fmin(a.lam_ub[kc], lr_l - sigma * vc);
-          a.y[kc] = yc;
+          if (st0) a.y[kc] = yc;
           for (int ch = 0; ch < r; ch++) {
             const double w = w0l[ch] + al * w1l[ch];
             w0l[ch] = w;

@@ -734,7 +734,7 @@ int rs_team_w(const S* s) {
   if (s->no_team) return 1;
   const char* e = getenv("SDPLR_HIP_TEAM");
   const int want = e ? atoi(e) : 2;   // (two: a 64-instance batch still fits the GPU twice over; four gains another 13 % per iteration)
-  if (want < 2 || s->n < 128 || s->h < 1 || s->h > 4 || s->lr.ST != 0 || s->no_pdrop || s->ff.gid_g != (int)s->m) return 1;
+  if (want < 2 || s->n < 128 || s->h < 1 || s->h > 4 || s->no_pdrop || s->ff.gid_g != (int)s->m) return 1;
   return std::min(want, SDPLR_RS_TEAM_MAX);
 }
 bool rs_rows_global(const S* s) {

@@ -536,3 +536,25 @@ def test_resident_team_in_batch_calls_and_whole_solves(hip_abi, monkeypatch):
     team = sj.sdplr(data=datas[0], r=10, **kw)
     assert team["obj"] == pytest.approx(plain["obj"], rel=1e-5) and team["max_dual_value"] == pytest.approx(plain["max_dual_value"], rel=1e-5)
     assert abs(team["iter"] - plain["iter"]) <= max(5, plain["iter"] // 10)
+
+
+def test_resident_team_with_a_rank_one_constraint(hip_abi, oracle_abi, monkeypatch):
+    """MinBisection on Gset G2 in a team: every member keeps Rᵀb, Dᵀb and the slot's primal_vio_raw for itself (same values in
+    every member), rank 0 stores them.  Against the one-workgroup loop and the oracle after 10 iterations (on this family
+    differences in the order of a sum grow ≈ 1.7× per iteration: scripts/probes/diag_mb.py)."""
+    data = problems.minimum_bisection_data(gset("G2"))
+    normC, normb = data.normC(), float(np.linalg.norm(data.b))
+    monkeypatch.setenv("SDPLR_HIP_TEAM", "1")
+    one, o = pair(hip_abi, oracle_abi, data, 10, 0)
+    r1 = run(one, normC, normb, 10, one.fg(normC, normb))
+    ro = run(o, normC, normb, 10, o.fg(normC, normb))
+    for W in (2, 4):
+        monkeypatch.setenv("SDPLR_HIP_TEAM", str(W))
+        team = make_solver(hip_abi, data, 10, seed=0)[0]
+        rt = run(team, normC, normb, 10, team.fg(normC, normb))
+        assert rt[4] == r1[4] == 10 and team.stats()["resident_loops"] == 1
+        assert np.allclose(rt[:3], r1[:3], rtol=1e-8) and rel(team.Rt, one.Rt) < 1e-7
+        assert np.allclose(rt[:3], ro[:3], rtol=1e-7) and rel(team.Rt, o.Rt) < 1e-6
+        assert np.array_equal(team.get_vec(cabi.V_PV_RAW)[[-2, -1]] != 0, [True, True])
+        team.close()
+    one.close(); o.close()
