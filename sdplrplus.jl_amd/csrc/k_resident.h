@@ -1538,6 +1538,18 @@ __device__ __forceinline__ void rs_lanczos_ell_run(const RsLzEllArgs& a) {
   double beta_prev = 0.0;
   int steps = 0;
   const double tiny = sqrt((double)n) * 2.220446049250313e-16;
+  constexpr int SLC = 2;
+  int c_jp[SLC], c_len[SLC], c_l0[SLC], c_w[SLC];
+#pragma unroll
+  for (int q = 0; q < SLC; q++) {
+    const int sl = wave + q * SDPLR_RS_NW;
+    const bool in = sl < a.E.n_slices;
+    const int idx = (in ? sl : 0) * 64 + wl;
+    c_jp[q] = in ? a.E.perm[idx] : -1;
+    c_len[q] = in ? a.E.len[idx] : 0;
+    c_l0[q] = in ? a.E.sptr[sl] : 0;
+    c_w[q] = in ? a.E.sptr[sl + 1] - c_l0[q] : 0;
+  }
   for (int it = 0; it < a.q; it++) {
     // Av = S·v  (:483), one row per lane
     double dot = 0.0;
@@ -1547,12 +1559,7 @@ __device__ __forceinline__ void rs_lanczos_ell_run(const RsLzEllArgs& a) {
       for (int i = tid; i < n; i += NT) t += a.lr.B[i] * v[i];
       lr_bv = lr_coef * bsum(t);
     }
-#pragma nounroll
-    for (int sl = wave; sl < a.E.n_slices; sl += SDPLR_RS_NW) {
-      const int idx = sl * 64 + wl;
-      const int jp = a.E.perm[idx];
-      const int len = a.E.len[idx];
-      const int l0 = a.E.sptr[sl], width = a.E.sptr[sl + 1] - l0;
+    auto do_slice = [&](int sl, int jp, int len, int l0, int width) {
       double acc = 0.0;
       if (ELL_LDS) {
         const unsigned* el = ell + (size_t)lp[sl] * 64 + wl;
@@ -1604,6 +1611,16 @@ __device__ __forceinline__ void rs_lanczos_ell_run(const RsLzEllArgs& a) {
         av[jp] = t;
         dot += vj * t;
       }
+    };
+    // (a wave's first SLC slices — all of them up to n = 1024 — keep their row, length and extent in registers: fetched from
+    // global memory in every step they were a dependent round trip in front of each slice, ≈ 1.6 of the step's 5.8 µs)
+#pragma unroll
+    for (int q = 0; q < SLC; q++)
+      if (wave + q * SDPLR_RS_NW < a.E.n_slices) do_slice(wave + q * SDPLR_RS_NW, c_jp[q], c_len[q], c_l0[q], c_w[q]);
+#pragma nounroll
+    for (int sl = wave + SLC * SDPLR_RS_NW; sl < a.E.n_slices; sl += SDPLR_RS_NW) {
+      const int idx = sl * 64 + wl;
+      do_slice(sl, a.E.perm[idx], a.E.len[idx], a.E.sptr[sl], a.E.sptr[sl + 1] - a.E.sptr[sl]);
     }
     const double al = bsum(dot);                                  // alpha[i] = v'·Av  (:484)
     double nn = 0.0;
