@@ -1552,6 +1552,12 @@ __device__ __forceinline__ void rs_lanczos_ell_run(const RsLzEllArgs& a) {
     c_l0[q] = in ? a.E.sptr[sl] : 0;
     c_w[q] = in ? a.E.sptr[sl + 1] - c_l0[q] : 0;
   }
+#ifdef SDPLR_RS_STAMPS
+  unsigned long long lz_acc[5] = {0, 0, 0, 0, 0}, lz_last = __builtin_amdgcn_s_memtime();
+#define LZ_STAMP(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); lz_acc[i] += t_ - lz_last; lz_last = t_; } while (0)
+#else
+#define LZ_STAMP(i) do { } while (0)
+#endif
   for (int it = 0; it < a.q; it++) {
     // Av = S·v  (:483), one row per lane
     double dot = 0.0;
@@ -1624,7 +1630,9 @@ __device__ __forceinline__ void rs_lanczos_ell_run(const RsLzEllArgs& a) {
       const int idx = sl * 64 + wl;
       do_slice(sl, a.E.perm[idx], a.E.len[idx], a.E.sptr[sl], a.E.sptr[sl + 1] - a.E.sptr[sl]);
     }
+    LZ_STAMP(0);
     const double al = bsum(dot);                                  // alpha[i] = v'·Av  (:484)
+    LZ_STAMP(1);
     double nn = 0.0;
     for (int i = tid; i < n; i += NT) {
       double x = av[i];
@@ -1633,7 +1641,9 @@ __device__ __forceinline__ void rs_lanczos_ell_run(const RsLzEllArgs& a) {
       av[i] = x;
       nn += x * x;
     }
+    LZ_STAMP(2);
     const double be = sqrt(bsum(nn));                             // beta[i] = ‖Av‖  (:492)
+    LZ_STAMP(3);
     steps = it + 1;
     if (tid == 0) {
       a.alpha_out[it] = al;
@@ -1647,7 +1657,13 @@ __device__ __forceinline__ void rs_lanczos_ell_run(const RsLzEllArgs& a) {
     v = av;
     av = t;
     beta_prev = be;
+    LZ_STAMP(4);
   }
+#ifdef SDPLR_RS_STAMPS
+  if (tid == 0 && steps > 20)
+    printf("[rs_lanczos] steps %d  cycles/step: spmv %llu dot-sum %llu update %llu norm-sum %llu scale %llu\n", steps, lz_acc[0] / steps,
+           lz_acc[1] / steps, lz_acc[2] / steps, lz_acc[3] / steps, lz_acc[4] / steps);
+#endif
   if (tid == 0) {
     a.c->lz_steps = steps;
     a.c->lz_beta_prev = beta_prev;
@@ -1663,10 +1679,22 @@ __device__ __forceinline__ void rs_lanczos_ell_run(const RsLzEllArgs& a) {
   // The smallest eigenvalue of SymTridiagonal(alpha .+ 1, beta) minus 1 (:502-513) — the host routine's bisection
   // (sdplr_hip_tridiag_mineig), with 64 trial points per round by wave 0 until the bracket is a few ulps wide and the
   // scalar loop finishes it: the bracket it ends on is the one the sequential bisection ends on.
+  // (α and β go to LDS first — the Lanczos vectors are done with: read from global memory inside the Sturm recurrence, two
+  // loads in front of every one of its k dependent divisions, the bisection took ≈ 300 of the run's 1050 µs)
+  __syncthreads();
+  const bool tri_lds = steps <= n;
+  if (tri_lds) {
+    __threadfence_block();
+    for (int i = tid; i < steps; i += NT) {
+      av[i] = a.alpha_out[i];
+      vpre[i] = a.beta_out[i];
+    }
+  }
+  __syncthreads();
   if (wave == 0) {
     __threadfence_block();
-    const double* al = a.alpha_out;   // (written by thread 0 above: same wave, global memory, fenced)
-    const double* be = a.beta_out;
+    const double* al = tri_lds ? av : a.alpha_out;   // (written by thread 0 above: same wave, global memory, fenced)
+    const double* be = tri_lds ? vpre : a.beta_out;
     const int k = steps;
     double ev;
     if (k == 1) {
