@@ -592,12 +592,13 @@ __device__ __forceinline__ RsRow rs_load_row(const RsLoopArgs& a, int j) {
 // in the prologue): STEP carries G forward — G_new = G_old + 2(αW + d_new∘R_new − d_old∘R_old), as k_fast_step2<…, PDROP>
 // does — and P is neither read nor written: two of STEP's seventeen streams gone, and no P = A_g·R at the loop's entry.
 // TEAM (with PDROP): team_w workgroups run this loop on ONE instance.  Each member forms the whole
-// direction in its own LDS (DIR is a ninth of the iteration and needs every row anyway) and takes its share of the rest:
-// the slices trank, trank + W, … of the SpMM, the rows [row_lo, row_hi) of the line-search sums, the commit and STEP.  Three
-// exchanges per iteration through the team's block in global memory, each behind a team barrier: the Gram / norm partials
-// of STEP (→ SEAM, made by every member for itself: same sums, same order, the same control block in every member), the
-// rows of W with their dots (SpMM → line search), the ten line-search sums (→ SOLVE, again by every member).  Rank 0 alone
-// runs the prologue, stores the scalars of the extra slot and the control block, and leaves dirt.
+// direction in its own LDS (DIR is a ninth of the iteration and needs every row anyway) and owns the rows [row_lo, row_hi) in
+// everything else: its slices of the sliced ELL hold exactly those rows (build_rs_ell cuts the matrix for the team), so the
+// SpMM's rows of W and their dots, the line-search sums, the commit and STEP never cross members.  Two exchanges per
+// iteration through the team's block in global memory, each behind a team barrier: the Gram / norm partials of STEP (→ SEAM,
+// made by every member for itself: same sums, same order, the same control block in every member — and the barrier is also
+// what makes every member's rows of G and of the history visible to DIR), and the ten line-search sums (→ SOLVE, again by
+// every member).  Rank 0 alone runs the prologue, stores the scalars of the extra slot and the control block, and leaves dirt.
 template <int VEC, int HM, bool PDROP, bool TEAM = false>
 __device__ __forceinline__ void rs_loop_run(const RsLoopArgs& a) {
   static_assert(!TEAM || PDROP, "teams run the P-less loop");
@@ -903,23 +904,17 @@ __device__ __forceinline__ void rs_loop_run(const RsLoopArgs& a) {
     {
       const RsDots dots{R, rdl, ddl};
       if constexpr (TEAM) {
-        RsEll Et = a.E;
-        Et.sl0 = trank;
-        Et.sl_step = TW;
+        RsEll Et = a.E;   // (this member's slices hold exactly its rows: W and the dots stay with their owner)
+        const int spp = (rpm + 63) / 64;   // slices per member: build_rs_ell cuts the matrix into runs of ⌈rpm/64⌉ slices
+        Et.sl0 = trank * spp;
+        Et.n_slices = min(a.E.n_slices, (trank + 1) * spp);
         rs_ell_spmm_dots<VEC>(Et, Dl, n, r, a.W, dots, rw_sum, dw_sum);
       } else {
         rs_ell_spmm_dots<VEC>(a.E, Dl, n, r, a.W, dots, rw_sum, dw_sum);
       }
     }
-    if constexpr (TEAM) {   // the rows of W and their dots → the members that own them in the line search and STEP
-      if (!rs_team_barrier(ts, &sh_team_ok)) {
-        if (tid == 0) { gd.c.err = SDPLR_ERR_TEAM_TIMEOUT; gd.c.done = 1; }
-        __syncthreads();
-        break;
-      }
-    } else {
-      __syncthreads();
-    }
+    if (TEAM) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (as in front of a team barrier: without it the team kernels' register allocation tips into 600 bytes of scratch)
+    __syncthreads();
     RS_STAMP(7);
     RS_STAMP(2);
     double acc[10];
@@ -934,7 +929,7 @@ __device__ __forceinline__ void rs_loop_run(const RsLoopArgs& a) {
         if (rw.k < 0) return;
         int kk = rw.k;
         asm volatile("" : "+v"(kk));   // (opaque: see commit_row)
-        const double rd = TEAM ? rs_ld_nt(rdl + j) : rdl[j], dd = TEAM ? rs_ld_nt(ddl + j) : ddl[j];
+        const double rd = rdl[j], dd = ddl[j];
         const double q1 = rw.v * (rd + rd), q2 = rw.v * dd;
         a.A_RD[kk] = q1;
         a.A_DD[kk] = q2;
@@ -1118,7 +1113,7 @@ __device__ __forceinline__ void rs_loop_run(const RsLoopArgs& a) {
           asm volatile("" : "+v"(kk));
           const int kb = kk < m ? kk : 0;
           const double lub = (kk < m) ? a.lam_ub[kb] : 0.0, lbv = (kk < m) ? a.lb[kb] : 0.0;
-          const double rd = TEAM ? rs_ld_nt(rdl + j) : rdl[j], dd = TEAM ? rs_ld_nt(ddl + j) : ddl[j];
+          const double rd = rdl[j], dd = ddl[j];
           const double q1 = rw.v * (rd + rd), q2 = rw.v * dd;
           const double v = rw.pvr + al * (al * q2 + q1);     // src/linesearch.jl:118
           rw.pvr = v;
@@ -1174,7 +1169,7 @@ __device__ __forceinline__ void rs_loop_run(const RsLoopArgs& a) {
           const vecd<VEC> x0 = ldrow<VEC>(R + e), gold = ldrow<VEC>(Gm + e);
           vecd<VEC> p0;
           if (!PDROP) p0 = ldrow<VEC>(a.P + e);
-          const vecd<VEC> w = TEAM ? ldrow_nt<VEC>(a.W + e) : ldrow<VEC>(a.W + e);   // (rows of W come from the member whose slice holds them)
+          const vecd<VEC> w = ldrow<VEC>(a.W + e);
           const vecd<VEC> d = ldrow<VEC>(Dl + e);
           vecd<VEC> sv[HM], yv[HM];
           if (upd) {

@@ -145,6 +145,8 @@ struct sdplr_hip_solver {
   bool no_lshead = false;    // SDPLR_HIP_NO_LSHEAD: the line-search scalar stage stays a kernel of its own
   bool no_team = false;      // a team launch found its members on different XCDs: this handle runs without teams from then on
   double* rs_xch = nullptr;  // the team's exchange block (k_resident.h, RsLoopArgs::xch)
+  int rs_ell_parts = 1;      // the team size the sliced ELL was cut for, and each member's first slice
+  int rs_ell_part_sl[SDPLR_RS_TEAM_MAX + 1] = {0, 0, 0, 0, 0};
   bool no_pdrop = false;     // SDPLR_HIP_NO_PDROP: the step kernel keeps P = A_g·R (P += α·W) instead of carrying G forward
   bool pdrop_now = false;    // this inner loop runs the P-less step kernel (decided at loop entry)
   // G is the gradient at the device's (R, λ, σ) with y as its g! left it: true after fg! / g! / an inner loop, cleared by
@@ -730,12 +732,17 @@ constexpr size_t RS_LDS_MAX = 150 * 1024;   // dynamic LDS of a resident kernel 
 // a CU has but the direction alone fits, the three per-row vectors move to global memory (k_resident.h, RsLoopArgs::rowvec).
 // Workgroups per instance on the resident loop (k_resident.h, TEAM): a function of the instance alone — never of the batch it
 // travels in — so that batch calls and single calls run the same kernel on it.  The P-less loop without a rank-one matrix.
-int rs_team_w(const S* s) {
+int rs_team_want(const S* s) {
   if (s->no_team) return 1;
   const char* e = getenv("SDPLR_HIP_TEAM");
   const int want = e ? atoi(e) : 2;   // (two: a 64-instance batch still fits the GPU twice over; four gains another 13 % per iteration)
   if (want < 2 || s->n < 128 || s->h < 1 || s->h > 4 || s->no_pdrop || s->ff.gid_g != (int)s->m) return 1;
   return std::min(want, SDPLR_RS_TEAM_MAX);
+}
+// … and the sliced ELL has to have been cut for that team (build_rs_ell: the members' row ranges are runs of whole slices)
+int rs_team_w(const S* s) {
+  const int want = rs_team_want(s);
+  return (want > 1 && want == s->rs_ell_parts) ? want : 1;
 }
 bool rs_rows_global(const S* s) {
   const size_t full = ((size_t)rs_npad(s->n, s->r) + 3 * (size_t)s->n + 4 * (size_t)s->r) * sizeof(double);
@@ -1175,13 +1182,25 @@ int build_rs_ell(S* s, const std::vector<int>& g_ptr, const std::vector<int>& g_
       if (!have_one) { one = g_val[q]; have_one = true; }
       else if (!(g_val[q] == one)) uniform = false;
     }
-  std::vector<int> order(n);
-  for (int64_t j = 0; j < n; j++) order[j] = (int)j;
-  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return len[a] > len[b]; });
-  const int S_ = (int)((n + 63) / 64);
-  std::vector<int> perm((size_t)S_ * 64, -1), plen((size_t)S_ * 64, 0), sptr(S_ + 1, 0);
-  for (int64_t t = 0; t < n; t++) { perm[t] = order[t]; plen[t] = len[order[t]]; }
-  for (int sl = 0; sl < S_; sl++) sptr[sl + 1] = sptr[sl] + plen[(size_t)sl * 64];   // the slice's first row is its longest
+  // Rows in order of decreasing length, 64 to a slice — within each TEAM MEMBER's range of rows (k_resident.h, TEAM: member w of
+  // W owns rows [w·⌈n/W⌉, (w+1)·⌈n/W⌉) in every phase, so its slices hold exactly those rows and the SpMM's output never
+  // crosses members); one range, the whole matrix, without a team.  A slice's lanes past its range's end hold no row (−1).
+  const int parts = rs_team_want(s);
+  const int64_t rpm = (n + parts - 1) / parts;
+  std::vector<int> perm, plen, sptr(1, 0);
+  s->rs_ell_parts = parts;
+  for (int w = 0; w < parts; w++) {
+    const int64_t lo = std::min<int64_t>(n, w * rpm), hi = std::min<int64_t>(n, lo + rpm);
+    s->rs_ell_part_sl[w] = (int)(perm.size() / 64);
+    std::vector<int> order((size_t)(hi - lo));
+    for (int64_t j = lo; j < hi; j++) order[j - lo] = (int)j;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return len[a] > len[b]; });
+    for (int v : order) { perm.push_back(v); plen.push_back(len[v]); }
+    while (perm.size() % 64) { perm.push_back(-1); plen.push_back(0); }
+  }
+  for (int w = parts; w <= SDPLR_RS_TEAM_MAX; w++) s->rs_ell_part_sl[w] = (int)(perm.size() / 64);
+  const int S_ = (int)(perm.size() / 64);
+  for (int sl = 0; sl < S_; sl++) sptr.push_back(sptr[sl] + plen[(size_t)sl * 64]);   // the slice's first row is its longest
   s->rs_ell_pair_lines = 0;
   for (int sl = 0; sl < S_; sl++) s->rs_ell_pair_lines += (size_t)(sptr[sl + 1] - sptr[sl] + 1) / 2;
   std::vector<unsigned> ent((size_t)std::max(sptr[S_], 1) * 64, 0u);

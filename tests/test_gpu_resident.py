@@ -495,7 +495,7 @@ def test_resident_team_matches_the_single_workgroup_loop(hip_abi, oracle_abi, mo
     monkeypatch.setenv("SDPLR_HIP_TEAM", str(W))
     team = make_solver(hip_abi, data, r, seed=0)[0]
     st = team.fg(normC, normb)
-    assert st == s1
+    assert np.allclose(st, s1, rtol=1e-13)     # (the sliced ELL is cut for the team: fg!'s sums run over the rows in another order)
     rt = run(team, normC, normb, 25, st)
     ro = run(o, normC, normb, 25, o.fg(normC, normb))
     assert rt[4] == r1[4] == ro[4] == 25 and rt[5] == r1[5]
