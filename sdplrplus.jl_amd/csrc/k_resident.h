@@ -761,15 +761,16 @@ __device__ __forceinline__ void rs_loop_run(const RsLoopArgs& a) {
     if (j < row_hi) rw_[q] = rs_load_row(a, j);
     else { rw_[q].k = -1; rw_[q].v = rw_[q].lam = rw_[q].pvr = 0.0; }
   }
-  if (PDROP && !a.pre_fg) {   // d_j at the multipliers the previous g! left (fg! in the prologue has just formed them)
+  // (in a team every member forms its rows' d_j itself: fg! in the prologue left them in rank 0's LDS)
+  if (PDROP && (TEAM || !a.pre_fg)) {   // d_j at the multipliers the previous g! left (fg! in the prologue has just formed them)
 #pragma unroll
     for (int q = 0; q < RPT; q++) {
       const int j = row_lo + tid + q * NT;
-      if (j < row_hi) djl[j] = (rw_[q].k >= 0) ? rw_[q].v * a.y[rw_[q].k] : 0.0;
+      if (j < row_hi) djl[j] = (rw_[q].k >= 0) ? rw_[q].v * (TEAM ? rs_ld_nt(a.y + rw_[q].k) : a.y[rw_[q].k]) : 0.0;
     }
     for (int j = row_lo + tid + RPT * NT; j < row_hi; j += NT) {
       const int k = a.row_k[j];
-      djl[j] = (k >= 0) ? a.row_v[j] * a.y[k] : 0.0;
+      djl[j] = (k >= 0) ? a.row_v[j] * (TEAM ? rs_ld_nt(a.y + k) : a.y[k]) : 0.0;
     }
   }
   if (!PDROP && a.refresh_P && !a.pre_fg) {   // P = A_g·R (entry of the loop: R was written outside, or the incremental P is due for a refresh)

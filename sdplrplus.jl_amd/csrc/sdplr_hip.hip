@@ -746,7 +746,6 @@ int rs_team_w(const S* s) {
 }
 bool rs_rows_global(const S* s) {
   const size_t full = ((size_t)rs_npad(s->n, s->r) + 3 * (size_t)s->n + 4 * (size_t)s->r) * sizeof(double);
-  if (rs_team_w(s) > 1) return true;   // (the members of a team share the per-row vectors through global memory)
   return full > RS_LDS_MAX && getenv("SDPLR_HIP_NO_RESIDENT_ROWVEC") == nullptr;
 }
 size_t rs_loop_lds(const S* s) {
