@@ -531,6 +531,7 @@ struct RsLoopArgs {
   // arrival counter, failure flag, the members' XCC ids (zeroed by the host before the launch).
   int team_w, team_rank;
   double* xch;
+  int team_test_fail;                   // tests: the placement check answers "not one XCD" (SDPLR_HIP_TEAM_TEST_FAIL)
 };
 #define SDPLR_RS_TEAM_MAX 4
 #define SDPLR_RS_XCH_DOUBLES (48 * SDPLR_RS_TEAM_MAX + 8)
@@ -662,7 +663,7 @@ __device__ __forceinline__ void rs_loop_run(const RsLoopArgs& a) {
         const unsigned x0 = __hip_atomic_load(xi + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         int same = 1;
         for (int k = 1; k < TW; k++) same &= (__hip_atomic_load(xi + 2 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == x0) ? 1 : 0;
-        sh_team_ok = same;
+        sh_team_ok = a.team_test_fail ? 0 : same;
       }
       __syncthreads();
       if (!sh_team_ok) code = SDPLR_ERR_TEAM_PLACEMENT;

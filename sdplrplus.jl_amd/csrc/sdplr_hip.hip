@@ -2865,6 +2865,7 @@ int enq_resident_loop(S* s, double time_budget_s, bool refresh_P, bool pre_lambd
   if (W > 1) {   // a team: W workgroups of one XCD (blocks 0, 8, …: k_resident.h)
     a.team_w = W;
     a.xch = s->rs_xch;
+    a.team_test_fail = getenv("SDPLR_HIP_TEAM_TEST_FAIL") != nullptr;
     HIPCK(s, hipMemsetAsync(s->rs_xch + 48 * W, 0, 8 * sizeof(double), s->stream));   // arrival counter, failure flag, XCC ids
     RS_VEC_DISPATCH(s, ({ RS_SET_ATTR((k_rs_team<VEC, 4>)); k_rs_team<VEC, 4><<<8 * (W - 1) + 1, SDPLR_RS_NT, lds, s->stream>>>(a); }))
   } else if (pdrop) { RS_VEC_DISPATCH(s, ({ RS_SET_ATTR((k_rs_loop<VEC, 4, true>)); k_rs_loop<VEC, 4, true><<<1, SDPLR_RS_NT, lds, s->stream>>>(a); })) }
@@ -4533,6 +4534,7 @@ int32_t sdplr_hip_batch_major_iteration(int32_t count, sdplr_hip_major_item* it)
           if (g_w > 1) {
             a.team_w = g_w;
             a.xch = reinterpret_cast<double*>(bb.dev + xch_off) + k * SDPLR_RS_XCH_DOUBLES;
+            a.team_test_fail = getenv("SDPLR_HIP_TEAM_TEST_FAIL") != nullptr;
           }
           tab[k] = a;
           lds = std::max(lds, rs_loop_lds(sk));

@@ -558,3 +558,31 @@ def test_resident_team_with_a_rank_one_constraint(hip_abi, oracle_abi, monkeypat
         assert np.array_equal(team.get_vec(cabi.V_PV_RAW)[[-2, -1]] != 0, [True, True])
         team.close()
     one.close(); o.close()
+
+
+def test_resident_team_that_is_not_on_one_xcd_falls_back(hip_abi, monkeypatch):
+    """The members check their placement before anything is touched (HW_REG_XCC_ID; dispatch order is observed, never
+    promised).  SDPLR_HIP_TEAM_TEST_FAIL makes the check answer "not one XCD": the launch returns untouched, the host runs the
+    instance without a team — for good — and the results are those of the one-workgroup loop on the same handle layout;
+    through the single entry point and through a batch call."""
+    datas = [problems.maxcut_data(gset(g)) for g in ("G1", "G2")]
+    norms = [(d.normC(), float(np.linalg.norm(d.b))) for d in datas]
+    args = [(nc, nb, 1, 1, 0, 0, 2.0, 1e-3, 1e-30, 12, 0.0) for nc, nb in norms]
+    A = [make_solver(hip_abi, d, 10, seed=3)[0] for d in datas]       # teams of two
+    ref = [s.major_iteration(*a) + (s.obj,) for s, a in zip(A, args)]
+    monkeypatch.setenv("SDPLR_HIP_TEAM_TEST_FAIL", "1")
+    B = [make_solver(hip_abi, d, 10, seed=3)[0] for d in datas]       # single calls: fall back inside the call
+    got = [s.major_iteration(*a) + (s.obj,) for s, a in zip(B, args)]
+    C_ = [make_solver(hip_abi, d, 10, seed=3)[0] for d in datas]      # a batch call: the items come back through the single route
+    gotb = cabi.batch_major_iteration(hip_abi, C_, args)
+    monkeypatch.delenv("SDPLR_HIP_TEAM_TEST_FAIL")
+    for r0, r1, r2 in zip(ref, got, gotb):
+        assert r1 == r2                                               # (both ran the one-workgroup loop on the same layout)
+        assert r0[4] == r1[4] and np.allclose(r0[:3], r1[:3], rtol=1e-9)
+    for a, b, c in zip(A, B, C_):
+        assert np.array_equal(b.Rt, c.Rt) and rel(a.Rt, b.Rt) < 1e-8
+    # … and they stay without a team: the next call (flag gone) still equals the one-workgroup result of the twin
+    nxt = [(nc, nb, 1, 1, 0, 1, 4.0, 1e-3, 1e-30, 9, 0.0) for nc, nb in norms]
+    assert [s.major_iteration(*a) for s, a in zip(B, nxt)] == [s.major_iteration(*a) for s, a in zip(C_, nxt)]
+    for s_ in A + B + C_:
+        s_.close()
