@@ -14,7 +14,8 @@ N = int(sys.argv[2]) if len(sys.argv) > 2 else 60
 rows = []
 for t in range(N):
     fam = FAMS[int(rng.integers(len(FAMS)))]
-    n = int(rng.integers(8, 50)); p = float(rng.uniform(0.1, 0.5)); r = int(rng.choice([2, 3, 5, 8]))
+    # (STRESS_NMIN / STRESS_NMAX: sizes from 128 up put the equality-constrained families on teams of workgroups, k_resident.h)
+    n = int(rng.integers(int(os.environ.get("STRESS_NMIN", "8")), int(os.environ.get("STRESS_NMAX", "50")))); p = float(rng.uniform(0.1, 0.5)); r = int(rng.choice([2, 3, 5, 8]))
     tol = float(rng.choice([1e-2, 1e-3]))
     try:
         data, *_ = make_data(fam, int(rng.integers(1 << 30)), n, p)
