@@ -316,6 +316,24 @@ struct DevPool {
   std::map<int, std::vector<hipStream_t>> streams_free;
   std::map<int, std::vector<hipEvent_t>> events_free;   // (an event belongs to the device it was created on)
   size_t cached = 0;
+  // Slabs: blocks of ≤ SLAB_ITEM bytes are carved out of 64-MiB allocations instead of being hipMalloc'ed one by one — the first
+  // batch of 64 small instances made ≈ 750 hipMalloc calls (45 ms of host time over its eight set-up threads: the first
+  // set-up 26 ms against 18 ms later; with slabs 20 ms); carved blocks live in the free lists like any other and go back to the runtime with their slab, when
+  // pool_trim finds every block of it free.  SDPLR_HIP_NO_SLAB=1: every block its own allocation.
+  struct Slab {
+    int dev;
+    char* base;
+    size_t size, used, n_carved, n_cached;
+  };
+  std::vector<Slab> slabs;
+  std::mutex slab_mu;
+  const bool no_slab = getenv("SDPLR_HIP_NO_SLAB") != nullptr;
+  static constexpr size_t SLAB_BYTES = (size_t)64 << 20, SLAB_ITEM = (size_t)8 << 20;
+  int slab_of(const void* p) const {
+    for (size_t i = 0; i < slabs.size(); i++)
+      if (slabs[i].base != nullptr && (const char*)p >= slabs[i].base && (const char*)p < slabs[i].base + slabs[i].size) return (int)i;
+    return -1;
+  }
   const bool off = getenv("SDPLR_HIP_NO_POOL") != nullptr;
   static constexpr size_t MAX_BLOCK = (size_t)16 << 20;
   // most bytes of device memory kept cached (SDPLR_HIP_POOL_MAX_MB; default 4 GiB: a lockstep batch has all of its
@@ -327,9 +345,20 @@ DevPool& pool() {
   return *p;
 }
 void pool_trim();
+// sizes are rounded up to classes an eighth of a power of two apart (≤ 12.5 % more): the arrays of two instances of one family
+// differ by a few hundred bytes (their nonzero counts), and a free list keyed by the exact size served only the very same
+// instance again
+size_t pool_size_class(size_t bytes) {
+  bytes = (std::max<size_t>(bytes, 1) + 255) / 256 * 256;
+  if (bytes <= 4096) return bytes;
+  size_t p2 = 1;
+  while (p2 * 2 <= bytes) p2 *= 2;
+  const size_t step = std::max<size_t>(256, p2 / 8);
+  return (bytes + step - 1) / step * step;
+}
 hipError_t pool_malloc(void** out, size_t bytes) {
   DevPool& P = pool();
-  bytes = (std::max<size_t>(bytes, 1) + 255) / 256 * 256;
+  bytes = P.off ? (std::max<size_t>(bytes, 1) + 255) / 256 * 256 : pool_size_class(bytes);
   int dev = 0;
   (void)hipGetDevice(&dev);
   if (!P.off && bytes <= DevPool::MAX_BLOCK) {
@@ -340,7 +369,38 @@ hipError_t pool_malloc(void** out, size_t bytes) {
       it->second.pop_back();
       P.cached -= bytes;
       P.live[*out] = {dev, bytes};
+      const int sl = P.slab_of(*out);
+      if (sl >= 0) P.slabs[sl].n_cached--;
       return hipSuccess;
+    }
+  }
+  if (!P.off && !P.no_slab && bytes <= DevPool::SLAB_ITEM) {   // carve it out of a slab
+    auto try_carve = [&]() -> bool {
+      std::lock_guard<std::mutex> g(P.mu);
+      for (auto& sb : P.slabs)
+        if (sb.base != nullptr && sb.dev == dev && sb.used + bytes <= sb.size) {
+          *out = sb.base + sb.used;
+          sb.used += bytes;
+          sb.n_carved++;
+          P.live[*out] = {dev, bytes};
+          return true;
+        }
+      return false;
+    };
+    if (try_carve()) return hipSuccess;
+    {
+      std::lock_guard<std::mutex> one(P.slab_mu);   // (one new slab at a time: eight set-up threads miss together at the start of a batch)
+      if (try_carve()) return hipSuccess;
+      void* base = nullptr;
+      if (hipMalloc(&base, DevPool::SLAB_BYTES) == hipSuccess) {
+        {
+          std::lock_guard<std::mutex> g(P.mu);
+          P.slabs.push_back(DevPool::Slab{dev, (char*)base, DevPool::SLAB_BYTES, 0, 0, 0});
+        }
+        if (try_carve()) return hipSuccess;
+      } else {
+        (void)hipGetLastError();   // (no room for a slab: the block gets an allocation of its own below)
+      }
     }
   }
   hipError_t e = hipMalloc(out, bytes);
@@ -364,7 +424,9 @@ void pool_free(void* p) {
     if (it != P.live.end()) {
       const auto key = it->second;
       P.live.erase(it);
-      if (key.second <= DevPool::MAX_BLOCK && P.cached + key.second <= P.MAX_CACHED) {
+      const int sl = P.slab_of(p);
+      if (sl >= 0) P.slabs[sl].n_cached++;
+      if (sl >= 0 || (key.second <= DevPool::MAX_BLOCK && P.cached + key.second <= P.MAX_CACHED)) {   // (a slab's blocks cannot go back one by one)
         P.free_blocks[key].push_back(p);
         P.cached += key.second;
         return;
@@ -468,18 +530,40 @@ void pool_trim() {
   std::vector<void*> pinned, chunks;
   std::map<int, std::vector<hipStream_t>> streams;
   std::map<int, std::vector<hipEvent_t>> events;
+  std::vector<std::pair<int, void*>> slab_bases;
   {
     std::lock_guard<std::mutex> g(P.mu);
     blocks.swap(P.free_blocks);
+    // the blocks of a slab that still has a live block stay cached; a slab all of whose blocks are free goes back whole
+    for (auto& kv : blocks) {
+      std::vector<void*> rest;
+      for (void* q : kv.second) {
+        const int sl = P.slab_of(q);
+        if (sl < 0) { rest.push_back(q); continue; }
+        DevPool::Slab& sb = P.slabs[sl];
+        if (sb.n_cached == sb.n_carved) continue;                       // (freed with its slab below)
+        P.free_blocks[kv.first].push_back(q);
+      }
+      kv.second.swap(rest);
+    }
+    size_t still = 0;
+    for (auto& kv : P.free_blocks) still += kv.first.second * kv.second.size();
+    for (auto& sb : P.slabs)
+      if (sb.base != nullptr && sb.n_cached == sb.n_carved) {
+        slab_bases.push_back({sb.dev, (void*)sb.base});
+        sb.base = nullptr;
+        sb.size = sb.used = sb.n_carved = sb.n_cached = 0;
+      }
     pinned.swap(P.pinned_free);
     chunks.swap(P.pinned_chunks_free);
     streams.swap(P.streams_free);
     events.swap(P.events_free);
-    P.cached = 0;
+    P.cached = still;
   }
   int cur = 0;
   (void)hipGetDevice(&cur);
   for (auto& kv : blocks) { (void)hipSetDevice(kv.first.first); for (void* q : kv.second) (void)hipFree(q); }
+  for (auto& sb : slab_bases) { (void)hipSetDevice(sb.first); (void)hipFree(sb.second); }
   for (auto& kv : streams) { (void)hipSetDevice(kv.first); for (hipStream_t st : kv.second) (void)hipStreamDestroy(st); }
   for (auto& kv : events) { (void)hipSetDevice(kv.first); for (hipEvent_t e : kv.second) (void)hipEventDestroy(e); }
   (void)hipSetDevice(cur);
