@@ -350,7 +350,7 @@ void pool_trim();
 // instance again
 size_t pool_size_class(size_t bytes) {
   bytes = (std::max<size_t>(bytes, 1) + 255) / 256 * 256;
-  if (bytes <= 4096) return bytes;
+  if (bytes <= 4096 || bytes > ((size_t)16 << 20)) return bytes;   // (blocks the pool does not keep are not padded)
   size_t p2 = 1;
   while (p2 * 2 <= bytes) p2 *= 2;
   const size_t step = std::max<size_t>(256, p2 / 8);
