@@ -344,8 +344,11 @@ int32_t sdplr_hip_factor_dot(sdplr_hip_solver* s, int32_t slot_a, int32_t slot_b
  * (sdplr_hip_batch_*), out[12] the inner loops (calls) that ran the step kernel WITHOUT P = A_g·R (the gradient carried
  * forward from G_old: cost matrix = the general sparse matrix, no low-rank term on the multi-launch route), out[13] the
  * inner loops this instance ran behind launches SHARED with other instances of a batch call on the multi-launch edge
- * path (one launch per kernel of the while body for the whole group, sdplr_hip_batch_major_iteration).  Writes
- * min(cap, 14) entries, *n_written says how many.                                                               */
+ * path (one launch per kernel of the while body for the whole group, sdplr_hip_batch_major_iteration), out[14] the
+ * inner loops (calls) that ran on the RING form of the L-BFGS history (lbfgshis.vecs[j].s / .y of src/lbfgs.jl:4-12
+ * kept as (α_j, dir_j) and (G_j, G_{j+1}) inside the loop: the same values, two stores per iteration less), out[15]
+ * the times that form was turned back into stored s_j, y_j because something outside the loop looked.  Writes
+ * min(cap, 16) entries, *n_written says how many.                                                               */
 int32_t sdplr_hip_get_stats(const sdplr_hip_solver* s, int64_t* out, int32_t cap, int32_t* n_written);
 
 /* ---- per-kernel device timing (hipEvent pairs on the handle's stream) ------------------------ */

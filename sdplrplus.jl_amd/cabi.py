@@ -30,7 +30,7 @@ F_RT, F_GT, F_DIRT, F_LBFGS_S, F_LBFGS_Y, F_SCRATCH = 0, 1, 2, 100, 200, 300
 STAT_NAMES = ("graph_captures", "graph_capture_failures", "graph_capture_skipped", "graph_batches",
               "eager_batches", "lanczos_graph_replays", "lanczos_eager_rounds", "inner_iterations",
               "resident_loops", "resident_lanczos", "resident_fg", "resident_shared_launches", "p_less_loops",
-              "group_launch_loops")
+              "group_launch_loops", "ring_history_loops", "ring_materializations")
 S_SIGMA, S_OBJ, S_LBFGS_LATEST = 0, 1, 2
 
 _i32, _i64, _f64, _vp = C.c_int32, C.c_int64, C.c_double, C.c_void_p

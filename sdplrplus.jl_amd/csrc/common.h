@@ -67,6 +67,15 @@ struct DevCtrl {
   double SY[SDPLR_HMAX * SDPLR_HMAX];                // SY[a][b] = ⟨s_a, y_b⟩
   double YY[SDPLR_HMAX * SDPLR_HMAX];                // YY[a][b] = ⟨y_a, y_b⟩
   double Sg[SDPLR_HMAX], Yg[SDPLR_HMAX];             // ⟨s_a, G⟩, ⟨y_a, G⟩ for the current G
+  // ---- ring form of the history (k_dense.h, "ring form") ----
+  int ring_on;         // the loop keeps G_k and D_k of the last h + 1 iterations instead of s_j, y_j
+  int ring_k;          // ring position (0..h) of the current G; the coming direction goes to the same position of the D ring
+  int ring_n;          // pairs in ring form (≤ h): the i-th newest is (D, G) at position ring_k − 1 − i and G at ring_k − i;
+                       // the older ones are still the stored s_j, y_j the loop found in their slots
+  int ring_unc;        // the last step was not followed by lbfgs_update! (relative-decrease exit): its G_new sits at ring_k + 1
+  int ring_j0;         // latest mod h when the ring was entered: position p ≥ 1 lives in history slot (ring_j0 + p − 1) mod h
+  int ring_pad_;
+  double ring_alpha[SDPLR_HMAX];                     // by pair slot: s_j = ring_alpha[j]·D
 };
 
 // ---- deterministic reductions --------------------------------------------------------------------

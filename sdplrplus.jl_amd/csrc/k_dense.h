@@ -50,6 +50,31 @@ __device__ __forceinline__ void stnt2(double* p, long long i, double2 v) {
 __host__ __device__ __forceinline__ double* aslot(const FactorArena& A, int k) { return A.base + (long long)k * A.stride; }
 __host__ __device__ __forceinline__ int as_y0(const FactorArena& A) { return AS_S0 + A.h; }  // y_j at as_y0(A) + j
 
+// ---- ring form of the history ---------------------------------------------------------------------------------------
+// s_j = α_j·D_j and y_j = G_{j+1} − G_j are functions of arrays the loop writes anyway: the direction D_k (k_lbfgs_dir) and
+// the gradient G_{k+1} (the step kernel).  In ring form the loop keeps the last h + 1 of each — the h + 1 "G-like" arrays
+// of the arena (G, y_0..y_{h-1}) and its h + 1 "D-like" ones (dirt, s_0..s_{h-1}) used as two rings — and every reader forms
+// s and y on the fly: fl(α·d) and fl(g' − g) are the very values lbfgs_update! would have stored (src/lbfgs.jl:142-145), so
+// the iterates are those of the stored form bit for bit, and the step kernel writes 2N bytes less per iteration (no s_j, no
+// y_j).  Ring position 0 is the array's own place (G / dirt); position p ≥ 1 is history slot (j0 + p − 1) mod h, j0 = latest
+// mod h when the ring was entered — the slot of the p-th pair the loop replaces, so the ring grows into the slots of the
+// stored pairs exactly as they expire: a loop may enter ring form on ANY stored history (an empty one is h stored pairs of
+// zeros), and for its first h iterations the pairs older than the ring are read from their slots as stored.  The control
+// block holds the position of the current G (ring_k), the number of pairs in ring form (ring_n), j0 and each ring pair's α
+// (ring_alpha, by pair slot); the seam kernel advances them when it folds an update.  Everything outside the loop sees the
+// stored form: the host turns the rings back into s_j, y_j, G (k_ring_materialize) before anything else touches the arena.
+__host__ __device__ __forceinline__ int ring_slot(int p, int j0, int h) { return (j0 + p - 1) % h; }   // p ≥ 1
+__host__ __device__ __forceinline__ double* ring_G(const FactorArena& A, int p, int j0) {
+  return p == 0 ? aslot(A, AS_G) : aslot(A, as_y0(A) + ring_slot(p, j0, A.h));
+}
+__host__ __device__ __forceinline__ double* ring_D(const FactorArena& A, int p, int j0) {
+  return p == 0 ? aslot(A, AS_D) : aslot(A, AS_S0 + ring_slot(p, j0, A.h));
+}
+__host__ __device__ __forceinline__ int ring_back(int k, int i, int h) {   // position i steps behind k
+  const int p = (k - i) % (h + 1);
+  return p < 0 ? p + h + 1 : p;
+}
+
 // ---- two-loop coefficients from the Gram data (one thread, control block staged in LDS) -------------
 // Mirrors src/lbfgs.jl:93-113 step by step; j runs newest → oldest, then oldest → newest.
 struct SeamLds {
@@ -385,6 +410,15 @@ __device__ __forceinline__ void lbfgs_boundary_body(DevCtrl* __restrict__ c, int
     gd.c.obj_pending = 0;
     if (pv_raw != nullptr) pv_raw[m] = gd.c.obj_next;
   }
+  if (tid == 0 && fin_mode == 1 && gd.c.ring_on) {   // ring form: the pair the step kernel has just completed
+    if (gp) {
+      gd.c.ring_alpha[gd.c.latest % h] = gd.c.alpha;
+      gd.c.ring_k = (gd.c.ring_k + 1) % (h + 1);
+      gd.c.ring_n = min(gd.c.ring_n + 1, h);
+    } else if (gd.c.reldelta_exit) {
+      gd.c.ring_unc = 1;
+    }
+  }
 #ifdef SDPLR_STAMPS
   const unsigned long long st1 = __builtin_amdgcn_s_memtime();
 #endif
@@ -543,6 +577,166 @@ __global__ void __launch_bounds__(SDPLR_NT)
 k_lbfgs_dir(const DevCtrl* __restrict__ c, FactorArena A, long long N, int h, int negate,
             int check_done, double* __restrict__ partials, int inline_fallback) {
   lbfgs_dir_body<HM, NTH>(c, A, N, h, negate, check_done, partials, inline_fallback);
+}
+
+// The in-loop direction on the ring form (see "ring form" above): the same combination from the same values — y_i =
+// G(ring_k − i) − G(ring_k − i − 1), s_i = α_i·D(ring_k − 1 − i), i = 0 the newest pair — written to position ring_k of the D
+// ring.  2h + 1 loads per element, as the stored form.  The steepest-descent fallback (decided by the seam kernel from the
+// Gram data) writes −G and leaves G alone: the flip G ← −G of src/sdplr.jl:203 is undone by the step kernel's y_j = G_new −
+// G_old in the stored form, and here nothing else reads G in between.  N even.
+template <int HM, bool NTH>
+__global__ void __launch_bounds__(SDPLR_NT)
+k_lbfgs_dir_ring(const DevCtrl* __restrict__ c, FactorArena A, long long N, int h, int check_done) {
+  const int dn = check_done ? c->done : 0;
+  const int latest = c->latest, rk = c->ring_k, rn = c->ring_n, j0 = c->ring_j0, fb = c->fallback;
+  double ca[HM], cg[HM], ra[HM];
+  int slot[HM];
+  {
+    int j = latest - 1;
+#pragma unroll
+    for (int i = 0; i < HM; i++) {
+      const int jj = (i < h && j >= 0) ? j : 0;
+      slot[i] = jj;
+      const double a0 = c->c_alpha[jj], g0 = c->c_gamma[jj], r0 = c->ring_alpha[jj];
+      ca[i] = (i < h) ? a0 : 0.0;
+      cg[i] = (i < h) ? g0 : 0.0;
+      ra[i] = (i < rn) ? r0 : 1.0;     // a pair still in its slot as stored: s = 1·s
+      j = (j <= 0) ? h - 1 : j - 1;
+    }
+  }
+  if (dn) return;
+  // gp[0..rn]: the G chain of the ring pairs; gp[i + 1], i ≥ rn: the stored y of the i-th newest pair.  Positions past
+  // the history alias the current G (loaded, never used): every load of a trip is unconditional
+  const double* gp[HM + 1];
+  const double* dp[HM];
+  gp[0] = ring_G(A, rk, j0);
+#pragma unroll
+  for (int i = 0; i < HM; i++) {
+    if (i >= h) {
+      gp[i + 1] = gp[0];
+      dp[i] = gp[0];
+    } else if (i < rn) {
+      gp[i + 1] = ring_G(A, ring_back(rk, i + 1, h), j0);
+      dp[i] = ring_D(A, ring_back(rk, i + 1, h), j0);
+    } else {
+      gp[i + 1] = aslot(A, as_y0(A) + slot[i]);
+      dp[i] = aslot(A, AS_S0 + slot[i]);
+    }
+  }
+  double* dir = ring_D(A, rk, j0);
+  const long long N2 = N >> 1;
+  const long long stride = (long long)gridDim.x * SDPLR_NT;
+  for (long long i = (long long)blockIdx.x * SDPLR_NT + threadIdx.x; i < N2; i += stride) {
+    double2 gv[HM + 1], dv[HM];
+    gv[0] = ldnt2(gp[0], i);
+#pragma unroll
+    for (int k = 0; k < HM; k++) {
+      if constexpr (NTH) {
+        gv[k + 1] = ldnt2(gp[k + 1], i);
+        dv[k] = ldnt2(dp[k], i);
+      } else {
+        gv[k + 1] = reinterpret_cast<const double2*>(gp[k + 1])[i];
+        dv[k] = reinterpret_cast<const double2*>(dp[k])[i];
+      }
+    }
+    double2 r = gv[0];
+#pragma unroll
+    for (int k = 0; k < HM; k++) {  // newest → oldest: q −= α y   (:94-102); ca = 0 beyond h
+      const bool ring = k < rn;
+      const double yx = ring ? gv[k].x - gv[k + 1].x : gv[k + 1].x, yy = ring ? gv[k].y - gv[k + 1].y : gv[k + 1].y;
+      r.x -= ca[k] * yx;
+      r.y -= ca[k] * yy;
+    }
+#pragma unroll
+    for (int k = HM - 1; k >= 0; k--) {  // oldest → newest: r += γ s  (:104-113); cg = 0 beyond h
+      const double sx = ra[k] * dv[k].x, sy = ra[k] * dv[k].y;
+      r.x += cg[k] * sx;
+      r.y += cg[k] * sy;
+    }
+    double2 d;
+    d.x = -1.0 * r.x;
+    d.y = -1.0 * r.y;
+    if (fb) {
+      d.x = -gv[0].x;
+      d.y = -gv[0].y;
+    }
+    reinterpret_cast<double2*>(dir)[i] = d;
+  }
+}
+
+// Ring form → stored form, in place: every element's 2h + 2 ring values are loaded before any of them is overwritten.
+// G ← the current gradient; s_j ← α_j·D, y_j ← G' − G for the pairs in ring form (the older ones are in their slots as
+// stored: untouched); after a step without lbfgs_update! (unc: the relative-decrease exit) the slot lbfgs_dir! had claimed
+// holds y = −G_old (src/lbfgs.jl:121-123) and dirt the unscaled direction.  Otherwise dirt is left to the lazy copy dirt ←
+// s_latest.  Arrays by physical index: 0 = G / dirt, 1 + j = history slot j.
+template <int HM>
+__global__ void __launch_bounds__(SDPLR_NT)
+k_ring_materialize(FactorArena A, long long N, int h, int rk, int rn, int unc, int latest, int j0, const DevCtrl* __restrict__ c) {
+  auto phys = [&](int p) { return p == 0 ? 0 : 1 + ring_slot(p, j0, h); };
+  double ra[HM];
+  int pd[HM], pg0[HM], pg1[HM];      // physical index of pair slot j's D, G_old, G_new; −1: the pair is in its slot as stored
+#pragma unroll
+  for (int j = 0; j < HM; j++) {
+    int age = (latest - 1 - j) % (h > 0 ? h : 1);   // 0 = newest
+    if (age < 0) age += h;
+    const bool ring = j < h && age < rn;
+    const int pos = ring_back(rk, 1 + age, h);
+    pd[j] = ring ? phys(pos) : -1;
+    pg0[j] = ring ? phys(pos) : -1;
+    pg1[j] = ring ? phys(ring_back(pos, -1, h)) : -1;
+    ra[j] = ring ? c->ring_alpha[j < h ? j : 0] : 0.0;
+  }
+  const int jnext = latest % (h > 0 ? h : 1);
+  double* gp[HM + 1];
+  double* dp[HM + 1];
+#pragma unroll
+  for (int q = 0; q <= HM; q++) {
+    gp[q] = (q == 0 || q > h) ? aslot(A, AS_G) : aslot(A, as_y0(A) + q - 1);
+    dp[q] = (q == 0 || q > h) ? aslot(A, AS_D) : aslot(A, AS_S0 + q - 1);
+  }
+  const int qcur = phys(unc ? ring_back(rk, -1, h) : rk), qold = phys(rk);
+  const long long stride = (long long)gridDim.x * SDPLR_NT;
+  for (long long i = (long long)blockIdx.x * SDPLR_NT + threadIdx.x; i < N; i += stride) {
+    double gv[HM + 1], dv[HM + 1];
+#pragma unroll
+    for (int q = 0; q <= HM; q++) {
+      gv[q] = gp[q][i];
+      dv[q] = dp[q][i];
+    }
+    auto pick = [&](const double* v, int q0) {
+      double o = 0.0;
+#pragma unroll
+      for (int q = 0; q <= HM; q++) o = (q == q0) ? v[q] : o;
+      return o;
+    };
+    const double gcur = pick(gv, qcur);
+    const double gold = pick(gv, qold), dcur = pick(dv, qold);
+    double sj[HM], yj[HM];
+#pragma unroll
+    for (int j = 0; j < HM; j++) {
+      sj[j] = dv[j + 1];          // as stored
+      yj[j] = gv[j + 1];
+      if (pd[j] >= 0) {
+        sj[j] = ra[j] * pick(dv, pd[j]);
+        yj[j] = pick(gv, pg1[j]) - pick(gv, pg0[j]);
+      }
+      if (unc && j == jnext) yj[j] = -gold;
+    }
+    gp[0][i] = gcur;
+    if (unc) dp[0][i] = dcur;
+#pragma unroll
+    for (int j = 0; j < HM; j++)
+      if (j < h) {
+        dp[j + 1][i] = sj[j];
+        gp[j + 1][i] = yj[j];
+      }
+  }
+}
+// dirt ← scale·(position p of the D ring): all that lbfgs_clear! needs of a ring it is about to drop
+__global__ void __launch_bounds__(SDPLR_NT)
+k_ring_dirt(double* dirt, const double* src, long long N, double scale) {
+  const long long stride = (long long)gridDim.x * SDPLR_NT;
+  for (long long i = (long long)blockIdx.x * SDPLR_NT + threadIdx.x; i < N; i += stride) dirt[i] = scale * src[i];
 }
 
 // descent = Σ partials (src/sdplr.jl:201); with `apply`, the steepest-descent fallback of

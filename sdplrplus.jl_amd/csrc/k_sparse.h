@@ -1161,6 +1161,280 @@ k_fast_step2(int n, int m, DevFast ff, double* __restrict__ R, double* __restric
   }
 }
 
+// k_fast_step2<LPR, VEC, HMU, true, true, true> on the ring form of the history (k_dense.h): G_old and D are read at position
+// ring_k of their rings, G_new goes to position ring_k + 1, and neither s_j nor y_j is stored — the Gram dots of the new pair
+// with the other pairs are formed from y_i = G(ring_k − i) − G(ring_k − i − 1) and s_i = α_i·D(ring_k − 1 − i), the values the
+// stored form would have read back: 10N bytes read, 2N written per iteration instead of 10N + 4N.  A row is one chunk
+// (r ≤ LPR·VEC); the head (the line-search scalar stage) and phase A are those of k_fast_step2.
+template <int LPR, int VEC, int HMU>
+__global__ void __launch_bounds__(SDPLR_NT)
+k_fast_step_ring(int n, int m, DevFast ff, double* __restrict__ R, const double* __restrict__ W, int r,
+                 double* __restrict__ yvec, const double* __restrict__ lam, const double* __restrict__ lam_ub,
+                 double* __restrict__ pv_raw, const double* __restrict__ lb, double* __restrict__ pv,
+                 const double* __restrict__ A_RD, const double* __restrict__ A_DD, double* __restrict__ partials,
+                 DevCtrl* __restrict__ c, int check_done, FactorArena A, int h, int nb_ls) {
+  static_assert(HMU >= 1, "the ring form rides the fused update");
+  __shared__ double sh[2 * (SDPLR_NT / 64)];
+  __shared__ double shl[10 * (SDPLR_NT / 64)];
+  extern __shared__ double accl[];  // [5·HMU][NT] running Gram sums, one column per lane
+  const int dn = check_done ? c->done : 0;
+  constexpr int G = SDPLR_NT / LPR;
+  const int lane = threadIdx.x % LPR;
+  const long long total = (long long)gridDim.x * G;
+  const double sigma = c->sigma;
+  const int latest = c->latest, rk = c->ring_k, rn = c->ring_n, rj0 = c->ring_j0;
+  double a;
+  bool upd;
+  {
+    const double obj0 = c->obj, amax = c->alpha_max, last = c->lastval, feps = c->fprec_eps;
+    double s10[10];
+    {
+      constexpr int PT = 2;
+      double2 v[10][PT];
+      const int ncols = (nb_ls + 2 * SDPLR_NT - 1) / (2 * SDPLR_NT);
+#pragma unroll
+      for (int q = 0; q < PT; q++) {
+        const int i = (int)threadIdx.x + SDPLR_NT * q;
+        if (q < ncols) {
+#pragma unroll
+          for (int k = 0; k < 8; k++) v[k][q] = reinterpret_cast<const double2*>(slot_partials(partials, SLOT_LS + k))[i];
+          v[8][q] = reinterpret_cast<const double2*>(slot_partials(partials, SLOT_PD))[i];
+          v[9][q] = reinterpret_cast<const double2*>(slot_partials(partials, SLOT_DW))[i];
+        } else {
+#pragma unroll
+          for (int k = 0; k < 10; k++) v[k][q].x = v[k][q].y = 0.0;
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 10; k++) {
+        s10[k] = 0.0;
+#pragma unroll
+        for (int q = 0; q < PT; q++) {
+          const int i = 2 * ((int)threadIdx.x + SDPLR_NT * q);
+          s10[k] += (i < nb_ls) ? v[k][q].x : 0.0;
+          s10[k] += (i + 1 < nb_ls) ? v[k][q].y : 0.0;
+        }
+      }
+    }
+    block_sum<10>(s10, shl);
+    const double g_rd = s10[8] + s10[8], g_dd = s10[9];
+    double bq[5];
+    bq[0] = obj0 - s10[0] + sigma * s10[1] / 2;      // src/linesearch.jl:44-56
+    bq[1] = g_rd - s10[2] + sigma * s10[3];
+    bq[2] = g_dd - s10[4] + sigma * s10[5] / 2;
+    bq[3] = sigma * s10[6];
+    bq[4] = sigma * s10[7] / 2;
+    double al = 0.0, f = bq[0];
+    const int rc = quartic_argmin(bq, amax, &al, &f);
+    if (rc != 0) {
+      if (blockIdx.x == 0 && threadIdx.x == 0 && !dn) {
+        c->err = rc;
+        c->done = 1;
+      }
+      return;
+    }
+    const double rel_delta = (last - f) / fmax(1.0, fmax(fabs(f), fabs(last)));   // src/sdplr.jl:238
+    upd = !(rel_delta < feps);
+    a = al;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && !dn) {
+      for (int k = 0; k < 5; k++) c->biquad[k] = bq[k];
+      c->alpha = al;
+      c->L = f;
+      c->reldelta_exit = upd ? 0 : 1;
+      const_cast<double*>(A_RD)[m] = g_rd;
+      const_cast<double*>(A_DD)[m] = g_dd;
+      c->obj_next = obj0 + al * (al * g_dd + g_rd);   // src/linesearch.jl:118-121: stored by the seam
+      c->obj_pending = 1;
+      c->pv2_extra = 0.0;
+    }
+  }
+  const int jslot = latest % h;
+  // the pairs that stay: i = 0 (newest) … nv − 1 (the h-th is the one the new pair replaces); of those the first rn are in
+  // ring form, the others still in their slots as stored
+  const int nv = h - 1;
+  constexpr int HO = HMU > 1 ? HMU - 1 : 1;
+  const double* gp[HMU];     // gp[0] = G_old; ring pair i: G(ring_k − i − 1) at gp[i + 1]; stored pair i: its y at gp[i + 1]
+  const double* dp[HO];      // D(ring_k − 1 − i), or the stored s
+  double ra[HO];
+  int lsl[HO];               // pair slot of the i-th newest pair
+  gp[0] = ring_G(A, rk, rj0);
+#pragma unroll
+  for (int i = 0; i < HO; i++) {
+    int l = (latest - 1 - i) % h;
+    if (l < 0) l += h;
+    lsl[i] = l;
+    const double r0 = c->ring_alpha[l];
+    ra[i] = (i < rn) ? r0 : 1.0;
+    if (i >= nv) {
+      dp[i] = gp[0];
+      if (i + 1 < HMU) gp[i + 1] = gp[0];
+    } else if (i < rn) {
+      dp[i] = ring_D(A, ring_back(rk, 1 + i, h), rj0);
+      if (i + 1 < HMU) gp[i + 1] = ring_G(A, ring_back(rk, 1 + i, h), rj0);
+    } else {
+      dp[i] = aslot(A, AS_S0 + l);
+      if (i + 1 < HMU) gp[i + 1] = aslot(A, as_y0(A) + l);
+    }
+  }
+  double* const D = ring_D(A, rk, rj0);
+  double* const Gnew = ring_G(A, ring_back(rk, -1, h), rj0);
+  double red[2] = {0.0, 0.0};  // ‖G‖², ‖pv‖² (row-attached slots)
+  const int ch0 = lane * VEC;
+#pragma unroll
+  for (int k = 0; k < 5 * HMU; k++) accl[k * SDPLR_NT + threadIdx.x] = 0.0;
+  constexpr int TR = LPR < SDPLR_STEP_TR ? LPR : SDPLR_STEP_TR;   // rows per tile
+  const long long ntiles = ((long long)n + TR - 1) / TR;
+  for (long long tile = (long long)blockIdx.x * G + threadIdx.x / LPR; tile < ntiles; tile += total) {
+    const long long j0 = tile * TR;
+    const int nrows = (int)min((long long)TR, (long long)n - j0);
+    if (dn) return;
+    double djl = 0.0, djo = 0.0;     // d_j at the new / the old multipliers
+    if (lane < nrows) {
+      const long long j = j0 + lane;
+      const int e0 = ff.drow_ptr[j], e1 = ff.drow_ptr[j + 1];
+      for (int e = e0; e < e1; e++) {
+        const int k = ff.drow_gid[e];
+        djo += ff.drow_val[e] * yvec[k];                            // y as the previous g! left it
+        const double v = pv_raw[k] + a * (a * A_DD[k] + A_RD[k]);   // src/linesearch.jl:118
+        double yk;
+        if (k < m) {
+          yk = -fmin(lam_ub[k], lam[k] - sigma * v);                // src/coreop.jl:233
+          const double pc = fmax(v, lb[k]);                         // src/linesearch.jl:122-124
+          pv[k] = pc;
+          red[1] += pc * pc;
+        } else {
+          yk = 1.0;                                                  // the cost slot, src/coreop.jl:235
+          c->obj = v;
+        }
+        djl += ff.drow_val[e] * yk;
+        yvec[k] = yk;
+        pv_raw[k] = v;
+      }
+    }
+    for (int i0 = 0; i0 < nrows; i0 += 2) {
+      vecd<VEC> xx[2], dd[2], ww[2], gv[2][HMU], dv[2][HO];
+      double dj[2], dq[2];
+      unsigned off[2];
+#pragma unroll
+      for (int u = 0; u < 2; u++) {
+        const int i = min(i0 + u, nrows - 1);                        // (odd tail: row repeated, not stored twice)
+        const long long j = j0 + i;
+        dj[u] = __shfl(djl, i, LPR);
+        dq[u] = __shfl(djo, i, LPR);
+        off[u] = (unsigned)(((unsigned long long)j * (unsigned)r + (unsigned)ch0) * 8ull);
+#pragma unroll
+        for (int q = 0; q < VEC; q++) xx[u].v[q] = dd[u].v[q] = ww[u].v[q] = 0.0;
+#pragma unroll
+        for (int l = 0; l < HMU; l++)
+#pragma unroll
+          for (int q = 0; q < VEC; q++) gv[u][l].v[q] = 0.0;
+#pragma unroll
+        for (int l = 0; l < HO; l++)
+#pragma unroll
+          for (int q = 0; q < VEC; q++) dv[u][l].v[q] = 0.0;
+        if (ch0 < r) {
+          xx[u] = ldrow<VEC>(rowat(R, off[u]));
+          dd[u] = ldrow<VEC>(rowat(D, off[u]));
+          ww[u] = ldrow<VEC>(rowat(W, off[u]));
+#pragma unroll
+          for (int l = 0; l < HMU; l++) gv[u][l] = ldrow_nt<VEC>(rowat(gp[l], off[u]));
+#pragma unroll
+          for (int l = 0; l < HO; l++) dv[u][l] = ldrow_nt<VEC>(rowat(dp[l], off[u]));
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 2; u++) {
+        if (i0 + u >= nrows) break;
+        if (ch0 >= r) continue;
+        vecd<VEC> x = xx[u];
+        const vecd<VEC> d = dd[u], w = ww[u], go = gv[u][0];
+        vecd<VEC> g;
+        // G_new = G_old + 2·(α·W + d_new∘R_new − d_old∘R_old)   (y_g ≡ 1: A_g is the cost matrix)
+#pragma unroll
+        for (int q = 0; q < VEC; q++) {
+          const double xo = x.v[q];
+          x.v[q] += a * d.v[q];
+          const double t = a * w.v[q] + (x.v[q] * dj[u] - xo * dq[u]);
+          g.v[q] = go.v[q] + 2.0 * t;
+          red[0] += g.v[q] * g.v[q];
+        }
+        strow<VEC>(rowat(R, off[u]), x);
+        strow<VEC>(rowat(Gnew, off[u]), g);
+        if (upd) {
+          vecd<VEC> sn, yn;
+#pragma unroll
+          for (int q = 0; q < VEC; q++) {
+            sn.v[q] = a * d.v[q];            // BLAS.scal!(stepsize, dir)  (src/lbfgs.jl:142): kept as (α, D)
+            yn.v[q] = g.v[q] - go.v[q];      // y_j = −G_old + G_new  (:122,145): kept as (G_old, G_new)
+          }
+          double* ac = accl + threadIdx.x;
+#pragma unroll
+          for (int i = 0; i < HO; i++)
+            if (i < nv) {
+              double q0 = 0.0, q1 = 0.0, q2 = 0.0, q3 = 0.0, q4 = 0.0;
+#pragma unroll
+              for (int q = 0; q < VEC; q++) {
+                const double sl = ra[i] * dv[u][i].v[q];
+                const double yn1 = gv[u][i + 1 < HMU ? i + 1 : i].v[q];
+                const double yl = (i < rn) ? gv[u][i].v[q] - yn1 : yn1;
+                q0 += sn.v[q] * yl;
+                q1 += sl * yn.v[q];
+                q2 += yn.v[q] * yl;
+                q3 += sl * g.v[q];
+                q4 += yl * g.v[q];
+              }
+              const int l = lsl[i];
+              (void)__hip_atomic_fetch_add(ac + (0 * HMU + l) * SDPLR_NT, q0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+              (void)__hip_atomic_fetch_add(ac + (1 * HMU + l) * SDPLR_NT, q1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+              (void)__hip_atomic_fetch_add(ac + (2 * HMU + l) * SDPLR_NT, q2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+              (void)__hip_atomic_fetch_add(ac + (3 * HMU + l) * SDPLR_NT, q3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+              (void)__hip_atomic_fetch_add(ac + (4 * HMU + l) * SDPLR_NT, q4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+          {   // the new pair with itself
+            double q0 = 0.0, q2 = 0.0, q3 = 0.0, q4 = 0.0;
+#pragma unroll
+            for (int q = 0; q < VEC; q++) {
+              q0 += sn.v[q] * yn.v[q];
+              q2 += yn.v[q] * yn.v[q];
+              q3 += sn.v[q] * g.v[q];
+              q4 += yn.v[q] * g.v[q];
+            }
+            (void)__hip_atomic_fetch_add(ac + (0 * HMU + jslot) * SDPLR_NT, q0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            (void)__hip_atomic_fetch_add(ac + (1 * HMU + jslot) * SDPLR_NT, q0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            (void)__hip_atomic_fetch_add(ac + (2 * HMU + jslot) * SDPLR_NT, q2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            (void)__hip_atomic_fetch_add(ac + (3 * HMU + jslot) * SDPLR_NT, q3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            (void)__hip_atomic_fetch_add(ac + (4 * HMU + jslot) * SDPLR_NT, q4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          }
+        }
+      }
+    }
+  }
+  if (dn) return;
+  __syncthreads();
+  if (upd) {
+    const int wave = threadIdx.x >> 6, wl = threadIdx.x & 63;
+    for (int k = wave; k < 5 * HMU; k += SDPLR_NT / 64) {
+      double t = 0.0;
+#pragma unroll
+      for (int i = 0; i < SDPLR_NT / 64; i++) t += accl[k * SDPLR_NT + wl + 64 * i];
+      t = wave_sum(t);
+      const int q = k / HMU, l = k % HMU;
+      if (wl == 0 && l < h) slot_partials(partials, SLOT_GRAM + q * SDPLR_HMAX + l)[blockIdx.x] = t;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) c->gram_pending = 1;  // consumed by k_lbfgs_boundary
+  }
+  block_sum<2>(red, sh);
+  if (threadIdx.x == 0) {
+    slot_partials(partials, SLOT_GNORM2)[blockIdx.x] = red[0];
+    slot_partials(partials, SLOT_PVNORM2)[blockIdx.x] = red[1];
+    if (blockIdx.x == 0) {
+      c->norms_pending = 1;
+      c->nb_gnorm = gridDim.x;
+      c->nb_pvnorm = gridDim.x;
+    }
+  }
+}
+
 // W = A_g·D with everything row-local of the line-search head riding along (singleton fast path):
 // while row j's neighbours are being gathered, R_j, D_j, P_j stream in, giving ⟨R_j,D_j⟩, ‖D_j‖², the
 // partials of ⟨P,D⟩ and ⟨D,W⟩, the 𝒜 values of the row's singleton constraints and their share of the
@@ -1425,15 +1699,17 @@ __global__ void __launch_bounds__(SDPLR_NT, 2)
 #else
 __global__ void __launch_bounds__(SDPLR_NT, LPR >= 32 ? 2 : 4)
 #endif
-k_spmm_tile(DevTile tl, int n, int m, DevFast ff, const double* __restrict__ R, const double* __restrict__ D,
+k_spmm_tile(DevTile tl, int n, int m, DevFast ff, const double* __restrict__ R, const double* __restrict__ Darg,
             const double* __restrict__ P, double* __restrict__ W, int r, const double* __restrict__ lam,
             const double* __restrict__ pv_raw, double* __restrict__ A_RD, double* __restrict__ A_DD,
             double* __restrict__ partials, const DevCtrl* __restrict__ c, int check_done,
-            DevLowRank lr, double* __restrict__ lr_part, int rowout) {
+            DevLowRank lr, double* __restrict__ lr_part, int rowout, int ring = 0, FactorArena RA = FactorArena{}) {
   // [G][K+1][LPR·VEC] partial rows, [G][K][2] row dots, [G][8] line-search sums
   extern __shared__ double tile_lds[];
   __shared__ double sh[10 * (SDPLR_NT / 64)];
   const int dn = check_done ? c->done : 0;  // tested below, once the first tile's pointers are on their way
+  // ring form of the history (k_dense.h): the direction sits at position ring_k of the D ring
+  const double* __restrict__ D = ring ? ring_D(RA, c->ring_k, c->ring_j0) : Darg;
   constexpr int G = SDPLR_NT / LPR;
   constexpr int RW = LPR * VEC;
   const int lane = threadIdx.x % LPR, grp = threadIdx.x / LPR;

@@ -149,6 +149,15 @@ struct sdplr_hip_solver {
   int rs_ell_part_sl[SDPLR_RS_TEAM_MAX + 1] = {0, 0, 0, 0, 0};
   bool no_pdrop = false;     // SDPLR_HIP_NO_PDROP: the step kernel keeps P = A_g·R (P += α·W) instead of carrying G forward
   bool pdrop_now = false;    // this inner loop runs the P-less step kernel (decided at loop entry)
+  // Ring form of the history (k_dense.h): the P-less loop with the line-search head keeps (α_j, D_j) and (G_j, G_{j+1})
+  // instead of s_j, y_j — 2N bytes less written per iteration.  ring_on: the arena IS in ring form (from a loop that entered
+  // it on an empty history until something outside the loop needs the stored form: ensure_canonical, or lbfgs_clear!
+  // drops it).  The ring's scalars as the last loop left them are kept here for those two.
+  bool no_ring = false;      // SDPLR_HIP_NO_RING
+  bool ring_on = false, ring_now = false;
+  int ring_k = 0, ring_n = 0, ring_unc = 0, ring_latest = 0, ring_j0 = 0;
+  double ring_alpha[SDPLR_HMAX] = {};
+  bool hist_empty = false;   // every history slot is zero (lbfgs_clear! / a fresh handle) and nothing has written one since
   // G is the gradient at the device's (R, λ, σ) with y as its g! left it: true after fg! / g! / an inner loop, cleared by
   // every other entry point that enqueues work (NEED_FINAL_RW).  The P-less step kernel carries G forward incrementally
   // and needs that; when in doubt the loop takes the P-based kernel, which rebuilds G from P and y.
@@ -201,7 +210,7 @@ struct sdplr_hip_solver {
   int nb_dense = 1, nb_m = 1, nb_sddmm = 1, nb_spmm = 1, nb_spmv = 1, nb_nnzT = 1, nb_nnzS = 1, nb_n = 1;
 
   // captured batch of inner iterations (hipGraph), per line-search kind; rebuilt after reset_rank
-  hipGraphExec_t graph_exec[3] = {nullptr, nullptr, nullptr};   // exact line search, Armijo, exact with the P-less step kernel
+  hipGraphExec_t graph_exec[4] = {nullptr, nullptr, nullptr, nullptr};   // exact line search, Armijo, exact with the P-less step kernel, … on the ring form
   int graph_iters = 8;
   bool graph_disabled = false;
   hipGraphExec_t lz_graph = nullptr;   // three Lanczos steps (one rotation of the vector buffers)
@@ -224,7 +233,7 @@ struct sdplr_hip_solver {
   double* scratchV = nullptr;
   // counters (sdplr_hip_get_stats)
   int64_t st_captures = 0, st_capture_failed = 0, st_capture_skipped = 0, st_graph_batches = 0,
-          st_eager_batches = 0, st_lz_graph = 0, st_lz_eager = 0, st_iters = 0, st_rs_loops = 0, st_rs_lz = 0, st_rs_fg = 0, st_rs_shared = 0, st_pdrop = 0, st_grp_loops = 0;
+          st_eager_batches = 0, st_lz_graph = 0, st_lz_eager = 0, st_iters = 0, st_rs_loops = 0, st_rs_lz = 0, st_rs_fg = 0, st_rs_shared = 0, st_pdrop = 0, st_grp_loops = 0, st_ring_loops = 0, st_ring_materialized = 0;
 
   // profiling
   bool prof_on = false;
@@ -259,11 +268,18 @@ int fail(S* s, int code, const std::string& msg) {
   } while (0)
 // entry points that enqueue kernels: the host shadow of the control block is stale until the next pull
 int ensure_dirt(S* s);
+int ensure_canonical(S* s);
+int blocks_for(long long work, int per_block, int cap);
 #define NEED_FINAL_RW(s)                                   \
   do {                                                     \
     NEED_FINAL(s);                                         \
     (s)->hc_valid = false;                                 \
     (s)->G_consistent = false;                             \
+    (s)->hist_empty = false;                               \
+    if ((s)->ring_on) {                                    \
+      const int rc_r__ = ensure_canonical(s);              \
+      if (rc_r__) return rc_r__;                           \
+    }                                                      \
     if ((s)->dirt_from >= 0) {                             \
       const int rc_d__ = ensure_dirt(s);                   \
       if (rc_d__) return rc_d__;                           \
@@ -798,10 +814,24 @@ int push(S* s) {
   return SDPLR_OK;   // (hc_valid is left as it is: a caller that enqueues kernels after this clears it at its entry)
 }
 int ensure_dirt(S* s) {   // dirt ← s_latest (see S::dirt_from); enqueued on the handle's stream, ahead of whatever reads dirt next
+  { const int rc_r = ensure_canonical(s); if (rc_r) return rc_r; }   // (s_latest as a stored vector)
   if (s->dirt_from < 0) return SDPLR_OK;
   const int j = s->dirt_from;
   s->dirt_from = -1;
   HIPCK(s, hipMemcpyAsync(aslot(s->arena, AS_D), aslot(s->arena, AS_S0 + j), s->N * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
+  return SDPLR_OK;
+}
+// ring form → stored form (k_dense.h, k_ring_materialize), enqueued on the handle's stream ahead of whatever asked for it
+int ensure_canonical(S* s) {
+  if (!s->ring_on) return SDPLR_OK;
+  s->ring_on = false;
+  const int nb = blocks_for(s->N, SDPLR_NT, 2048);
+  k_ring_materialize<4><<<nb, SDPLR_NT, 0, s->stream>>>(s->arena, s->N, (int)s->h, s->ring_k, s->ring_n, s->ring_unc, s->ring_latest, s->ring_j0, s->ctrl);
+  HIPCK(s, hipGetLastError());
+  // the device's control block leaves ring form too (the stored-form kernels never look, the seam does)
+  HIPCK(s, hipMemsetAsync(&s->ctrl->ring_on, 0, sizeof(int), s->stream));
+  if (s->hc) s->hc->ring_on = 0;
+  s->st_ring_materialized++;
   return SDPLR_OK;
 }
 int sync_check(S* s) {
@@ -1330,6 +1360,15 @@ bool step_can_drop_P(const S* s) {
          !s->no_pdrop;
 }
 
+// the ring form of the history (k_dense.h) rides the P-less step kernel with the line-search head on the tile path: rows
+// of one chunk, 16-byte pieces, an even number of elements, h ≤ 4
+int tile_shape_lpr(const S* s);
+bool ring_shape_ok(const S* s) {
+  return step_can_drop_P(s) && !s->no_ring && !s->no_lshead && s->n_extra == 1 && s->VEC == 2 && s->LPR >= 4 &&
+         s->r <= (int64_t)s->LPR * s->VEC && (s->N & 1) == 0 && s->use_tile && s->tile_lpr == tile_shape_lpr(s) &&
+         !s->tile_panels && s->nb_tile <= 4 * SDPLR_NT && s->HM == 4 && !s->lit;
+}
+
 int alloc_factors(S* s) {
   s->N = s->n * s->r;
   long long stride = (s->N + 31) / 32 * 32;
@@ -1853,6 +1892,7 @@ int32_t sdplr_hip_finalize(S* s) {
   s->no_updfuse = getenv("SDPLR_HIP_NO_UPDFUSE") != nullptr;
   s->no_pdrop = getenv("SDPLR_HIP_NO_PDROP") != nullptr;
   s->no_lshead = getenv("SDPLR_HIP_NO_LSHEAD") != nullptr;
+  s->no_ring = getenv("SDPLR_HIP_NO_RING") != nullptr;
   s->tile_panels = getenv("SDPLR_HIP_TILE_PANELS") != nullptr;
   if (s->have_sparse && getenv("SDPLR_HIP_NO_FAST") == nullptr) {
     std::vector<int> general;
@@ -2120,6 +2160,7 @@ int32_t sdplr_hip_finalize(S* s) {
   HIPCK(s, hipStreamSynchronize(s->stream));
   lap("final sync");
   s->finalized = true;
+  s->hist_empty = !s->lit;   // (alloc_factors zero-filled the arena)
   return SDPLR_OK;
 }
 
@@ -2142,7 +2183,8 @@ int32_t sdplr_hip_destroy(S* s) {
     if (s->snap_ev[k]) pool_event_free(s->snap_ev[k]);
     if (s->graph_exec[k]) (void)hipGraphExecDestroy(s->graph_exec[k]);
   }
-  if (s->graph_exec[2]) (void)hipGraphExecDestroy(s->graph_exec[2]);
+  for (int k = 2; k < 4; k++)
+    if (s->graph_exec[k]) (void)hipGraphExecDestroy(s->graph_exec[k]);
   if (s->stream) { (void)hipStreamSynchronize(s->stream); pool_stream_free(s->stream); }
   delete s;
   return SDPLR_OK;
@@ -2155,7 +2197,7 @@ int32_t sdplr_hip_reset_rank(S* s, int64_t new_r) {
   HIPCK(s, hipStreamSynchronize(s->stream));
   if (s->arena.base) pool_free(s->arena.base);
   s->arena.base = nullptr;
-  for (int k = 0; k < 3; k++)
+  for (int k = 0; k < 4; k++)
     if (s->graph_exec[k]) { (void)hipGraphExecDestroy(s->graph_exec[k]); s->graph_exec[k] = nullptr; }
   // everything sized by the rank is released before it is re-allocated (the graphs above hold their pointers)
   for (double** p : {&s->lr_part, &s->lr_W, &s->lr_WS, &s->scratchF[0], &s->scratchF[1]}) { dfree(s, *p); *p = nullptr; }
@@ -2183,7 +2225,9 @@ int32_t sdplr_hip_reset_rank(S* s, int64_t new_r) {
   s->gram_dirty = s->sg_stale = s->ynext_pending = false;
   s->P_valid = false;
   s->S_stale = false;
-  return push(s);
+  rc = push(s);
+  s->hist_empty = (rc == SDPLR_OK) && !s->lit;   // (alloc_factors zero-fills the arena)
+  return rc;
 }
 
 // ================================================================================================
@@ -2193,6 +2237,8 @@ int32_t sdplr_hip_set_factor(S* s, int32_t slot, const double* h) {
   ApiShared api_guard(dev_of(s));
   NEED_FINAL(s);
   s->G_consistent = false;   // (the host writes state behind G's back)
+  if (slot >= SDPLR_F_LBFGS_S && slot < SDPLR_F_SCRATCH) s->hist_empty = false;
+  { const int rc_r = ensure_canonical(s); if (rc_r) return rc_r; }
   { const int rc_d = ensure_dirt(s); if (rc_d) return rc_d; }
   double* p = factor_ptr(s, slot);
   if (!p || !h) return fail(s, SDPLR_ERR_INVALID_ARG, "set_factor: bad slot");
@@ -2206,7 +2252,10 @@ int32_t sdplr_hip_set_factor(S* s, int32_t slot, const double* h) {
 int32_t sdplr_hip_get_factor(S* s, int32_t slot, double* h) {
   ApiShared api_guard(dev_of(s));
   NEED_FINAL(s);
-  { const int rc_d = ensure_dirt(s); if (rc_d) return rc_d; }
+  if (slot != SDPLR_F_RT) {   // (R is never in ring form, and does not wait for the lazy dirt ← s_latest)
+    const int rc_d = ensure_dirt(s);
+    if (rc_d) return rc_d;
+  }
   double* p = factor_ptr(s, slot);
   if (!p || !h) return fail(s, SDPLR_ERR_INVALID_ARG, "get_factor: bad slot");
   HIPCK(s, hipMemcpyAsync(h, p, s->N * sizeof(double), hipMemcpyDeviceToHost, s->stream));
@@ -2342,6 +2391,9 @@ namespace {
   TLV_CASE(1, 1, CALL) TLV_CASE(2, 1, CALL) TLV_CASE(4, 1, CALL) TLV_CASE(8, 1, CALL) TLV_CASE(16, 1, CALL) \
   TLV_CASE(32, 1, CALL) TLV_CASE(64, 1, CALL) TLV_CASE(1, 2, CALL) TLV_CASE(2, 2, CALL) TLV_CASE(4, 2, CALL) \
   TLV_CASE(8, 2, CALL) TLV_CASE(16, 2, CALL) TLV_CASE(32, 2, CALL) TLV_CASE(64, 2, CALL) {}
+// (the shapes the ring form of the history is built for: ring_shape_ok)
+#define RING_DISPATCH(CALL)                                                                            \
+  LV_CASE(4, 2, CALL) LV_CASE(8, 2, CALL) LV_CASE(16, 2, CALL) LV_CASE(32, 2, CALL) LV_CASE(64, 2, CALL) {}
 #define HM_DISPATCH(CALL)                                       \
   if (s->HM == 4) { constexpr int HM = 4; CALL; }               \
   else if (s->HM == 8) { constexpr int HM = 8; CALL; }          \
@@ -2794,6 +2846,22 @@ void enq_iteration_fast2(S* s) {
   // lbfgs_update! fused into the step kernel for h ≤ 4 (its Gram partials then come from nb_step blocks)
   const bool upd_fused = step_fuses_update(s);
   s->gram_nb = upd_fused ? s->nb_step : s->nb_upd;
+  if (s->ring_now) {   // ring form of the history (k_dense.h): seam, direction, gather, step — the same four launches
+    enq_boundary(s, 0, 1, 1, 1, 1);
+    {
+      ProfScope ps(s, "lbfgs_dir");
+      k_lbfgs_dir_ring<4, true><<<s->nb_dense, SDPLR_NT, 0, s->stream>>>(s->ctrl, s->arena, s->N, (int)s->h, 1);
+    }
+    {
+      ProfScope ps(s, "spmm_W");
+      const size_t lds = ((size_t)SDPLR_NT * s->VEC * (s->tile.K + 1) + (size_t)(SDPLR_NT / s->tile_lpr) * (2 * s->tile.K + 8)) * sizeof(double);
+      if (s->tile.gdiag) { TLV_DISPATCH((k_spmm_tile<LPR, VEC, 0, true><<<s->nb_tile, SDPLR_NT, lds, s->stream>>>(s->tile, (int)s->n, (int)s->m, s->ff, R, D, P, W, (int)s->r, s->lambda, s->pv_raw, s->A_RD, s->A_DD, s->partials, s->ctrl, 1, s->lr, s->lr_part, 0, 1, s->arena))) }
+      else { TLV_DISPATCH((k_spmm_tile<LPR, VEC, 0><<<s->nb_tile, SDPLR_NT, lds, s->stream>>>(s->tile, (int)s->n, (int)s->m, s->ff, R, D, P, W, (int)s->r, s->lambda, s->pv_raw, s->A_RD, s->A_DD, s->partials, s->ctrl, 1, s->lr, s->lr_part, 0, 1, s->arena))) }
+    }
+    ProfScope ps(s, "fast_step");
+    RING_DISPATCH((k_fast_step_ring<LPR, VEC, 4><<<s->nb_step, SDPLR_NT, 5 * 4 * SDPLR_NT * sizeof(double), s->stream>>>((int)s->n, (int)s->m, s->ff, R, W, (int)s->r, s->y, s->lambda, s->lambda_ub, s->pv_raw, s->pv_lb, s->pv, s->A_RD, s->A_DD, s->partials, s->ctrl, 1, s->arena, (int)s->h, s->nb_tile)))
+    return;
+  }
   enq_lbfgs_dir(s, 1, 1, 1, upd_fused && !s->dot_descent);                            // :197-205
 #ifdef SDPLR_PROBE_TILE_HIST
   s->ff.probe_hist[0] = G;
@@ -3368,10 +3436,10 @@ int32_t sdplr_hip_At_right_device(S* s, const double* x, double* yd, int64_t k) 
 
 int32_t sdplr_hip_get_stats(const S* s, int64_t* out, int32_t cap, int32_t* n_written) {
   if (!s || !out || cap < 0) return SDPLR_ERR_INVALID_ARG;
-  const int64_t v[14] = {s->st_captures, s->st_capture_failed, s->st_capture_skipped, s->st_graph_batches,
+  const int64_t v[16] = {s->st_captures, s->st_capture_failed, s->st_capture_skipped, s->st_graph_batches,
                          s->st_eager_batches, s->st_lz_graph, s->st_lz_eager, s->st_iters, s->st_rs_loops, s->st_rs_lz, s->st_rs_fg,
-                         s->st_rs_shared, s->st_pdrop, s->st_grp_loops};
-  const int32_t k = std::min<int32_t>(cap, 14);
+                         s->st_rs_shared, s->st_pdrop, s->st_grp_loops, s->st_ring_loops, s->st_ring_materialized};
+  const int32_t k = std::min<int32_t>(cap, 16);
   for (int32_t i = 0; i < k; i++) out[i] = v[i];
   if (n_written) *n_written = k;
   return SDPLR_OK;
@@ -3423,7 +3491,9 @@ int set_norm_params(S* s, double normC, double normb, int grel, int prel) {
 extern "C" {
 int32_t sdplr_hip_fg(S* s, double normC, double normb, int32_t grel, int32_t prel, double* L, double* gn, double* pn) {
   ApiShared api_guard(dev_of(s));
+  const bool hist_was_empty = s && s->finalized && s->hist_empty;   // (fg! does not touch the history)
   NEED_FINAL_RW(s);
+  s->hist_empty = hist_was_empty;
   int rc = set_norm_params(s, normC, normb, grel, prel);
   if (rc) return rc;
   if (rs_fg_applies(s)) {   // resident route (k_resident.h): one launch; P = A_g·R stays for the loop that follows
@@ -3531,8 +3601,32 @@ int32_t sdplr_hip_update_lambda(S* s) {
 }
 
 // ---- L-BFGS ------------------------------------------------------------------------------------------
+// lbfgs_clear! on a history in ring form: of the ring only G (the current gradient) and dirt (= s_latest; the unscaled
+// direction after a step without lbfgs_update!) survive the clear — two N-sized passes instead of the whole materialisation
+static int ring_drop_for_clear(S* s) {
+  if (!s || !s->finalized || !s->ring_on) return SDPLR_OK;
+  const int h = (int)s->h, rk = s->ring_k, j0 = s->ring_j0;
+  const int pG = s->ring_unc ? ring_back(rk, -1, h) : rk;
+  if (pG != 0) HIPCK(s, hipMemcpyAsync(aslot(s->arena, AS_G), ring_G(s->arena, pG, j0), s->N * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
+  const int nb = blocks_for(s->N, SDPLR_NT, 2048);
+  if (s->dirt_from >= 0 && s->ring_n >= 1) {        // s_latest = α·D of the newest ring pair
+    k_ring_dirt<<<nb, SDPLR_NT, 0, s->stream>>>(aslot(s->arena, AS_D), ring_D(s->arena, ring_back(rk, 1, h), j0), s->N, s->ring_alpha[s->dirt_from]);
+    s->dirt_from = -1;
+  } else if (s->dirt_from >= 0) {                   // (not one pair in ring form: s_latest is in its slot as stored)
+    HIPCK(s, hipMemcpyAsync(aslot(s->arena, AS_D), aslot(s->arena, AS_S0 + s->dirt_from), s->N * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
+    s->dirt_from = -1;
+  } else if (s->ring_unc && rk != 0) {
+    HIPCK(s, hipMemcpyAsync(aslot(s->arena, AS_D), ring_D(s->arena, rk, j0), s->N * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
+  }
+  HIPCK(s, hipGetLastError());
+  HIPCK(s, hipMemsetAsync(&s->ctrl->ring_on, 0, sizeof(int), s->stream));
+  if (s->hc) s->hc->ring_on = 0;
+  s->ring_on = false;
+  return SDPLR_OK;
+}
 int32_t sdplr_hip_lbfgs_clear(S* s) {
   ApiShared api_guard(dev_of(s));
+  { const int rc_r = ring_drop_for_clear(s); if (rc_r) return rc_r; }
   NEED_FINAL_RW(s);
   // the 2h history slots are neighbours in the arena: one fill (a small solve clears the history once per major iteration)
   if (s->h > 0) HIPCK(s, hipMemsetAsync(aslot(s->arena, AS_S0), 0, (size_t)2 * s->h * s->arena.stride * sizeof(double), s->stream));
@@ -3547,7 +3641,10 @@ int32_t sdplr_hip_lbfgs_clear(S* s) {
   memset(s->hc->Sg, 0, sizeof s->hc->Sg); memset(s->hc->Yg, 0, sizeof s->hc->Yg);
   memset(s->hc->c_alpha, 0, sizeof s->hc->c_alpha); memset(s->hc->c_gamma, 0, sizeof s->hc->c_gamma);
   s->gram_dirty = s->sg_stale = s->ynext_pending = false;  // zero vectors ⇒ zero Gram data, exact for any G
-  return push(s);
+  s->hc->ring_on = 0;
+  rc = push(s);
+  s->hist_empty = (rc == SDPLR_OK) && !s->lit;
+  return rc;
 }
 int32_t sdplr_hip_lbfgs_dir(S* s, int32_t negate, double* descent) {
   ApiShared api_guard(dev_of(s));
@@ -3640,8 +3737,21 @@ static int32_t inner_loop_impl(S* s, double normC, double normb, int32_t grel, i
   // (the loop's first kernel after the seam overwrites dirt: a pending dirt ← s_latest is dropped, not made — unless the
   // loop turns out not to run a single iteration, see below)
   const int dirt_was_from = (s && s->finalized) ? s->dirt_from : -1;
+  // Ring form of the history (k_dense.h): entered on an empty history, kept across calls while nothing else has touched
+  // the arena.  Decided before NEED_FINAL_RW, which would turn a ring back into the stored form.
+  const bool hist_was_empty = s && s->finalized && s->hist_empty;
+  bool ring_keep = false;
+  if (s && s->finalized && s->ring_on) {
+    const bool fast2_ = s->fast && s->fast_singleton && !use_armijo;
+    static const int64_t refresh_iters_ = getenv("SDPLR_HIP_P_REFRESH_ITERS") ? atoll(getenv("SDPLR_HIP_P_REFRESH_ITERS")) : 256;
+    ring_keep = fast2_ && ring_shape_ok(s) && s->G_consistent && !s->ring_unc && Lio && gnio && pnio &&
+                max_local_iters >= 1 && !rs_loop_applies(s, use_armijo) && (resume || s->G_age < refresh_iters_) &&
+                !(s->gram_dirty || s->ynext_pending || s->sg_stale);
+    if (ring_keep) s->ring_on = false;   // (NEED_FINAL_RW leaves it alone; set again below)
+  }
   if (s && s->finalized && max_local_iters >= 1 && Lio && gnio && pnio) s->dirt_from = -1;
   NEED_FINAL_RW(s);
+  if (ring_keep) s->ring_on = true;
   if (!Lio || !gnio || !pnio || max_local_iters < 1) return fail(s, SDPLR_ERR_INVALID_ARG, "inner_loop: bad args");
   const bool gram_work = s->h > 0 && (s->gram_dirty || s->ynext_pending || s->sg_stale);
   ensure_gram(s);
@@ -3684,7 +3794,29 @@ static int32_t inner_loop_impl(S* s, double normC, double normb, int32_t grel, i
     s->S_stale = false;
     s->G_age = 0;
   }
-  const int ar = use_armijo ? 1 : (s->pdrop_now ? 2 : 0);
+  s->ring_now = s->pdrop_now && ring_shape_ok(s);   // (a ring is entered on whatever history is stored: k_dense.h)
+  if (getenv("SDPLR_HIP_DEBUG"))
+    fprintf(stderr, "[sdplr_hip] inner_loop: ring %d (kept %d, history empty %d, pdrop %d, shape %d: can_drop %d n_extra %d VEC %d LPR %d tile %d/%d nb_tile %d)\n",
+            (int)s->ring_now, (int)ring_keep, (int)hist_was_empty, (int)s->pdrop_now, (int)ring_shape_ok(s), (int)step_can_drop_P(s), s->n_extra,
+            s->VEC, s->LPR, (int)s->use_tile, s->tile_lpr, s->nb_tile);
+  if (s->ring_on && !s->ring_now) {   // (a ring kept for a loop that turns out not to take it)
+    if ((rc = ensure_canonical(s))) return rc;
+  }
+  {
+    const bool fresh = s->ring_now && !s->ring_on;
+    const int was = c->ring_on;
+    if (fresh) {   // G and dirt at their own places are position 0; every pair is still in its slot as stored
+      c->ring_k = 0; c->ring_n = 0; c->ring_unc = 0;
+      c->ring_j0 = c->latest % (int)s->h;
+      memset(c->ring_alpha, 0, sizeof c->ring_alpha);
+    }
+    c->ring_on = s->ring_now ? 1 : 0;
+    s->ring_on = s->ring_now;
+    // (the control block went to the device above, before the route was known: the ring's scalars follow it)
+    if (fresh || was != c->ring_on)
+      HIPCK(s, hipMemcpyAsync(&s->ctrl->ring_on, &c->ring_on, sizeof(DevCtrl) - offsetof(DevCtrl, ring_on), hipMemcpyHostToDevice, s->stream));
+  }
+  const int ar = use_armijo ? 1 : (s->ring_now ? 3 : (s->pdrop_now ? 2 : 0));
   const bool edgep = !fastp && edge_applies(s, use_armijo);
   auto enq_iter = [&]() {
     if (fast2) enq_iteration_fast2(s);
@@ -3863,6 +3995,11 @@ static int32_t inner_loop_impl(S* s, double normC, double normb, int32_t grel, i
   s->P_age += c->iters;
   s->G_age = s->pdrop_now ? s->G_age + c->iters : 0;   // (the P-based kernels form G from P and y at every step)
   if (s->pdrop_now) s->st_pdrop++;
+  if (s->ring_now) {   // the ring as the loop left it (ensure_canonical / lbfgs_clear work from these)
+    s->st_ring_loops++;
+    s->ring_k = c->ring_k; s->ring_n = c->ring_n; s->ring_unc = c->ring_unc; s->ring_latest = c->latest; s->ring_j0 = c->ring_j0;
+    memcpy(s->ring_alpha, c->ring_alpha, sizeof s->ring_alpha);
+  }
   s->G_consistent = true;                              // g! has run at the loop's last point
   *Lio = c->L; *gnio = c->gnorm; *pnio = c->pvnorm;
   if (last_alpha) *last_alpha = c->alpha;
@@ -3886,6 +4023,7 @@ int32_t sdplr_hip_major_iteration(S* s, double normC, double normb, int32_t grel
   bool resident = false;
   {
     ApiShared api_guard(dev_of(s));
+    { const int rc_r = ring_drop_for_clear(s); if (rc_r) return rc_r; }   // (lbfgs_clear! follows on every route)
     NEED_FINAL_RW(s);
     resident = rs_loop_applies(s, use_armijo) && rs_fg_applies(s);
     if (resident) {

@@ -1,0 +1,136 @@
+"""The ring form of the L-BFGS history (csrc/k_dense.h): inside the device-driven loop of the P-less singleton fast path
+lbfgshis.vecs[j].s / .y (src/lbfgs.jl:4-12) are kept as (α_j, dir_j) and (G_j, G_{j+1}) — the step kernel stores neither
+s_j nor y_j.  fl(α·d) and fl(g' − g) are the values lbfgs_update! (src/lbfgs.jl:142-145) would have stored, so the
+iterates must be those of the stored form BIT FOR BIT, and whatever looks at the arena outside the loop must find the stored
+form.  SDPLR_HIP_NO_RING (read at solver construction) keeps the stored form inside the loop: the reference of these tests;
+the CPU oracle is the second one."""
+import numpy as np
+import pytest
+
+from helpers import make_solver
+from sdplrplus_jl_amd import cabi, problems
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    return float(np.linalg.norm(np.asarray(a) - np.asarray(b)) / max(np.linalg.norm(np.asarray(b)), 1e-300))
+
+
+def _state(s_, h):
+    S = [s_.get_factor(cabi.F_LBFGS_S + j).copy() for j in range(h)]
+    Y = [s_.get_factor(cabi.F_LBFGS_Y + j).copy() for j in range(h)]
+    return dict(R=s_.Rt.copy(), G=s_.Gt.copy(), D=s_.get_factor(cabi.F_DIRT).copy(), S=S, Y=Y,
+                rho=s_.get_vec(cabi.V_LBFGS_RHO).copy(), y=s_.y.copy())
+
+
+def _same(a, b):
+    for k in ("R", "G", "D", "rho", "y"):
+        assert np.array_equal(a[k], b[k]), k
+    for j, (x, z) in enumerate(zip(a["S"], b["S"])):
+        assert np.array_equal(x, z), ("s", j)
+    for j, (x, z) in enumerate(zip(a["Y"], b["Y"])):
+        assert np.array_equal(x, z), ("y", j)
+
+
+@pytest.mark.parametrize("r,h,n", [(32, 4, 600), (6, 4, 500), (8, 3, 400), (16, 2, 300), (10, 1, 300), (64, 4, 200), (128, 4, 150)])
+def test_ring_form_is_the_stored_form_bit_for_bit(hip_abi, oracle_abi, monkeypatch, r, h, n):
+    """fg! → 3 iterations → 9 more (the ring wraps: h + 1 positions) → look → 4 more from the stored pairs (for its first h
+    iterations such a ring reads the pairs older than itself from their slots) → look: R, G, dirt, every s_j, y_j, ρ and y
+    equal the stored-form run bitwise both times; the oracle agrees to 1e-8."""
+    data = problems.maxcut_data(problems.gnp_graph(n, 8.0 / n, 100 + r))
+    normC, normb = data.normC(), float(np.linalg.norm(data.b))
+
+    def run(abi, ring):
+        if ring:
+            monkeypatch.delenv("SDPLR_HIP_NO_RING", raising=False)
+        else:
+            monkeypatch.setenv("SDPLR_HIP_NO_RING", "1")
+        s_, _ = make_solver(abi, data, r, seed=3, h=h)
+        st = s_.fg(normC, normb)
+        out1 = s_.inner_loop(normC, normb, True, True, False, 0.0, -1e300, 3, 0.0, *st)
+        out2 = s_.inner_loop(normC, normb, True, True, False, 0.0, -1e300, 9, 0.0, *out1[:3])
+        stats_before = s_.stats() if abi is hip_abi else None
+        a = _state(s_, h)
+        out3 = s_.inner_loop(normC, normb, True, True, False, 0.0, -1e300, 4, 0.0, *out2[:3])   # a new ring, entered on the stored pairs
+        b = _state(s_, h)
+        stats = s_.stats() if abi is hip_abi else None
+        s_.close()
+        return (out1, out2, out3), a, b, stats_before, stats
+
+    outs_r, a_r, b_r, sb, st = run(hip_abi, True)
+    outs_s, a_s, b_s, _, st_s = run(hip_abi, False)
+    assert sb["ring_history_loops"] == 2 and sb["ring_materializations"] == 0   # the two calls shared one ring
+    assert st["ring_history_loops"] == 3 and st["ring_materializations"] == 2
+    assert st_s["ring_history_loops"] == 0 and st_s["p_less_loops"] == 3
+    assert outs_r == outs_s
+    _same(a_r, a_s)
+    _same(b_r, b_s)
+    outs_o, a_o, b_o, _, _ = run(oracle_abi, False)
+    for x, z in zip(outs_r, outs_o):
+        assert x[4] == z[4] and np.allclose(x[:3], z[:3], rtol=1e-8)
+    assert rel(b_r["R"], b_o["R"]) < 1e-8 and rel(b_r["G"], b_o["G"]) < 1e-7
+
+
+def test_ring_after_the_relative_decrease_exit(hip_abi, monkeypatch):
+    """A step that is not followed by lbfgs_update! (src/sdplr.jl:238-241) leaves the slot lbfgs_dir! had claimed with
+    y = −G_old and dirt unscaled: the ring is turned back into exactly that, and the next loop carries on from it."""
+    data = problems.maxcut_data(problems.gnp_graph(500, 0.02, 5))
+    normC, normb = data.normC(), float(np.linalg.norm(data.b))
+    r, h = 8, 4
+
+    def run(ring):
+        if ring:
+            monkeypatch.delenv("SDPLR_HIP_NO_RING", raising=False)
+        else:
+            monkeypatch.setenv("SDPLR_HIP_NO_RING", "1")
+        s_, _ = make_solver(hip_abi, data, r, seed=9, h=h)
+        st = s_.fg(normC, normb)
+        out1 = s_.inner_loop(normC, normb, True, True, False, 0.0, -1e300, 6, 0.0, *st)
+        # fprec·eps so large that the next step's relative decrease is "too small": the loop leaves before the update
+        out2 = s_.inner_loop(normC, normb, True, True, False, 0.0, 1e300, 6, 0.0, *out1[:3])
+        a = _state(s_, h)
+        out3 = s_.inner_loop(normC, normb, True, True, False, 0.0, -1e300, 5, 0.0, *out2[:3])
+        b = _state(s_, h)
+        s_.close()
+        return (out1, out2, out3), a, b
+
+    o_r, a_r, b_r = run(True)
+    o_s, a_s, b_s = run(False)
+    assert o_r[1][5] == 1 and o_r[1][4] == 1   # EXIT_RELDELTA after one step
+    assert o_r == o_s
+    _same(a_r, a_s)
+    _same(b_r, b_s)
+
+
+def test_ring_and_lbfgs_clear(hip_abi, monkeypatch):
+    """lbfgs_clear! on a ring keeps what the stored form keeps — G and dirt = s_latest — and the next loop starts a new
+    ring; major_iteration (clear → fg! → loop in one call) goes the same way."""
+    data = problems.maxcut_data(problems.gnp_graph(450, 0.03, 6))
+    normC, normb = data.normC(), float(np.linalg.norm(data.b))
+    r, h = 12, 4
+
+    def run(ring):
+        if ring:
+            monkeypatch.delenv("SDPLR_HIP_NO_RING", raising=False)
+        else:
+            monkeypatch.setenv("SDPLR_HIP_NO_RING", "1")
+        s_, _ = make_solver(hip_abi, data, r, seed=2, h=h)
+        st = s_.fg(normC, normb)
+        out1 = s_.inner_loop(normC, normb, True, True, False, 0.0, -1e300, 7, 0.0, *st)
+        s_.lbfgs_clear()
+        a = _state(s_, h)
+        st = s_.fg(normC, normb)
+        out2 = s_.inner_loop(normC, normb, True, True, False, 0.0, -1e300, 6, 0.0, *st)
+        out3 = s_.major_iteration(normC, normb, True, True, False, True, 4.0, 0.0, -1e300, 8, 0.0)
+        b = _state(s_, h)
+        stats = s_.stats()
+        s_.close()
+        return (out1, out2, out3), a, b, stats
+
+    o_r, a_r, b_r, st = run(True)
+    o_s, a_s, b_s, _ = run(False)
+    assert st["ring_history_loops"] == 3 and st["ring_materializations"] == 1   # (only the closing look)
+    assert o_r == o_s
+    _same(a_r, a_s)
+    _same(b_r, b_s)
