@@ -128,6 +128,9 @@ def algorithmic_bytes(d, h):
         "fast_step_upd": 10 * N,
         # … and without P (the gradient carried forward from G_old; stats: p_less_loops): R, D, W, G_old in; R, G, s_j, y_j out
         "fast_step_upd_pless": 8 * N,
+        # … and on the ring form of the history (stats: ring_history_loops): s_j = α_j·D_j and y_j = G_{j+1} − G_j are not stored
+        # at all — R, D, W, G_old in; R, G out
+        "fast_step_ring": 6 * N,
     }
     b_iter = ((2 * h + 1) * N + 2 * N      # lbfgs_dir!
               + 2 * N                      # dot(dirt, Gt)
@@ -330,7 +333,8 @@ def main():
         # lbfgs_update! rides the step kernel (k_fast_step2<…,4>): charged the fused dataflow's compulsory bytes,
         # and the in-loop direction kernel no longer parks y_next
         pless = hasattr(var, "stats") and var.stats().get("p_less_loops", 0) > 0     # … and P = A_g·R is neither read nor written
-        per_kernel_bytes["fast_step"] = per_kernel_bytes["fast_step_upd_pless" if pless else "fast_step_upd"]
+        ring = hasattr(var, "stats") and var.stats().get("ring_history_loops", 0) > 0   # … and the history is kept as (α, D), (G, G')
+        per_kernel_bytes["fast_step"] = per_kernel_bytes["fast_step_ring" if ring else ("fast_step_upd_pless" if pless else "fast_step_upd")]
         per_kernel_bytes["lbfgs_dir"] = per_kernel_bytes["lbfgs_dir_noynext"]
     candidates = [k for k in per_kernel_bytes if k in prof_all]
     dominant = max(candidates, key=lambda k: prof_all[k][1]) if candidates else "fast_step"
@@ -452,7 +456,9 @@ def measure_config(sj, abi, data, r, seed, K=200, W=20, P=40, parity_iters=PARIT
     fused_step = prof.get("fast_step", (0, 0.0))[0] and not prof.get("lbfgs_update", (0, 0.0))[0]
     fused_spmm = prof.get("spmm", (0, 0.0))[0] and not prof.get("lbfgs_update", (0, 0.0))[0] and not prof.get("fast_step", (0, 0.0))[0]
     if fused_step:
-        per_kernel["fast_step"] = per_kernel["fast_step_upd_pless" if var.stats().get("p_less_loops", 0) > 0 else "fast_step_upd"]
+        st_ = var.stats()
+        per_kernel["fast_step"] = per_kernel["fast_step_ring" if st_.get("ring_history_loops", 0) > 0 else
+                                             ("fast_step_upd_pless" if st_.get("p_less_loops", 0) > 0 else "fast_step_upd")]
         per_kernel["lbfgs_dir"] = per_kernel["lbfgs_dir_noynext"]
     if fused_spmm:
         per_kernel["spmm"] = per_kernel["spmm_upd"]

@@ -14,7 +14,7 @@ python3 - "$OUT" <<'PY'
 import sys, glob, csv, collections, statistics, json, shutil
 out = sys.argv[1]
 SCOPE = {"k_spmm_tile": "spmm_W", "k_spmm_fast": "spmm_W", "k_lbfgs_update": "lbfgs_update", "k_lbfgs_dir": "lbfgs_dir",
-         "k_fast_step2": "fast_step", "k_lbfgs_boundary": "lbfgs_boundary", "k_ls_solve_fast": "ls_solve_fast"}
+         "k_fast_step2": "fast_step", "k_fast_step_ring": "fast_step", "k_lbfgs_dir_ring": "lbfgs_dir", "k_lbfgs_boundary": "lbfgs_boundary", "k_ls_solve_fast": "ls_solve_fast"}
 def short(name):
     n = name.split("(")[0].replace("void ", "")
     return n.split("<")[0]
