@@ -1161,18 +1161,20 @@ k_fast_step2(int n, int m, DevFast ff, double* __restrict__ R, double* __restric
   }
 }
 
-// k_fast_step2<LPR, VEC, HMU, true, true, true> on the ring form of the history (k_dense.h): G_old and D are read at position
-// ring_k of their rings, G_new goes to position ring_k + 1, and neither s_j nor y_j is stored — the Gram dots of the new pair
-// with the other pairs are formed from y_i = G(ring_k − i) − G(ring_k − i − 1) and s_i = α_i·D(ring_k − 1 − i), the values the
-// stored form would have read back: 10N bytes read, 2N written per iteration instead of 10N + 4N.  A row is one chunk
-// (r ≤ LPR·VEC); the head (the line-search scalar stage) and phase A are those of k_fast_step2.
-template <int LPR, int VEC, int HMU>
+// The singleton step kernel (k_fast_step2<LPR, VEC, HMU, true, …>) on the ring form of the history (k_dense.h): G_old and D
+// are read at position ring_k of their rings, G_new goes to position ring_k + 1, and neither s_j nor y_j is stored — the Gram
+// dots of the new pair with the other pairs are formed from y_i = G(ring_k − i) − G(ring_k − i − 1) and s_i = α_i·D(ring_k − 1 − i),
+// the values the stored form would have read back: 2N bytes less written per iteration.  A row is one chunk (r ≤ LPR·VEC).
+// PB = false: k_fast_step2<…, true, true, true> — P-less (G carried forward), the line-search scalar stage as its head.
+// PB = true:  k_fast_step2<…, true> — P += α·W, G = 2·(y_g·P + d(y)∘R + Σ_c WS[c]·B[c]); the scalars come from k_ls_solve_fast.
+template <int LPR, int VEC, int HMU, bool PB = false>
 __global__ void __launch_bounds__(SDPLR_NT)
 k_fast_step_ring(int n, int m, DevFast ff, double* __restrict__ R, const double* __restrict__ W, int r,
                  double* __restrict__ yvec, const double* __restrict__ lam, const double* __restrict__ lam_ub,
                  double* __restrict__ pv_raw, const double* __restrict__ lb, double* __restrict__ pv,
                  const double* __restrict__ A_RD, const double* __restrict__ A_DD, double* __restrict__ partials,
-                 DevCtrl* __restrict__ c, int check_done, FactorArena A, int h, int nb_ls) {
+                 DevCtrl* __restrict__ c, int check_done, FactorArena A, int h, int nb_ls,
+                 double* __restrict__ P = nullptr, DevLowRank lr = DevLowRank{}, const double* __restrict__ WS = nullptr) {
   static_assert(HMU >= 1, "the ring form rides the fused update");
   __shared__ double sh[2 * (SDPLR_NT / 64)];
   __shared__ double shl[10 * (SDPLR_NT / 64)];
@@ -1183,9 +1185,13 @@ k_fast_step_ring(int n, int m, DevFast ff, double* __restrict__ R, const double*
   const long long total = (long long)gridDim.x * G;
   const double sigma = c->sigma;
   const int latest = c->latest, rk = c->ring_k, rn = c->ring_n, rj0 = c->ring_j0;
-  double a;
+  double a, yg = 1.0;
   bool upd;
-  {
+  if constexpr (PB) {
+    a = c->alpha;
+    yg = yvec[ff.gid_g];
+    upd = c->reldelta_exit == 0;
+  } else {
     const double obj0 = c->obj, amax = c->alpha_max, last = c->lastval, feps = c->fprec_eps;
     double s10[10];
     {
@@ -1294,7 +1300,7 @@ k_fast_step_ring(int n, int m, DevFast ff, double* __restrict__ R, const double*
       const int e0 = ff.drow_ptr[j], e1 = ff.drow_ptr[j + 1];
       for (int e = e0; e < e1; e++) {
         const int k = ff.drow_gid[e];
-        djo += ff.drow_val[e] * yvec[k];                            // y as the previous g! left it
+        if (!PB) djo += ff.drow_val[e] * yvec[k];                   // y as the previous g! left it
         const double v = pv_raw[k] + a * (a * A_DD[k] + A_RD[k]);   // src/linesearch.jl:118
         double yk;
         if (k < m) {
@@ -1312,7 +1318,7 @@ k_fast_step_ring(int n, int m, DevFast ff, double* __restrict__ R, const double*
       }
     }
     for (int i0 = 0; i0 < nrows; i0 += 2) {
-      vecd<VEC> xx[2], dd[2], ww[2], gv[2][HMU], dv[2][HO];
+      vecd<VEC> xx[2], pq[2], dd[2], ww[2], gv[2][HMU], dv[2][HO];
       double dj[2], dq[2];
       unsigned off[2];
 #pragma unroll
@@ -1323,7 +1329,7 @@ k_fast_step_ring(int n, int m, DevFast ff, double* __restrict__ R, const double*
         dq[u] = __shfl(djo, i, LPR);
         off[u] = (unsigned)(((unsigned long long)j * (unsigned)r + (unsigned)ch0) * 8ull);
 #pragma unroll
-        for (int q = 0; q < VEC; q++) xx[u].v[q] = dd[u].v[q] = ww[u].v[q] = 0.0;
+        for (int q = 0; q < VEC; q++) xx[u].v[q] = pq[u].v[q] = dd[u].v[q] = ww[u].v[q] = 0.0;
 #pragma unroll
         for (int l = 0; l < HMU; l++)
 #pragma unroll
@@ -1334,6 +1340,7 @@ k_fast_step_ring(int n, int m, DevFast ff, double* __restrict__ R, const double*
           for (int q = 0; q < VEC; q++) dv[u][l].v[q] = 0.0;
         if (ch0 < r) {
           xx[u] = ldrow<VEC>(rowat(R, off[u]));
+          if (PB) pq[u] = ldrow<VEC>(rowat(P, off[u]));
           dd[u] = ldrow<VEC>(rowat(D, off[u]));
           ww[u] = ldrow<VEC>(rowat(W, off[u]));
 #pragma unroll
@@ -1349,14 +1356,37 @@ k_fast_step_ring(int n, int m, DevFast ff, double* __restrict__ R, const double*
         vecd<VEC> x = xx[u];
         const vecd<VEC> d = dd[u], w = ww[u], go = gv[u][0];
         vecd<VEC> g;
-        // G_new = G_old + 2·(α·W + d_new∘R_new − d_old∘R_old)   (y_g ≡ 1: A_g is the cost matrix)
+        if constexpr (PB) {
+          vecd<VEC> pp = pq[u];
 #pragma unroll
-        for (int q = 0; q < VEC; q++) {
-          const double xo = x.v[q];
-          x.v[q] += a * d.v[q];
-          const double t = a * w.v[q] + (x.v[q] * dj[u] - xo * dq[u]);
-          g.v[q] = go.v[q] + 2.0 * t;
-          red[0] += g.v[q] * g.v[q];
+          for (int q = 0; q < VEC; q++) {
+            x.v[q] += a * d.v[q];
+            pp.v[q] += a * w.v[q];
+            g.v[q] = pp.v[q] * yg + x.v[q] * dj[u];
+          }
+          const long long jrow = j0 + i0 + u;
+          for (int cc = 0; cc < lr.ST; cc++) {
+            const double bb = lr.Bcat[(long long)cc * n + jrow];
+            const vecd<VEC> ws = ldrow<VEC>(WS + (long long)cc * r + ch0);
+#pragma unroll
+            for (int q = 0; q < VEC; q++) g.v[q] += ws.v[q] * bb;
+          }
+#pragma unroll
+          for (int q = 0; q < VEC; q++) {
+            g.v[q] *= 2.0;
+            red[0] += g.v[q] * g.v[q];
+          }
+          strow<VEC>(rowat(P, off[u]), pp);
+        } else {
+          // G_new = G_old + 2·(α·W + d_new∘R_new − d_old∘R_old)   (y_g ≡ 1: A_g is the cost matrix)
+#pragma unroll
+          for (int q = 0; q < VEC; q++) {
+            const double xo = x.v[q];
+            x.v[q] += a * d.v[q];
+            const double t = a * w.v[q] + (x.v[q] * dj[u] - xo * dq[u]);
+            g.v[q] = go.v[q] + 2.0 * t;
+            red[0] += g.v[q] * g.v[q];
+          }
         }
         strow<VEC>(rowat(R, off[u]), x);
         strow<VEC>(rowat(Gnew, off[u]), g);

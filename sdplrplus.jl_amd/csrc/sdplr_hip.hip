@@ -210,7 +210,7 @@ struct sdplr_hip_solver {
   int nb_dense = 1, nb_m = 1, nb_sddmm = 1, nb_spmm = 1, nb_spmv = 1, nb_nnzT = 1, nb_nnzS = 1, nb_n = 1;
 
   // captured batch of inner iterations (hipGraph), per line-search kind; rebuilt after reset_rank
-  hipGraphExec_t graph_exec[4] = {nullptr, nullptr, nullptr, nullptr};   // exact line search, Armijo, exact with the P-less step kernel, … on the ring form
+  hipGraphExec_t graph_exec[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // exact line search, Armijo, exact with the P-less step kernel, the last and the first on the ring form
   int graph_iters = 8;
   bool graph_disabled = false;
   hipGraphExec_t lz_graph = nullptr;   // three Lanczos steps (one rotation of the vector buffers)
@@ -1363,10 +1363,20 @@ bool step_can_drop_P(const S* s) {
 // the ring form of the history (k_dense.h) rides the P-less step kernel with the line-search head on the tile path: rows
 // of one chunk, 16-byte pieces, an even number of elements, h ≤ 4
 int tile_shape_lpr(const S* s);
-bool ring_shape_ok(const S* s) {
-  return step_can_drop_P(s) && !s->no_ring && !s->no_lshead && s->n_extra == 1 && s->VEC == 2 && s->LPR >= 4 &&
+bool ring_shape_common(const S* s) {
+  return s->fast && s->fast_singleton && step_fuses_update(s) && !s->dot_descent && !s->no_ring && s->VEC == 2 && s->LPR >= 4 &&
          s->r <= (int64_t)s->LPR * s->VEC && (s->N & 1) == 0 && s->use_tile && s->tile_lpr == tile_shape_lpr(s) &&
-         !s->tile_panels && s->nb_tile <= 4 * SDPLR_NT && s->HM == 4 && !s->lit;
+         !s->tile_panels && s->HM == 4 && !s->lit;
+}
+// … the P-less step kernel with the line-search head (MaxCut-shaped instances)
+bool ring_shape_ok(const S* s) {
+  return ring_shape_common(s) && step_can_drop_P(s) && !s->no_lshead && s->n_extra == 1 && s->nb_tile <= 4 * SDPLR_NT;
+}
+// … the P-based one (a rank-one constraint — MinBisection — or a P-less loop that may not trust its G): the projections
+// come out of the tile kernel, or there are none (k_lr_project reads dirt where it always is)
+bool ring_shape_pb_ok(const S* s) {
+  const bool lr_fused = s->lr.ST == 1 && s->r <= (int64_t)s->tile_lpr * s->VEC && !s->no_lrfuse;
+  return ring_shape_common(s) && (s->lr.ST == 0 || lr_fused);
 }
 
 int alloc_factors(S* s) {
@@ -2183,7 +2193,7 @@ int32_t sdplr_hip_destroy(S* s) {
     if (s->snap_ev[k]) pool_event_free(s->snap_ev[k]);
     if (s->graph_exec[k]) (void)hipGraphExecDestroy(s->graph_exec[k]);
   }
-  for (int k = 2; k < 4; k++)
+  for (int k = 2; k < 5; k++)
     if (s->graph_exec[k]) (void)hipGraphExecDestroy(s->graph_exec[k]);
   if (s->stream) { (void)hipStreamSynchronize(s->stream); pool_stream_free(s->stream); }
   delete s;
@@ -2197,7 +2207,7 @@ int32_t sdplr_hip_reset_rank(S* s, int64_t new_r) {
   HIPCK(s, hipStreamSynchronize(s->stream));
   if (s->arena.base) pool_free(s->arena.base);
   s->arena.base = nullptr;
-  for (int k = 0; k < 4; k++)
+  for (int k = 0; k < 5; k++)
     if (s->graph_exec[k]) { (void)hipGraphExecDestroy(s->graph_exec[k]); s->graph_exec[k] = nullptr; }
   // everything sized by the rank is released before it is re-allocated (the graphs above hold their pointers)
   for (double** p : {&s->lr_part, &s->lr_W, &s->lr_WS, &s->scratchF[0], &s->scratchF[1]}) { dfree(s, *p); *p = nullptr; }
@@ -2846,7 +2856,7 @@ void enq_iteration_fast2(S* s) {
   // lbfgs_update! fused into the step kernel for h ≤ 4 (its Gram partials then come from nb_step blocks)
   const bool upd_fused = step_fuses_update(s);
   s->gram_nb = upd_fused ? s->nb_step : s->nb_upd;
-  if (s->ring_now) {   // ring form of the history (k_dense.h): seam, direction, gather, step — the same four launches
+  if (s->ring_now && s->pdrop_now) {   // ring form of the history (k_dense.h): seam, direction, gather, step — the same four launches
     enq_boundary(s, 0, 1, 1, 1, 1);
     {
       ProfScope ps(s, "lbfgs_dir");
@@ -2862,6 +2872,12 @@ void enq_iteration_fast2(S* s) {
     RING_DISPATCH((k_fast_step_ring<LPR, VEC, 4><<<s->nb_step, SDPLR_NT, 5 * 4 * SDPLR_NT * sizeof(double), s->stream>>>((int)s->n, (int)s->m, s->ff, R, W, (int)s->r, s->y, s->lambda, s->lambda_ub, s->pv_raw, s->pv_lb, s->pv, s->A_RD, s->A_DD, s->partials, s->ctrl, 1, s->arena, (int)s->h, s->nb_tile)))
     return;
   }
+  const bool ring_pb = s->ring_now;   // … the P-based step kernel on the ring form: the launches below, D found on the ring
+  if (ring_pb) {
+    enq_boundary(s, 0, 1, 1, 1, 1);
+    ProfScope ps(s, "lbfgs_dir");
+    k_lbfgs_dir_ring<4, true><<<s->nb_dense, SDPLR_NT, 0, s->stream>>>(s->ctrl, s->arena, s->N, (int)s->h, 1);
+  } else
   enq_lbfgs_dir(s, 1, 1, 1, upd_fused && !s->dot_descent);                            // :197-205
 #ifdef SDPLR_PROBE_TILE_HIST
   s->ff.probe_hist[0] = G;
@@ -2875,16 +2891,16 @@ void enq_iteration_fast2(S* s) {
     if (s->use_tile && s->tile_lpr == tile_shape_lpr(s) && s->n * s->r * 8 < (1LL << 32)) {
       lr_fused = s->lr.ST == 1 && s->r <= (int64_t)s->tile_lpr * s->VEC && !s->no_lrfuse;
       const size_t lds = ((size_t)SDPLR_NT * s->VEC * (s->tile.K + 1) + (size_t)(SDPLR_NT / s->tile_lpr) * (2 * s->tile.K + 8) + (lr_fused ? (size_t)(SDPLR_NT / 64) * 2 * s->tile_lpr * s->VEC : 0)) * sizeof(double);
-      if (lr_fused && s->tile.gdiag) { TLV_DISPATCH((k_spmm_tile<LPR, VEC, 1, true><<<s->nb_tile, SDPLR_NT, lds, s->stream>>>(s->tile, (int)s->n, (int)s->m, s->ff, R, D, P, W, (int)s->r, s->lambda, s->pv_raw, s->A_RD, s->A_DD, s->partials, s->ctrl, 1, s->lr, s->lr_part, 0))) }
-      else if (lr_fused) { TLV_DISPATCH((k_spmm_tile<LPR, VEC, 1><<<s->nb_tile, SDPLR_NT, lds, s->stream>>>(s->tile, (int)s->n, (int)s->m, s->ff, R, D, P, W, (int)s->r, s->lambda, s->pv_raw, s->A_RD, s->A_DD, s->partials, s->ctrl, 1, s->lr, s->lr_part, 0))) }
+      if (lr_fused && s->tile.gdiag) { TLV_DISPATCH((k_spmm_tile<LPR, VEC, 1, true><<<s->nb_tile, SDPLR_NT, lds, s->stream>>>(s->tile, (int)s->n, (int)s->m, s->ff, R, D, P, W, (int)s->r, s->lambda, s->pv_raw, s->A_RD, s->A_DD, s->partials, s->ctrl, 1, s->lr, s->lr_part, 0, ring_pb ? 1 : 0, s->arena))) }
+      else if (lr_fused) { TLV_DISPATCH((k_spmm_tile<LPR, VEC, 1><<<s->nb_tile, SDPLR_NT, lds, s->stream>>>(s->tile, (int)s->n, (int)s->m, s->ff, R, D, P, W, (int)s->r, s->lambda, s->pv_raw, s->A_RD, s->A_DD, s->partials, s->ctrl, 1, s->lr, s->lr_part, 0, ring_pb ? 1 : 0, s->arena))) }
       else if (s->tile_panels && s->VEC == 2 && s->tile_lpr == 16 && s->LPR == 16 && !s->tile.gdiag) {
         // rank panels: the same kernel with 8 bytes per lane walks the lists once per 16-column half of the rank, so a
         // gathered row is 128 B and the XCD's L2 holds twice as many of them (tile kernel)
         const size_t lds1 = ((size_t)SDPLR_NT * 1 * (s->tile.K + 1) + (size_t)(SDPLR_NT / s->LPR) * (2 * s->tile.K + 8)) * sizeof(double);
         k_spmm_tile<16, 1, 0><<<s->nb_tile, SDPLR_NT, lds1, s->stream>>>(s->tile, (int)s->n, (int)s->m, s->ff, R, D, P, W, (int)s->r, s->lambda, s->pv_raw, s->A_RD, s->A_DD, s->partials, s->ctrl, 1, s->lr, s->lr_part, 0);
       }
-      else if (s->tile.gdiag) { TLV_DISPATCH((k_spmm_tile<LPR, VEC, 0, true><<<s->nb_tile, SDPLR_NT, lds, s->stream>>>(s->tile, (int)s->n, (int)s->m, s->ff, R, D, P, W, (int)s->r, s->lambda, s->pv_raw, s->A_RD, s->A_DD, s->partials, s->ctrl, 1, s->lr, s->lr_part, 0))) }
-      else { TLV_DISPATCH((k_spmm_tile<LPR, VEC, 0><<<s->nb_tile, SDPLR_NT, lds, s->stream>>>(s->tile, (int)s->n, (int)s->m, s->ff, R, D, P, W, (int)s->r, s->lambda, s->pv_raw, s->A_RD, s->A_DD, s->partials, s->ctrl, 1, s->lr, s->lr_part, 0))) }
+      else if (s->tile.gdiag) { TLV_DISPATCH((k_spmm_tile<LPR, VEC, 0, true><<<s->nb_tile, SDPLR_NT, lds, s->stream>>>(s->tile, (int)s->n, (int)s->m, s->ff, R, D, P, W, (int)s->r, s->lambda, s->pv_raw, s->A_RD, s->A_DD, s->partials, s->ctrl, 1, s->lr, s->lr_part, 0, ring_pb ? 1 : 0, s->arena))) }
+      else { TLV_DISPATCH((k_spmm_tile<LPR, VEC, 0><<<s->nb_tile, SDPLR_NT, lds, s->stream>>>(s->tile, (int)s->n, (int)s->m, s->ff, R, D, P, W, (int)s->r, s->lambda, s->pv_raw, s->A_RD, s->A_DD, s->partials, s->ctrl, 1, s->lr, s->lr_part, 0, ring_pb ? 1 : 0, s->arena))) }
     } else {
       LV_DISPATCH((k_spmm_fast<LPR, VEC><<<s->nb_spmm, SDPLR_NT, 0, s->stream>>>(s->spg, (int)s->m, s->ff, R, D, P, W, (int)s->r, s->lambda, s->pv_raw, s->A_RD, s->A_DD, s->partials, s->ctrl, 1)))
     }
@@ -2913,6 +2929,8 @@ void enq_iteration_fast2(S* s) {
       LV_DISPATCH((k_fast_step2<LPR, VEC, 4, true, true, true><<<s->nb_step, SDPLR_NT, 5 * 4 * SDPLR_NT * sizeof(double), s->stream>>>((int)s->n, (int)s->m, s->ff, R, D, P, W, G, (int)s->r, s->y, s->lambda, s->lambda_ub, s->pv_raw, s->pv_lb, s->pv, s->A_RD, s->A_DD, s->lr, s->lr_WS, s->partials, s->ctrl, 1, s->arena, (int)s->h, 1, nb_ls)))
     } else if (upd_fused && s->pdrop_now) {   // … P-less: G carried forward from G_old (k_sparse.h, PDROP)
       LV_DISPATCH((k_fast_step2<LPR, VEC, 4, true, true><<<s->nb_step, SDPLR_NT, 5 * 4 * SDPLR_NT * sizeof(double), s->stream>>>((int)s->n, (int)s->m, s->ff, R, D, P, W, G, (int)s->r, s->y, s->lambda, s->lambda_ub, s->pv_raw, s->pv_lb, s->pv, s->A_RD, s->A_DD, s->lr, s->lr_WS, s->partials, s->ctrl, 1, s->arena, (int)s->h, 1)))
+    } else if (ring_pb) {   // … the same on the ring form of the history (no s_j, y_j stored)
+      RING_DISPATCH((k_fast_step_ring<LPR, VEC, 4, true><<<s->nb_step, SDPLR_NT, 5 * 4 * SDPLR_NT * sizeof(double), s->stream>>>((int)s->n, (int)s->m, s->ff, R, W, (int)s->r, s->y, s->lambda, s->lambda_ub, s->pv_raw, s->pv_lb, s->pv, s->A_RD, s->A_DD, s->partials, s->ctrl, 1, s->arena, (int)s->h, 0, P, s->lr, s->lr_WS)))
     } else if (upd_fused) {   // … and lbfgs_update! (:244-246) in the same pass
       LV_DISPATCH((k_fast_step2<LPR, VEC, 4, true><<<s->nb_step, SDPLR_NT, 5 * 4 * SDPLR_NT * sizeof(double), s->stream>>>((int)s->n, (int)s->m, s->ff, R, D, P, W, G, (int)s->r, s->y, s->lambda, s->lambda_ub, s->pv_raw, s->pv_lb, s->pv, s->A_RD, s->A_DD, s->lr, s->lr_WS, s->partials, s->ctrl, 1, s->arena, (int)s->h, s->dot_descent ? 0 : 1)))
     } else {
@@ -3744,8 +3762,11 @@ static int32_t inner_loop_impl(S* s, double normC, double normb, int32_t grel, i
   if (s && s->finalized && s->ring_on) {
     const bool fast2_ = s->fast && s->fast_singleton && !use_armijo;
     static const int64_t refresh_iters_ = getenv("SDPLR_HIP_P_REFRESH_ITERS") ? atoll(getenv("SDPLR_HIP_P_REFRESH_ITERS")) : 256;
-    ring_keep = fast2_ && ring_shape_ok(s) && s->G_consistent && !s->ring_unc && Lio && gnio && pnio &&
-                max_local_iters >= 1 && !rs_loop_applies(s, use_armijo) && (resume || s->G_age < refresh_iters_) &&
+    // (a P-less loop due for its refresh of G writes G at its own place: not on a ring)
+    const bool would_pdrop = fast2_ && step_can_drop_P(s) && s->G_consistent && (!resume || s->pdrop_now);
+    const bool refresh_due = would_pdrop && !resume && s->G_age >= refresh_iters_;
+    ring_keep = fast2_ && ring_shape_common(s) && !refresh_due && !s->ring_unc && Lio && gnio && pnio &&
+                max_local_iters >= 1 && !rs_loop_applies(s, use_armijo) &&
                 !(s->gram_dirty || s->ynext_pending || s->sg_stale);
     if (ring_keep) s->ring_on = false;   // (NEED_FINAL_RW leaves it alone; set again below)
   }
@@ -3794,7 +3815,8 @@ static int32_t inner_loop_impl(S* s, double normC, double normb, int32_t grel, i
     s->S_stale = false;
     s->G_age = 0;
   }
-  s->ring_now = s->pdrop_now && ring_shape_ok(s);   // (a ring is entered on whatever history is stored: k_dense.h)
+  // (a ring is entered on whatever history is stored: k_dense.h)
+  s->ring_now = fast2 && (s->pdrop_now ? ring_shape_ok(s) : ring_shape_pb_ok(s));
   if (getenv("SDPLR_HIP_DEBUG"))
     fprintf(stderr, "[sdplr_hip] inner_loop: ring %d (kept %d, history empty %d, pdrop %d, shape %d: can_drop %d n_extra %d VEC %d LPR %d tile %d/%d nb_tile %d)\n",
             (int)s->ring_now, (int)ring_keep, (int)hist_was_empty, (int)s->pdrop_now, (int)ring_shape_ok(s), (int)step_can_drop_P(s), s->n_extra,
@@ -3816,7 +3838,7 @@ static int32_t inner_loop_impl(S* s, double normC, double normb, int32_t grel, i
     if (fresh || was != c->ring_on)
       HIPCK(s, hipMemcpyAsync(&s->ctrl->ring_on, &c->ring_on, sizeof(DevCtrl) - offsetof(DevCtrl, ring_on), hipMemcpyHostToDevice, s->stream));
   }
-  const int ar = use_armijo ? 1 : (s->ring_now ? 3 : (s->pdrop_now ? 2 : 0));
+  const int ar = use_armijo ? 1 : (s->ring_now ? (s->pdrop_now ? 3 : 4) : (s->pdrop_now ? 2 : 0));
   const bool edgep = !fastp && edge_applies(s, use_armijo);
   auto enq_iter = [&]() {
     if (fast2) enq_iteration_fast2(s);

@@ -134,3 +134,46 @@ def test_ring_and_lbfgs_clear(hip_abi, monkeypatch):
     assert o_r == o_s
     _same(a_r, a_s)
     _same(b_r, b_s)
+
+
+@pytest.mark.parametrize("family,toggle,r", [("minbis", None, 8), ("minbis", None, 32), ("cutnorm", None, 8),
+                                              ("maxcut", "SDPLR_HIP_NO_PDROP", 16), ("maxcut", "SDPLR_HIP_NO_LSHEAD", 16)])
+def test_ring_form_on_the_other_singleton_loops(hip_abi, oracle_abi, monkeypatch, family, toggle, r):
+    """The ring form also carries the P-based step kernel (MinBisection's rank-one constraint with its projections out of the
+    tile kernel; a MaxCut loop told to keep P) and CutNorm's P-less loop: bitwise the stored form after a chain of calls that
+    wraps the ring, materialises it, and enters a new one on the stored pairs; 1e-8 against the oracle.  A shape the ring
+    form does not take (the P-less kernel without its line-search head) must simply stay on the stored form."""
+    g = problems.gnp_graph(360, 0.03, 21)
+    data = {"minbis": problems.minimum_bisection_data, "cutnorm": problems.cutnorm_data, "maxcut": problems.maxcut_data}[family](g)
+    normC, normb = data.normC(), float(np.linalg.norm(data.b))
+    h = 4
+    if toggle:
+        monkeypatch.setenv(toggle, "1")
+
+    def run(abi, ring):
+        if ring:
+            monkeypatch.delenv("SDPLR_HIP_NO_RING", raising=False)
+        else:
+            monkeypatch.setenv("SDPLR_HIP_NO_RING", "1")
+        s_, _ = make_solver(abi, data, r, seed=13, h=h)
+        st = s_.fg(normC, normb)
+        out1 = s_.inner_loop(normC, normb, True, True, False, 0.0, -1e300, 2, 0.0, *st)
+        out2 = s_.inner_loop(normC, normb, True, True, False, 0.0, -1e300, 7, 0.0, *out1[:3])
+        a = _state(s_, h)
+        out3 = s_.inner_loop(normC, normb, True, True, False, 0.0, -1e300, 3, 0.0, *out2[:3])
+        b = _state(s_, h)
+        stats = s_.stats() if abi is hip_abi else None
+        s_.close()
+        return (out1, out2, out3), a, b, stats
+
+    o_r, a_r, b_r, st = run(hip_abi, True)
+    o_s, a_s, b_s, st_s = run(hip_abi, False)
+    expect_ring = toggle != "SDPLR_HIP_NO_LSHEAD"
+    assert st["ring_history_loops"] == (3 if expect_ring else 0) and st_s["ring_history_loops"] == 0
+    assert o_r == o_s
+    _same(a_r, a_s)
+    _same(b_r, b_s)
+    o_o, a_o, b_o, _ = run(oracle_abi, False)
+    for x, z in zip(o_r, o_o):
+        assert x[4] == z[4] and np.allclose(x[:3], z[:3], rtol=1e-8)
+    assert rel(b_r["R"], b_o["R"]) < 1e-8
