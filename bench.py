@@ -131,6 +131,7 @@ def algorithmic_bytes(d, h):
         # … and on the ring form of the history (stats: ring_history_loops): s_j = α_j·D_j and y_j = G_{j+1} − G_j are not stored
         # at all — R, D, W, G_old in; R, G out
         "fast_step_ring": 6 * N,
+        "fast_step_ring_pb": 8 * N,                   # … the P-based kernel on the ring form: R, D, P, W, G_old in; R, P, G out
     }
     b_iter = ((2 * h + 1) * N + 2 * N      # lbfgs_dir!
               + 2 * N                      # dot(dirt, Gt)
@@ -334,7 +335,8 @@ def main():
         # and the in-loop direction kernel no longer parks y_next
         pless = hasattr(var, "stats") and var.stats().get("p_less_loops", 0) > 0     # … and P = A_g·R is neither read nor written
         ring = hasattr(var, "stats") and var.stats().get("ring_history_loops", 0) > 0   # … and the history is kept as (α, D), (G, G')
-        per_kernel_bytes["fast_step"] = per_kernel_bytes["fast_step_ring" if ring else ("fast_step_upd_pless" if pless else "fast_step_upd")]
+        per_kernel_bytes["fast_step"] = per_kernel_bytes[("fast_step_ring" if pless else "fast_step_ring_pb") if ring else
+                                                         ("fast_step_upd_pless" if pless else "fast_step_upd")]
         per_kernel_bytes["lbfgs_dir"] = per_kernel_bytes["lbfgs_dir_noynext"]
     candidates = [k for k in per_kernel_bytes if k in prof_all]
     dominant = max(candidates, key=lambda k: prof_all[k][1]) if candidates else "fast_step"
@@ -457,8 +459,9 @@ def measure_config(sj, abi, data, r, seed, K=200, W=20, P=40, parity_iters=PARIT
     fused_spmm = prof.get("spmm", (0, 0.0))[0] and not prof.get("lbfgs_update", (0, 0.0))[0] and not prof.get("fast_step", (0, 0.0))[0]
     if fused_step:
         st_ = var.stats()
-        per_kernel["fast_step"] = per_kernel["fast_step_ring" if st_.get("ring_history_loops", 0) > 0 else
-                                             ("fast_step_upd_pless" if st_.get("p_less_loops", 0) > 0 else "fast_step_upd")]
+        pl_, rg_ = st_.get("p_less_loops", 0) > 0, st_.get("ring_history_loops", 0) > 0
+        per_kernel["fast_step"] = per_kernel[("fast_step_ring" if pl_ else "fast_step_ring_pb") if rg_ else
+                                             ("fast_step_upd_pless" if pl_ else "fast_step_upd")]
         per_kernel["lbfgs_dir"] = per_kernel["lbfgs_dir_noynext"]
     if fused_spmm:
         per_kernel["spmm"] = per_kernel["spmm_upd"]

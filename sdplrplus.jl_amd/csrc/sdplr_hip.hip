@@ -2625,6 +2625,17 @@ void enq_lbfgs_dir(S* s, int negate, int in_loop, int apply_fallback, bool skip_
   k_descent<<<nb, SDPLR_NT, 0, s->stream>>>(s->ctrl, s->arena, s->N, s->nb_dense, apply_fallback, in_loop, s->partials);
 }
 
+// the in-loop seam and direction on the ring form of the history (k_dense.h)
+void enq_dir_ring(S* s) {
+  enq_boundary(s, 0, 1, 1, 1, 1);
+  ProfScope ps(s, "lbfgs_dir");
+  // (history loads non-temporal only when the arena does not fit the 256 MiB Infinity Cache: k_dense.h, NTH)
+  static const long long nt_above = getenv("SDPLR_HIP_DIR_NT_ABOVE_MB") ? atoll(getenv("SDPLR_HIP_DIR_NT_ABOVE_MB")) << 20 : 200LL << 20;
+  const long long arena_bytes = (long long)(3 + 2 * s->h + (s->fast ? 2 : 0)) * s->arena.stride * (long long)sizeof(double);
+  if (arena_bytes > nt_above) k_lbfgs_dir_ring<4, true><<<s->nb_dense, SDPLR_NT, 0, s->stream>>>(s->ctrl, s->arena, s->N, (int)s->h, 1);
+  else k_lbfgs_dir_ring<4, false><<<s->nb_dense, SDPLR_NT, 0, s->stream>>>(s->ctrl, s->arena, s->N, (int)s->h, 1);
+}
+
 // lbfgs_update!: the pass over the history; its partials are folded by the next seam kernel
 void enq_lbfgs_update(S* s, int chk) {
   if (s->h == 0) return;
@@ -2857,11 +2868,7 @@ void enq_iteration_fast2(S* s) {
   const bool upd_fused = step_fuses_update(s);
   s->gram_nb = upd_fused ? s->nb_step : s->nb_upd;
   if (s->ring_now && s->pdrop_now) {   // ring form of the history (k_dense.h): seam, direction, gather, step — the same four launches
-    enq_boundary(s, 0, 1, 1, 1, 1);
-    {
-      ProfScope ps(s, "lbfgs_dir");
-      k_lbfgs_dir_ring<4, true><<<s->nb_dense, SDPLR_NT, 0, s->stream>>>(s->ctrl, s->arena, s->N, (int)s->h, 1);
-    }
+    enq_dir_ring(s);
     {
       ProfScope ps(s, "spmm_W");
       const size_t lds = ((size_t)SDPLR_NT * s->VEC * (s->tile.K + 1) + (size_t)(SDPLR_NT / s->tile_lpr) * (2 * s->tile.K + 8)) * sizeof(double);
@@ -2873,11 +2880,8 @@ void enq_iteration_fast2(S* s) {
     return;
   }
   const bool ring_pb = s->ring_now;   // … the P-based step kernel on the ring form: the launches below, D found on the ring
-  if (ring_pb) {
-    enq_boundary(s, 0, 1, 1, 1, 1);
-    ProfScope ps(s, "lbfgs_dir");
-    k_lbfgs_dir_ring<4, true><<<s->nb_dense, SDPLR_NT, 0, s->stream>>>(s->ctrl, s->arena, s->N, (int)s->h, 1);
-  } else
+  if (ring_pb) enq_dir_ring(s);
+  else
   enq_lbfgs_dir(s, 1, 1, 1, upd_fused && !s->dot_descent);                            // :197-205
 #ifdef SDPLR_PROBE_TILE_HIST
   s->ff.probe_hist[0] = G;

@@ -137,14 +137,16 @@ def test_ring_and_lbfgs_clear(hip_abi, monkeypatch):
 
 
 @pytest.mark.parametrize("family,toggle,r", [("minbis", None, 8), ("minbis", None, 32), ("cutnorm", None, 8),
-                                              ("maxcut", "SDPLR_HIP_NO_PDROP", 16), ("maxcut", "SDPLR_HIP_NO_LSHEAD", 16)])
+                                              ("maxcut", "SDPLR_HIP_NO_PDROP", 16), ("maxcut", "SDPLR_HIP_NO_LSHEAD", 16),
+                                              ("lovasz", None, 8)])
 def test_ring_form_on_the_other_singleton_loops(hip_abi, oracle_abi, monkeypatch, family, toggle, r):
     """The ring form also carries the P-based step kernel (MinBisection's rank-one constraint with its projections out of the
     tile kernel; a MaxCut loop told to keep P) and CutNorm's P-less loop: bitwise the stored form after a chain of calls that
     wraps the ring, materialises it, and enters a new one on the stored pairs; 1e-8 against the oracle.  A shape the ring
     form does not take (the P-less kernel without its line-search head) must simply stay on the stored form."""
     g = problems.gnp_graph(360, 0.03, 21)
-    data = {"minbis": problems.minimum_bisection_data, "cutnorm": problems.cutnorm_data, "maxcut": problems.maxcut_data}[family](g)
+    data = {"minbis": problems.minimum_bisection_data, "cutnorm": problems.cutnorm_data, "maxcut": problems.maxcut_data,
+            "lovasz": problems.lovasz_theta_data}[family](g)
     normC, normb = data.normC(), float(np.linalg.norm(data.b))
     h = 4
     if toggle:
@@ -168,7 +170,7 @@ def test_ring_form_on_the_other_singleton_loops(hip_abi, oracle_abi, monkeypatch
 
     o_r, a_r, b_r, st = run(hip_abi, True)
     o_s, a_s, b_s, st_s = run(hip_abi, False)
-    expect_ring = toggle != "SDPLR_HIP_NO_LSHEAD"
+    expect_ring = toggle != "SDPLR_HIP_NO_LSHEAD" and family != "lovasz"   # (the edge path: measured, no gain — stored form)
     assert st["ring_history_loops"] == (3 if expect_ring else 0) and st_s["ring_history_loops"] == 0
     assert o_r == o_s
     _same(a_r, a_s)
