@@ -286,6 +286,16 @@ int blocks_for(long long work, int per_block, int cap);
     }                                                      \
   } while (0)
 
+// … for the entry points that read or write nothing of the factor arena but R (the dual bound and the eigensolvers work on
+// S(y) and their own vectors, the λ update on the constraint vectors): a history in ring form (k_dense.h) stays a ring, and the
+// lazy dirt ← s_latest stays pending
+#define NEED_FINAL_RW_KEEP_HISTORY(s)                      \
+  do {                                                     \
+    NEED_FINAL(s);                                         \
+    (s)->hc_valid = false;                                 \
+    (s)->G_consistent = false;                             \
+  } while (0)
+
 int have_device() {
   int c = 0;
   if (hipGetDeviceCount(&c) != hipSuccess) return 0;
@@ -1403,7 +1413,12 @@ int alloc_factors(S* s) {
   if (const char* e = getenv("SDPLR_HIP_NB_SPMM")) s->nb_spmm = std::max(1, std::min(atoi(e), 768));
   s->nb_tile = blocks_for(s->tile.n_tiles, SDPLR_NT / std::max(1, s->tile_lpr > 0 ? s->tile_lpr : s->LPR), s->tile_blocks);   // one resident round; taller instances stride
   s->nb_lr = (s->N >= (1LL << 22)) ? 1024 : 256;   // low-rank projection grid (lr_part is sized for 1024)
-  { const int tr = std::min<int>(s->LPR, SDPLR_STEP_TR); s->nb_step = blocks_for((s->n + tr - 1) / tr, G, step_fuses_update(s) ? 512 : 1024); }  // one group per tile of LPR rows; its ‖G‖², ‖pv‖² (and Gram)
+  {
+    // (SDPLR_HIP_NB_STEP: the fused kernel's grid — its 5h Gram sums are folded by ONE block, so more blocks lengthen the seam)
+    static const int nb_step_cap = getenv("SDPLR_HIP_NB_STEP") ? std::max(64, std::min(atoi(getenv("SDPLR_HIP_NB_STEP")), 2048)) : 512;
+    const int tr = std::min<int>(s->LPR, SDPLR_STEP_TR);
+    s->nb_step = blocks_for((s->n + tr - 1) / tr, G, step_fuses_update(s) ? nb_step_cap : 1024);
+  }  // one group per tile of LPR rows; its ‖G‖², ‖pv‖² (and Gram)
                                                                     // partials are folded by the one-block seam kernel: keep them few
   if (const char* e = getenv("SDPLR_HIP_NB_STEP")) s->nb_step = std::max(1, std::min(atoi(e), SDPLR_MAXNB));
   return SDPLR_OK;
@@ -3617,7 +3632,7 @@ int32_t sdplr_hip_axpy_R(S* s, double alpha) {
 }
 int32_t sdplr_hip_update_lambda(S* s) {
   ApiShared api_guard(dev_of(s));
-  NEED_FINAL_RW(s);
+  NEED_FINAL_RW_KEEP_HISTORY(s);
   k_update_lambda<<<s->nb_m, SDPLR_NT, 0, s->stream>>>(s->ctrl, (int)s->m, s->lambda, s->lambda_ub, s->pv_raw);
   return sync_check(s);
 }
@@ -4078,7 +4093,7 @@ int32_t sdplr_hip_major_iteration(S* s, double normC, double normb, int32_t grel
 // ---- Lanczos / dual bound ------------------------------------------------------------------------------
 int32_t sdplr_hip_lanczos(S* s, int64_t q, const double* v0, double* alpha, double* beta, int64_t* steps) {
   ApiShared api_guard(dev_of(s));
-  NEED_FINAL_RW(s);
+  NEED_FINAL_RW_KEEP_HISTORY(s);
   if (!v0 || !alpha || !beta || !steps || q < 1) return fail(s, SDPLR_ERR_INVALID_ARG, "lanczos: bad args");
   ensure_S(s);
   return run_lanczos(s, q, v0, alpha, beta, steps, &api_guard.l);
@@ -4111,14 +4126,14 @@ static int32_t approx_mineig_impl(S* s, int64_t q, const double* v0, double* min
 }
 int32_t sdplr_hip_approx_mineigval_lanczos(S* s, int64_t q, const double* v0, double* mineig) {
   ApiShared api_guard(dev_of(s));
-  NEED_FINAL_RW(s);
+  NEED_FINAL_RW_KEEP_HISTORY(s);
   if (!v0 || !mineig || q < 1) return fail(s, SDPLR_ERR_INVALID_ARG, "approx_mineigval_lanczos: bad args");
   ensure_S(s);
   return approx_mineig_impl(s, q, v0, mineig, &api_guard.l);
 }
 int32_t sdplr_hip_dual_obj(S* s, double trace_bound, int64_t iter, const double* v0, double* dual_value, double* mineig) {
   ApiShared api_guard(dev_of(s));
-  NEED_FINAL_RW(s);
+  NEED_FINAL_RW_KEEP_HISTORY(s);
   if (!v0) return fail(s, SDPLR_ERR_INVALID_ARG, "dual_obj: null v0");
   if (rs_lanczos_ell_applies(s) && s->n >= 2 && getenv("SDPLR_HIP_NO_FUSED_DUAL") == nullptr) {
     // resident route: copy2y (:384), the q Lanczos steps on S(y) (:461-500), the tridiagonal's smallest eigenvalue

@@ -105,7 +105,8 @@ def test_ring_after_the_relative_decrease_exit(hip_abi, monkeypatch):
 
 def test_ring_and_lbfgs_clear(hip_abi, monkeypatch):
     """lbfgs_clear! on a ring keeps what the stored form keeps — G and dirt = s_latest — and the next loop starts a new
-    ring; major_iteration (clear → fg! → loop in one call) goes the same way."""
+    ring; major_iteration (clear → fg! → loop in one call) goes the same way.  The dual bound between loop and clear (the
+    order of src/sdplr.jl:280-389) reads nothing of the history and leaves the ring alone."""
     data = problems.maxcut_data(problems.gnp_graph(450, 0.03, 6))
     normC, normb = data.normC(), float(np.linalg.norm(data.b))
     r, h = 12, 4
@@ -118,6 +119,8 @@ def test_ring_and_lbfgs_clear(hip_abi, monkeypatch):
         s_, _ = make_solver(hip_abi, data, r, seed=2, h=h)
         st = s_.fg(normC, normb)
         out1 = s_.inner_loop(normC, normb, True, True, False, 0.0, -1e300, 7, 0.0, *st)
+        v0 = np.random.Generator(np.random.PCG64(1)).standard_normal(data.n)
+        dual = s_.dual_obj(float(data.n), 0, v0)        # (works on S(y): a ring stays a ring — counted below)
         s_.lbfgs_clear()
         a = _state(s_, h)
         st = s_.fg(normC, normb)
@@ -126,7 +129,7 @@ def test_ring_and_lbfgs_clear(hip_abi, monkeypatch):
         b = _state(s_, h)
         stats = s_.stats()
         s_.close()
-        return (out1, out2, out3), a, b, stats
+        return (out1, out2, out3, dual), a, b, stats
 
     o_r, a_r, b_r, st = run(True)
     o_s, a_s, b_s, _ = run(False)
