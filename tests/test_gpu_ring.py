@@ -182,3 +182,79 @@ def test_ring_form_on_the_other_singleton_loops(hip_abi, oracle_abi, monkeypatch
     for x, z in zip(o_r, o_o):
         assert x[4] == z[4] and np.allclose(x[:3], z[:3], rtol=1e-8)
     assert rel(b_r["R"], b_o["R"]) < 1e-8
+
+
+def test_ring_on_the_eager_route_and_under_the_profiler(hip_abi, monkeypatch):
+    """hipGraph batches (the suite's default), eager launches (SDPLR_HIP_NO_GRAPH) and the per-kernel event timing all enqueue
+    the same ring kernels: the same state bitwise.  A budget of one and of two iterations (shorter than a batch) too."""
+    data = problems.maxcut_data(problems.gnp_graph(420, 0.03, 33))
+    normC, normb = data.normC(), float(np.linalg.norm(data.b))
+    r, h = 16, 4
+
+    def run(mode, ring=True):
+        monkeypatch.delenv("SDPLR_HIP_NO_GRAPH", raising=False)
+        monkeypatch.delenv("SDPLR_HIP_NO_RING", raising=False)
+        if mode == "eager":
+            monkeypatch.setenv("SDPLR_HIP_NO_GRAPH", "1")
+        if not ring:
+            monkeypatch.setenv("SDPLR_HIP_NO_RING", "1")
+        s_, _ = make_solver(hip_abi, data, r, seed=8, h=h)
+        st = s_.fg(normC, normb)
+        outs = []
+        for k in (1, 2, 9, 1, 5):
+            if mode == "profile" and k == 9:
+                s_.profile_enable(True)
+            out = s_.inner_loop(normC, normb, True, True, False, 0.0, -1e300, k, 0.0, *st)
+            st = out[:3]
+            outs.append(out)
+        if mode == "profile":
+            prof = s_.profile()
+            s_.profile_enable(False)
+            assert prof["fast_step"][0] >= 15 and prof["lbfgs_dir"][0] >= 15
+        a = _state(s_, h)
+        stats = s_.stats()
+        s_.close()
+        return outs, a, stats
+
+    o_g, a_g, st_g = run("graph")
+    assert st_g["ring_history_loops"] == 5 and st_g["ring_materializations"] == 1
+    for mode in ("eager", "profile"):
+        o_m, a_m, st_m = run(mode)
+        assert st_m["ring_history_loops"] == 5
+        assert o_m == o_g
+        _same(a_m, a_g)
+    o_s, a_s, _ = run("graph", ring=False)
+    assert o_s == o_g
+    _same(a_s, a_g)
+
+
+def test_ring_left_by_the_time_budget_and_by_a_loop_that_does_not_start(hip_abi):
+    """The time budget ends a loop wherever the device happens to be (no two runs alike): whatever the ring held, the stored
+    form it is turned back into must be consistent — ρ_j = 1/⟨s_j, y_j⟩ for every pair, the newest pair's s = dirt,
+    G the gradient from scratch at R — and a loop that leaves before its first iteration (‖G‖ already below the tolerance)
+    leaves a ring of no pairs, i.e. the history as it found it."""
+    data = problems.maxcut_data(problems.gnp_graph(2000, 0.01, 3))
+    normC, normb = data.normC(), float(np.linalg.norm(data.b))
+    r, h = 32, 4
+    s_, _ = make_solver(hip_abi, data, r, seed=1, h=h)
+    st = s_.fg(normC, normb)
+    out = s_.inner_loop(normC, normb, True, True, False, 0.0, -1e300, 100000, 2e-3, *st)
+    assert out[5] == 3 and out[4] >= h + 2            # EXIT_TIME, after the ring has wrapped
+    a = _state(s_, h)
+    rho = s_.get_vec(cabi.V_LBFGS_RHO)
+    latest = int(s_.get_scalar(cabi.S_LBFGS_LATEST))
+    for j in range(h):
+        assert abs(rho[j] * float(np.sum(a["S"][j] * a["Y"][j])) - 1.0) < 1e-10, j
+    assert np.array_equal(a["D"], a["S"][latest - 1])
+    s_.g()
+    assert rel(a["G"], s_.Gt) < 1e-10
+    assert s_.stats()["ring_history_loops"] == 1 and s_.stats()["ring_materializations"] == 1
+    # a loop that does not start: tolerance above ‖G‖
+    st = s_.fg(normC, normb)
+    out2 = s_.inner_loop(normC, normb, True, True, False, 10.0 * st[1], -1e300, 50, 0.0, *st)
+    assert out2[4] == 0 and out2[5] == 0
+    b = _state(s_, h)
+    for j in range(h):
+        assert np.array_equal(a["S"][j], b["S"][j]) and np.array_equal(a["Y"][j], b["Y"][j])
+    assert np.array_equal(b["D"], a["D"])
+    s_.close()
