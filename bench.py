@@ -579,9 +579,9 @@ def other_configs(sj, abi):
     dd = one.dims()
     Ns = 8.0 * dd["n"] * dd["r"]
     ell_bytes = 4.0 * (dd["nnzS"] - dd["n"]) + 8.0 * 4 * dd["n"]
-    # a team of W workgroups per instance (k_resident.h, TEAM; SDPLR_HIP_TEAM, default 2): every member forms the whole
+    # a team of W workgroups per instance (k_resident.h, TEAM; SDPLR_HIP_TEAM, default 3): every member forms the whole
     # direction (9N each), the SpMM, the line search and STEP are shared out
-    team = max(1, min(4, int(os.environ.get("SDPLR_HIP_TEAM", "2")))) if dd["n"] >= 128 else 1
+    team = max(1, min(4, int(os.environ.get("SDPLR_HIP_TEAM", "3")))) if dd["n"] >= 128 else 1
     it_bytes = 9 * Ns * team + (2 * Ns + ell_bytes) + 15 * Ns
     one.close()
     out["config5_batch64"]["roofline"] = {

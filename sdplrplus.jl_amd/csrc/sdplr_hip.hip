@@ -859,7 +859,9 @@ constexpr size_t RS_LDS_MAX = 150 * 1024;   // dynamic LDS of a resident kernel 
 int rs_team_want(const S* s) {
   if (s->no_team) return 1;
   const char* e = getenv("SDPLR_HIP_TEAM");
-  const int want = e ? atoi(e) : 2;   // (two: a 64-instance batch still fits the GPU twice over; four gains another 13 % per iteration)
+  // (three: a 64-instance batch — 192 workgroups — is still co-resident on the 256 CUs, lockstep calls 26.9 → 25.3 ms against two;
+  // four — 29 µs per iteration alone — needs every CU of the GPU for such a batch and loses: 33.6 ms)
+  const int want = e ? atoi(e) : 3;
   if (want < 2 || s->n < 128 || s->h < 1 || s->h > 4 || s->no_pdrop || s->ff.gid_g != (int)s->m) return 1;
   return std::min(want, SDPLR_RS_TEAM_MAX);
 }

@@ -478,10 +478,10 @@ def test_major_iteration_is_the_sequence_it_stands_for(hip_abi, oracle_abi, upda
         s_.close()
 
 
-@pytest.mark.parametrize("W", [2, 4])
+@pytest.mark.parametrize("W", [2, 3, 4])
 @pytest.mark.parametrize("r", [10, 7])
 def test_resident_team_matches_the_single_workgroup_loop(hip_abi, oracle_abi, monkeypatch, W, r):
-    """SDPLR_HIP_TEAM=W (default 2; 1: none): W workgroups of one XCD share an instance inside the resident loop (k_resident.h, TEAM) — every
+    """SDPLR_HIP_TEAM=W (default 3; 1: none): W workgroups of one XCD share an instance inside the resident loop (k_resident.h, TEAM) — every
     member forms the direction, each takes its slices of the SpMM and its rows of the line search, the commit and STEP;
     Gram / norm partials, the rows of W with their dots and the ten line-search sums cross between them behind three team
     barriers per iteration.  Same iterates as the one-workgroup loop up to the order of those sums, and the oracle's to
@@ -548,7 +548,7 @@ def test_resident_team_with_a_rank_one_constraint(hip_abi, oracle_abi, monkeypat
     one, o = pair(hip_abi, oracle_abi, data, 10, 0)
     r1 = run(one, normC, normb, 10, one.fg(normC, normb))
     ro = run(o, normC, normb, 10, o.fg(normC, normb))
-    for W in (2, 4):
+    for W in (2, 3, 4):
         monkeypatch.setenv("SDPLR_HIP_TEAM", str(W))
         team = make_solver(hip_abi, data, 10, seed=0)[0]
         rt = run(team, normC, normb, 10, team.fg(normC, normb))
