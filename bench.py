@@ -374,7 +374,12 @@ def main():
                          "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                          "traffic": load_traffic(dominant),
                          "algorithmic_bytes_per_launch": per_kernel_bytes[dominant],
-                         "avg_launch_us": 1e6 * avg_s, "launches_timed": launches},
+                         "avg_launch_us": 1e6 * avg_s, "launches_timed": launches,
+                         # (the PMC bytes the kernel really moves over the same duration: what the memory system is doing)
+                         "traffic_GBps": (load_traffic(dominant) or 0) / avg_s / 1e9 if avg_s > 0 else None,
+                         "note": ("fast_step on the ring form of the L-BFGS history is charged R, D, W, G_old in and R, G out (6N): "
+                                  "s_j, y_j are not stored; the 6N of history its Gram dots re-read are this design's choice"
+                                  if dominant == "fast_step" and stats.get("ring_history_loops", 0) > 0 else None)},
             "iteration_roofline": {"achieved": b_iter * (K / dt_max) / 1e9, "peak": HBM_PEAK_GBPS,
                                    "unit": "GB/s", "frac": b_iter * (K / dt_max) / 1e9 / HBM_PEAK_GBPS},
             "kernels_eager_profile": kern,

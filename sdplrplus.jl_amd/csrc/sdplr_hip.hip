@@ -149,15 +149,14 @@ struct sdplr_hip_solver {
   int rs_ell_part_sl[SDPLR_RS_TEAM_MAX + 1] = {0, 0, 0, 0, 0};
   bool no_pdrop = false;     // SDPLR_HIP_NO_PDROP: the step kernel keeps P = A_g·R (P += α·W) instead of carrying G forward
   bool pdrop_now = false;    // this inner loop runs the P-less step kernel (decided at loop entry)
-  // Ring form of the history (k_dense.h): the P-less loop with the line-search head keeps (α_j, D_j) and (G_j, G_{j+1})
-  // instead of s_j, y_j — 2N bytes less written per iteration.  ring_on: the arena IS in ring form (from a loop that entered
-  // it on an empty history until something outside the loop needs the stored form: ensure_canonical, or lbfgs_clear!
-  // drops it).  The ring's scalars as the last loop left them are kept here for those two.
+  // Ring form of the history (k_dense.h): the singleton loops on the tile path keep (α_j, D_j) and (G_j, G_{j+1}) instead of
+  // s_j, y_j — 2N bytes less written per iteration.  ring_on: the arena IS in ring form (from a loop that entered it until
+  // something outside the loop needs the stored form: ensure_canonical, or lbfgs_clear! drops it).  The ring's scalars as the
+  // last loop left them are kept here for those two.
   bool no_ring = false;      // SDPLR_HIP_NO_RING
   bool ring_on = false, ring_now = false;
   int ring_k = 0, ring_n = 0, ring_unc = 0, ring_latest = 0, ring_j0 = 0;
   double ring_alpha[SDPLR_HMAX] = {};
-  bool hist_empty = false;   // every history slot is zero (lbfgs_clear! / a fresh handle) and nothing has written one since
   // G is the gradient at the device's (R, λ, σ) with y as its g! left it: true after fg! / g! / an inner loop, cleared by
   // every other entry point that enqueues work (NEED_FINAL_RW).  The P-less step kernel carries G forward incrementally
   // and needs that; when in doubt the loop takes the P-based kernel, which rebuilds G from P and y.
@@ -275,7 +274,6 @@ int blocks_for(long long work, int per_block, int cap);
     NEED_FINAL(s);                                         \
     (s)->hc_valid = false;                                 \
     (s)->G_consistent = false;                             \
-    (s)->hist_empty = false;                               \
     if ((s)->ring_on) {                                    \
       const int rc_r__ = ensure_canonical(s);              \
       if (rc_r__) return rc_r__;                           \
@@ -2187,7 +2185,6 @@ int32_t sdplr_hip_finalize(S* s) {
   HIPCK(s, hipStreamSynchronize(s->stream));
   lap("final sync");
   s->finalized = true;
-  s->hist_empty = !s->lit;   // (alloc_factors zero-filled the arena)
   return SDPLR_OK;
 }
 
@@ -2252,9 +2249,7 @@ int32_t sdplr_hip_reset_rank(S* s, int64_t new_r) {
   s->gram_dirty = s->sg_stale = s->ynext_pending = false;
   s->P_valid = false;
   s->S_stale = false;
-  rc = push(s);
-  s->hist_empty = (rc == SDPLR_OK) && !s->lit;   // (alloc_factors zero-fills the arena)
-  return rc;
+  return push(s);
 }
 
 // ================================================================================================
@@ -2264,7 +2259,6 @@ int32_t sdplr_hip_set_factor(S* s, int32_t slot, const double* h) {
   ApiShared api_guard(dev_of(s));
   NEED_FINAL(s);
   s->G_consistent = false;   // (the host writes state behind G's back)
-  if (slot >= SDPLR_F_LBFGS_S && slot < SDPLR_F_SCRATCH) s->hist_empty = false;
   { const int rc_r = ensure_canonical(s); if (rc_r) return rc_r; }
   { const int rc_d = ensure_dirt(s); if (rc_d) return rc_d; }
   double* p = factor_ptr(s, slot);
@@ -3530,9 +3524,7 @@ int set_norm_params(S* s, double normC, double normb, int grel, int prel) {
 extern "C" {
 int32_t sdplr_hip_fg(S* s, double normC, double normb, int32_t grel, int32_t prel, double* L, double* gn, double* pn) {
   ApiShared api_guard(dev_of(s));
-  const bool hist_was_empty = s && s->finalized && s->hist_empty;   // (fg! does not touch the history)
   NEED_FINAL_RW(s);
-  s->hist_empty = hist_was_empty;
   int rc = set_norm_params(s, normC, normb, grel, prel);
   if (rc) return rc;
   if (rs_fg_applies(s)) {   // resident route (k_resident.h): one launch; P = A_g·R stays for the loop that follows
@@ -3681,9 +3673,7 @@ int32_t sdplr_hip_lbfgs_clear(S* s) {
   memset(s->hc->c_alpha, 0, sizeof s->hc->c_alpha); memset(s->hc->c_gamma, 0, sizeof s->hc->c_gamma);
   s->gram_dirty = s->sg_stale = s->ynext_pending = false;  // zero vectors ⇒ zero Gram data, exact for any G
   s->hc->ring_on = 0;
-  rc = push(s);
-  s->hist_empty = (rc == SDPLR_OK) && !s->lit;
-  return rc;
+  return push(s);
 }
 int32_t sdplr_hip_lbfgs_dir(S* s, int32_t negate, double* descent) {
   ApiShared api_guard(dev_of(s));
@@ -3776,9 +3766,8 @@ static int32_t inner_loop_impl(S* s, double normC, double normb, int32_t grel, i
   // (the loop's first kernel after the seam overwrites dirt: a pending dirt ← s_latest is dropped, not made — unless the
   // loop turns out not to run a single iteration, see below)
   const int dirt_was_from = (s && s->finalized) ? s->dirt_from : -1;
-  // Ring form of the history (k_dense.h): entered on an empty history, kept across calls while nothing else has touched
-  // the arena.  Decided before NEED_FINAL_RW, which would turn a ring back into the stored form.
-  const bool hist_was_empty = s && s->finalized && s->hist_empty;
+  // Ring form of the history (k_dense.h): kept across calls while nothing else has touched the arena.  Decided before
+  // NEED_FINAL_RW, which would turn a ring back into the stored form.
   bool ring_keep = false;
   if (s && s->finalized && s->ring_on) {
     const bool fast2_ = s->fast && s->fast_singleton && !use_armijo;
@@ -3839,8 +3828,8 @@ static int32_t inner_loop_impl(S* s, double normC, double normb, int32_t grel, i
   // (a ring is entered on whatever history is stored: k_dense.h)
   s->ring_now = fast2 && (s->pdrop_now ? ring_shape_ok(s) : ring_shape_pb_ok(s));
   if (getenv("SDPLR_HIP_DEBUG"))
-    fprintf(stderr, "[sdplr_hip] inner_loop: ring %d (kept %d, history empty %d, pdrop %d, shape %d: can_drop %d n_extra %d VEC %d LPR %d tile %d/%d nb_tile %d)\n",
-            (int)s->ring_now, (int)ring_keep, (int)hist_was_empty, (int)s->pdrop_now, (int)ring_shape_ok(s), (int)step_can_drop_P(s), s->n_extra,
+    fprintf(stderr, "[sdplr_hip] inner_loop: ring %d (kept %d, pdrop %d, shape %d: can_drop %d n_extra %d VEC %d LPR %d tile %d/%d nb_tile %d)\n",
+            (int)s->ring_now, (int)ring_keep, (int)s->pdrop_now, (int)ring_shape_ok(s), (int)step_can_drop_P(s), s->n_extra,
             s->VEC, s->LPR, (int)s->use_tile, s->tile_lpr, s->nb_tile);
   if (s->ring_on && !s->ring_now) {   // (a ring kept for a loop that turns out not to take it)
     if ((rc = ensure_canonical(s))) return rc;
