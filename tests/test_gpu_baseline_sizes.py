@@ -359,3 +359,32 @@ def test_schedule_parity_at_baseline_size_minimum_bisection(hip_abi):
     assert a["obj"] == pytest.approx(b["obj"], rel=0.1)
     full = sj.sdplr(data=data, abi=hip_abi, **kw)
     assert full["primal_vio"] <= 1e-2 and full["min_duality_gap"] <= 1e-2 and full["majoriter"] < 100
+
+
+@pytest.mark.parametrize("which", ["maxcut_n1e5", "minbis_n1e5"])
+def test_ring_form_of_the_history_is_bitwise_the_stored_form_at_baseline_size(hip_abi, monkeypatch, which):
+    """The loop keeps lbfgshis.vecs[j].s / .y (src/lbfgs.jl:4-12) as (α_j, dir_j) and (G_j, G_{j+1}) (csrc/k_dense.h, "ring
+    form"; tests/test_gpu_ring.py on small instances): at the north-star size — full grids, hipGraph batches, the ring wrapped
+    five times — R, G, every s_j and y_j after 3 + 22 iterations equal the stored-form run (SDPLR_HIP_NO_RING) bit for bit."""
+    data, seed = _instance(which)
+    r, h = 32, 4
+    normC, normb = data.normC(), float(np.linalg.norm(data.b))
+    got = {}
+    for ring in (True, False):
+        if ring:
+            monkeypatch.delenv("SDPLR_HIP_NO_RING", raising=False)
+        else:
+            monkeypatch.setenv("SDPLR_HIP_NO_RING", "1")
+        s, _ = make_solver(hip_abi, data, r, seed=seed, h=h)
+        st = s.fg(normC, normb)
+        o1 = s.inner_loop(normC, normb, True, True, False, 0.0, -1e300, 3, 0.0, *st)
+        o2 = s.inner_loop(normC, normb, True, True, False, 0.0, -1e300, 22, 0.0, *o1[:3])
+        assert s.stats()["ring_history_loops"] == (2 if ring else 0)
+        got[ring] = (o1, o2, s.Rt, s.Gt, [s.get_factor(cabi.F_LBFGS_S + j) for j in range(h)],
+                     [s.get_factor(cabi.F_LBFGS_Y + j) for j in range(h)], s.get_factor(cabi.F_DIRT))
+        s.close()
+    a, b = got[True], got[False]
+    assert a[0] == b[0] and a[1] == b[1]
+    assert np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3]) and np.array_equal(a[6], b[6])
+    for j in range(h):
+        assert np.array_equal(a[4][j], b[4][j]) and np.array_equal(a[5][j], b[5][j]), j
