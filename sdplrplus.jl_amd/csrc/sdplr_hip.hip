@@ -1649,11 +1649,25 @@ int32_t sdplr_hip_set_sparse_coo(S* s, int64_t base, int64_t n_sparse, const int
       int64_t cum = start;
       for (int64_t k = kcut[t]; k < kcut[t + 1]; k++) {
         if (fill) { s->h_matptr[k] = (int)cum; s->h_gids[k] = (int)(gids[k] - base); }
+        // (a matrix's entries usually come column by column with ascending rows — findnz order — and so do the pattern's:
+        // the position is then found by walking a cursor along the column instead of a binary search per entry)
+        int pcol = -1, prow = -1, cur = 0;
+        const bool walk = ent_ptr[k + 1] - ent_ptr[k] > 4;       // (a singleton's diagonal entry is the LAST of its column: searched)
         for (int64_t e = ent_ptr[k] - base; e < ent_ptr[k + 1] - base; e++) {
           const int i = (int)(I[e] - base), j = (int)(J[e] - base);
           if (i > j) continue;                                   // triu keeps i ≤ j (:9)
           if (fill) {
-            s->h_nzind[cum] = find_triu(j, i);
+            int pos;
+            if (j != pcol) { pcol = j; prow = -1; cur = tcp[j]; }
+            if (!walk || i < prow) {
+              pos = find_triu(j, i);
+            } else {
+              const int end = tcp[j + 1];
+              while (cur < end && trv[cur] < i) cur++;
+              pos = (cur < end && trv[cur] == i) ? cur : -1;
+              prow = i;
+            }
+            s->h_nzind[cum] = pos;
             s->h_one[cum] = V[e];
             s->h_two[cum] = (i == j) ? V[e] : 2.0 * V[e];         // off-diagonal entries count twice (:121-128)
           }
@@ -1682,6 +1696,24 @@ int32_t sdplr_hip_set_sparse_coo(S* s, int64_t base, int64_t n_sparse, const int
   // ARE column j of the triu pattern, in order; a lower entry (i > j) is searched in column i ----
   s->h_mapped.resize(nnzS);
   std::atomic<int> missing{0};
+  if (n <= 4096) {
+    // (one chunk: the lower entries of successive columns j ask column i of the triu pattern for ascending rows j — a cursor
+    // per column that only moves forward, instead of a binary search per entry)
+    std::vector<int> cursor(tcp.begin(), tcp.end() - 1);
+    for (int64_t j = 0; j < n; j++) {
+      int up = tcp[j];
+      for (int p = fcp[j]; p < fcp[j + 1]; p++) {
+        const int i = frv[p];
+        if (i <= (int)j) { s->h_mapped[p] = up++; continue; }
+        int& c = cursor[i];
+        const int end = tcp[i + 1];
+        while (c < end && trv[c] < (int)j) c++;
+        const int q = (c < end && trv[c] == (int)j) ? c : -1;
+        if (q < 0) missing.store(1, std::memory_order_relaxed);
+        s->h_mapped[p] = q;
+      }
+    }
+  } else
   parallel_for(n, 4096, [&](int64_t j0, int64_t j1) {
     for (int64_t j = j0; j < j1; j++) {
       int up = tcp[j];
@@ -2150,7 +2182,11 @@ int32_t sdplr_hip_finalize(S* s) {
     H.env_ch = envi("SDPLR_HIP_LZBAND_CH"); H.env_nc = envi("SDPLR_HIP_LZBAND_NC");
     H.env_no_band = getenv("SDPLR_HIP_NO_LZBAND") != nullptr; H.env_no_pal = getenv("SDPLR_HIP_NO_LZPAL") != nullptr;
   }
-  if (getenv("SDPLR_HIP_BAND_SYNC") != nullptr) {
+  // (no thread for an instance the plan does not apply to — n < 2¹⁴: band_host returns at once — a batch of small instances
+  // would start and join one per instance for nothing)
+  const bool band_possible = s->have_sparse && s->nnzS > 0 && !s->band_host->env_no_band &&
+                             n >= (s->band_host->env_min_n > 0 ? s->band_host->env_min_n : (1 << 14));
+  if (getenv("SDPLR_HIP_BAND_SYNC") != nullptr || !band_possible) {
     band_host(s, *s->band_host);
   } else {
     S* sp_ = s;
