@@ -267,7 +267,10 @@ def main():
     dist = None
     if world > 1 or os.environ.get("SDPLR_BENCH_FORCE_DIST") or os.environ.get("SDPLR_BENCH_FORCE_LAUNCH"):
         # torch first: its wheel bundles a HIP runtime with the same SONAME as /opt/rocm's, and whichever is
-        # loaded first serves both torch and libsdplr_hip.so — one runtime per process either way
+        # loaded first serves both torch and libsdplr_hip.so — one runtime per process either way.  (The wheel's runtime is
+        # the older one — HIP 7.0 against /opt/rocm's 7.2 — and replays the iteration graphs ≈ 2.4 µs per kernel boundary
+        # slower: 5865 against 6210 it/s on one GPU with identical kernel times, DESIGN §7.  The other order — the library
+        # and /opt/rocm's runtime first — was tried: the rank dies while torch initialises.)
         import torch
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
