@@ -258,3 +258,53 @@ def test_ring_left_by_the_time_budget_and_by_a_loop_that_does_not_start(hip_abi)
         assert np.array_equal(a["S"][j], b["S"][j]) and np.array_equal(a["Y"][j], b["Y"][j])
     assert np.array_equal(b["D"], a["D"])
     s_.close()
+
+
+@pytest.mark.parametrize("fresh_g", [False, True])
+def test_ring_takes_the_steepest_descent_fallback(hip_abi, oracle_abi, monkeypatch, fresh_g):
+    """src/sdplr.jl:201-205 on the ring form: the seam kernel finds ⟨dir, G⟩ ≥ 0 from the Gram data and k_lbfgs_dir_ring writes
+    −G — leaving G itself unflipped (the flip of :203 is undone by y_j = G_new − G_old in the stored form; on a ring nothing
+    reads G in between).  The newest stored pair is replaced by (s = G, y = 0, ρ ≪ 0) as in
+    test_inner_loop_takes_the_steepest_descent_fallback; the next loop enters a ring on that history and falls back in its
+    first iteration — on the P-based step kernel (the host wrote behind G's back) and, after a fresh g!, on the P-less one.
+    Bitwise the stored form, 1e-8 the oracle."""
+    data = problems.maxcut_data(problems.gnp_graph(200, 0.06, 17))
+    normC, normb = data.normC(), float(np.linalg.norm(data.b))
+    r, h = 8, 4
+
+    def run(abi, ring):
+        if ring:
+            monkeypatch.delenv("SDPLR_HIP_NO_RING", raising=False)
+        else:
+            monkeypatch.setenv("SDPLR_HIP_NO_RING", "1")
+        s_, _ = make_solver(abi, data, r, seed=5, h=h)
+        st = s_.inner_loop(normC, normb, True, True, False, 0.0, -1e300, h + 2, 0.0, *s_.fg(normC, normb))[:3]
+        j = int(s_.get_scalar(cabi.S_LBFGS_LATEST)) - 1
+        G = s_.Gt
+        s_.set_factor(cabi.F_LBFGS_S + j, G)
+        s_.set_factor(cabi.F_LBFGS_Y + j, np.zeros_like(G))
+        rho = s_.get_vec(cabi.V_LBFGS_RHO)
+        rho[j] = -1e6 / float(np.sum(G * G))
+        s_.set_vec(cabi.V_LBFGS_RHO, rho)
+        if fresh_g:
+            s_.g()
+        outs = []
+        for k in (1, 1, 6):
+            out = s_.inner_loop(normC, normb, True, True, False, 0.0, -1e300, k, 0.0, *st)
+            st = out[:3]
+            outs.append(out)
+        a = _state(s_, h)
+        stats = s_.stats() if abi is hip_abi else None
+        s_.close()
+        return outs, a, stats
+
+    o_r, a_r, st = run(hip_abi, True)
+    o_s, a_s, _ = run(hip_abi, False)
+    assert st["ring_history_loops"] == 4
+    assert o_r == o_s
+    _same(a_r, a_s)
+    o_o, a_o, _ = run(oracle_abi, False)
+    # the first step is a steepest-descent one: α·‖G‖² = −⟨dir, G⟩·α, far from the L-BFGS step it replaces
+    for x, z in zip(o_r, o_o):
+        assert x[4] == z[4] and np.allclose(x[:3], z[:3], rtol=1e-8)
+    assert rel(a_r["R"], a_o["R"]) < 1e-8
