@@ -87,6 +87,20 @@ __device__ __forceinline__ void strow(double* __restrict__ p, const vecd<VEC>& o
   }
 }
 
+// non-temporal row store (experiments: -DSDPLR_RING_NT_G / -DSDPLR_RING_NT_R)
+template <int VEC>
+__device__ __forceinline__ void strow_nt(double* __restrict__ p, const vecd<VEC>& o) {
+  if constexpr (VEC == 2) {
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    d2 t;
+    t.x = o.v[0];
+    t.y = o.v[VEC - 1];
+    __builtin_nontemporal_store(t, reinterpret_cast<d2*>(p));
+  } else {
+    __builtin_nontemporal_store(o.v[0], p);
+  }
+}
+
 #ifndef SDPLR_STEP_TR
 #define SDPLR_STEP_TR 4   /* rows per tile of k_fast_step2 (2: 4541, 4: 4565, 8: 4458, 16: 4389 it/s on the north-star instance) */
 #endif
@@ -1388,8 +1402,16 @@ k_fast_step_ring(int n, int m, DevFast ff, double* __restrict__ R, const double*
             red[0] += g.v[q] * g.v[q];
           }
         }
+#ifdef SDPLR_RING_NT_R
+        strow_nt<VEC>(rowat(R, off[u]), x);
+#else
         strow<VEC>(rowat(R, off[u]), x);
+#endif
+#ifdef SDPLR_RING_NT_G
+        strow_nt<VEC>(rowat(Gnew, off[u]), g);
+#else
         strow<VEC>(rowat(Gnew, off[u]), g);
+#endif
         if (upd) {
           vecd<VEC> sn, yn;
 #pragma unroll
