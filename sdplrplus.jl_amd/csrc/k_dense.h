@@ -11,7 +11,9 @@
 // instead of the reference's 2h dependent dot/axpy sweeps (48 N of traffic at h = 4).  The Gram
 // rows of the newest pair and the dots with the new gradient are accumulated by the pass that
 // writes the pair (k_lbfgs_update, src/lbfgs.jl:129-149) — direct dots on the stored vectors, no
-// differences of dots.  The history vectors themselves are kept exactly as the reference keeps them.
+// differences of dots.  The history vectors themselves are kept exactly as the reference keeps them — outside the loop;
+// inside it the singleton loops keep them as the arrays they are functions of ("ring form" below): the same values, formed
+// on the fly.
 #pragma once
 #include "common.h"
 
