@@ -14,6 +14,9 @@
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
 #define OK 0
 #define ERR_INVALID (-1)
@@ -392,8 +395,33 @@ int32_t sdplr_oracle_get_dims(const S* s, int64_t* n, int64_t* m, int64_t* r, in
  * reports beside the one-thread number; tests/test_oracle_omp.py checks that build
  * against this one. */
 static double ddot(int64_t N, const double* x, const double* y) {
+#ifdef _OPENMP
+  /* all-cores timing build only: every thread sums one contiguous range and the ranges' sums are added in thread order,
+   * so that the result does not depend on which thread finishes first (an OpenMP `reduction` combines in arrival order:
+   * two runs of the same solve took different numbers of major iterations on MinBisection n = 1e5) */
+  if (N > 65536) {
+    enum { MAXT = 512 };
+    double part[MAXT];
+    int used = 1;
+#pragma omp parallel
+    {
+      const int t = omp_get_thread_num();
+      int T = omp_get_num_threads();
+      if (T > MAXT) T = MAXT;
+      if (t < T) {
+        const int64_t lo = N * t / T, hi = N * (t + 1) / T;
+        double a = 0.0;
+        for (int64_t i = lo; i < hi; i++) a += x[i] * y[i];
+        part[t] = a;
+      }
+      if (t == 0) used = T;
+    }
+    double acc = 0.0;
+    for (int t = 0; t < used; t++) acc += part[t];
+    return acc;
+  }
+#endif
   double acc = 0.0;
-#pragma omp parallel for reduction(+ : acc) schedule(static) if (N > 65536)
   for (int64_t i = 0; i < N; i++) acc += x[i] * y[i];
   return acc;
 }
