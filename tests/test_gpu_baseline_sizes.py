@@ -343,8 +343,8 @@ def test_schedule_parity_at_baseline_size_maxcut(hip_abi):
 def test_schedule_parity_at_baseline_size_minimum_bisection(hip_abi):
     """MinBisection n = 1e5, r = 32: the landscape is flat, the inner loops stop on a coarse gradient test, and the count of
     inner iterations per major iteration — with it the later σ decisions — is sensitive to round-off (on the same inputs:
-    HIP 19 major iterations to convergence, the OpenMP oracle 30, and the OpenMP oracle differs from itself run to run:
-    measured).  The comparison with the oracle therefore covers the first four major iterations — identical σ/η/ω/rank
+    HIP 16–19 major iterations to convergence, the OpenMP oracle 30; until its dot product was made to add the threads' sums
+    in thread order the OpenMP oracle even differed from itself run to run).  The comparison with the oracle therefore covers the first four major iterations — identical σ/η/ω/rank
     schedule, objectives within 10 % of each other — and the full solve is checked on its own terms: stop by the gap test
     within the reference's tolerances (src/sdplr.jl:335-345)."""
     n = 100_000
