@@ -308,3 +308,19 @@ def test_ring_takes_the_steepest_descent_fallback(hip_abi, oracle_abi, monkeypat
     for x, z in zip(o_r, o_o):
         assert x[4] == z[4] and np.allclose(x[:3], z[:3], rtol=1e-8)
     assert rel(a_r["R"], a_o["R"]) < 1e-8
+
+
+def test_random_call_sequences_on_a_ring_handle_and_a_stored_form_handle(hip_abi):
+    """scripts/stress_ring.py, 25 sequences: random interleavings of loops (every kind of exit), lbfgs_clear!, fg!, g!, the
+    dual bound, the λ update, major_iteration, looks at and writes to G / the history / λ, stand-alone lbfgs_dir! and
+    lbfgs_update!, a line search and a rank reset — on two handles of the same instance, one keeping the history in ring
+    form inside its loops, one storing it: equal bit for bit after every call and in full at the end."""
+    import importlib.util
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts", "stress_ring.py")
+    spec = importlib.util.spec_from_file_location("_stress_ring", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    bad, degenerate, ring_loops, mats = mod.run(7, 25, hip=hip_abi, nmax=500)
+    assert bad == 0
+    assert ring_loops >= 25 and mats >= 10      # (the sweep did exercise the hand-overs)
